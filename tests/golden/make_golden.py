@@ -1,0 +1,430 @@
+"""Generate the golden vectors under tests/golden/ by importing the reference's modules.
+
+Runs ONLY in the build container (needs /root/reference); nothing here travels to the
+GPU box except the .npz/.json files it writes.  The reference is imported unmodified;
+third-party imports it never calls on this path (spatialmath, termcolor, minari,
+diffusers) are satisfied with empty in-memory placeholder modules.  ``car_env`` (casadi,
+gymnasium) and ``local_map_encoder`` (torchvision) cannot be imported here, so the
+dynamics and the ResNet encoder have no executable reference: see oracle/__init__.py.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz, *.json
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+
+def _placeholders():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+    mod("spatialmath")
+    mod("spatialmath.base", r2q=None)
+    mod("spatialmath.base.transforms3d", isrot=None)
+    mod("termcolor", cprint=print)
+    mod("minari")
+    mod("diffusers")
+    mod("diffusers.schedulers")
+    mod("diffusers.schedulers.scheduling_ddpm", DDPMScheduler=object)
+
+
+_placeholders()
+import common.map_utils as ref_mu                                   # noqa: E402
+from common.fm_utils import get_timesteps as ref_get_timesteps      # noqa: E402
+from lidar_sim.lidar_2d_sim import Lidar2DSim as RefLidar           # noqa: E402
+from model.diffusion.conditional_unet1d import ConditionalUnet1D as RefUnet   # noqa: E402
+import policies.fm_policy as ref_fm                                  # noqa: E402
+import planners.RRT as ref_rrt                                       # noqa: E402
+import planners.base_planner as ref_bp                               # noqa: E402
+
+from oracle import geometry as G                                     # noqa: E402
+from oracle import rrt as ORRT                                       # noqa: E402
+from oracle import sampler as OS                                     # noqa: E402
+from oracle import denoiser as OD                                    # noqa: E402
+from oracle.tapes import ActionTape                                  # noqa: E402
+
+MAZE_DIR = os.path.join(REF, "maps", "mazes")
+
+
+def load_maze(name):
+    return np.loadtxt(os.path.join(MAZE_DIR, f"{name}.csv"), delimiter=",")
+
+
+def random_poses(rng, maze, n, boundary_frac=0.25, oob_frac=0.05):
+    H, W = maze.shape
+    x = rng.uniform(-W / 2, W / 2, n)
+    y = rng.uniform(-H / 2, H / 2, n)
+    th = rng.uniform(-np.pi, np.pi, n)
+    nb = int(n * boundary_frac)
+    # snap a fraction onto / next to cell boundaries
+    x[:nb] = np.round(x[:nb]) + rng.choice([0.0, 1e-12, -1e-12, 0.1, -0.1, 0.025], nb)
+    y[nb:2 * nb] = np.round(y[nb:2 * nb]) + rng.choice([0.0, 1e-12, -1e-12, 0.1, -0.1, 0.025], nb)
+    no = int(n * oob_frac)
+    if no > 0:
+        x[-no:] = rng.uniform(-W / 2 - 1, W / 2 + 1, no)
+        y[-no:] = rng.uniform(-H / 2 - 1, H / 2 + 1, no)
+    return np.stack([x, y, th], axis=1)
+
+
+def gen_collision(out):
+    rng = np.random.default_rng(101)
+    for name in ("Race_Track", "boxes", "random_huge", "narrow_short"):
+        maze = load_maze(name)
+        poses = random_poses(rng, maze, 4096)
+        exp = np.array([bool(ref_mu.is_colliding_car(p, maze)) for p in poses])
+        mine = G.is_colliding_car(poses, maze)
+        assert (exp == mine).all(), f"oracle collision mismatch on {name}: {np.nonzero(exp != mine)[0][:10]}"
+        out[f"collision_{name}_poses"] = poses
+        out[f"collision_{name}_expected"] = exp
+        print(f"collision {name}: {exp.mean():.3f} colliding, oracle == reference")
+
+
+def gen_local_map(out):
+    rng = np.random.default_rng(102)
+    for name in ("Race_Track", "boxes", "random_huge"):
+        maze = np.float32(load_maze(name))
+        H, W = maze.shape
+        poses = random_poses(rng, maze, 256, boundary_frac=0.1, oob_frac=0.0)
+        center = (W / 2, H / 2)
+        for tag, (n, scale, sg) in {"car": (20, 0.2, 1.0), "ant": (16, 0.8, 4.0)}.items():
+            exp = np.concatenate([ref_mu.create_local_map(maze, p[0] * sg, p[1] * sg, p[2] if tag == "car" else 0.0,
+                                                          n, scale, sg, (center[0] * sg, center[1] * sg))
+                                  for p in poses])
+            th = poses[:, 2] if tag == "car" else np.zeros(len(poses))
+            mine = G.create_local_map(maze, poses[:, 0] * sg, poses[:, 1] * sg, th, n, scale, sg,
+                                      (center[0] * sg, center[1] * sg))
+            assert exp.dtype == np.float32 and (exp == mine).all(), f"local map mismatch {name} {tag}"
+            out[f"localmap_{name}_{tag}_poses"] = poses
+            out[f"localmap_{name}_{tag}_expected"] = np.packbits(exp.astype(np.uint8), axis=None)
+        print(f"local map {name}: oracle == reference")
+
+
+class _RecordingNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.calls = []
+
+    def forward(self, sample, local_map, timestep, global_cond):
+        self.calls.append(dict(sample=sample.clone(), local_map=local_map.clone(),
+                               timestep=timestep.clone(), cond=global_cond.clone()))
+        return 0.25 * sample + 0.5          # any deterministic velocity
+
+
+def _ref_sampler(net, k_iters=1):
+    """DiffusionSampler without its __init__ (which unpickles metadata/*.pt with
+    weights_only=False -- not allowed here); attributes set as run_scenarios.py:179-185."""
+    s = ref_fm.DiffusionSampler.__new__(ref_fm.DiffusionSampler)
+    torch.nn.Module.__init__(s)
+    s.device = "cpu"
+    s.metadata = {k: v.copy() for k, v in OS.CAR_META.items()}
+    s.action_dim, s.prediction_type, s.env_id, s.policy = 2, "actions", "carmaze", "flow_matching"
+    s.num_diffusion_iters, s.pred_horizon, s.obs_history, s.action_history = k_iters, 64, 1, 1
+    s.position_conditioned, s.goal_conditioned, s.local_map_conditioned = False, True, True
+    s.local_map_size = 20
+    s.noise_pred_net, s.noise_scheduler = net, None
+    return s
+
+
+def gen_sampler(out):
+    rng = np.random.default_rng(103)
+    maze = np.float32(load_maze("boxes"))
+    n = 64
+    states = np.stack([rng.uniform(-9, 9, n), rng.uniform(-9, 9, n), rng.uniform(-np.pi, np.pi, n),
+                       rng.uniform(-1, 5, n), rng.uniform(-1, 1, n), rng.uniform(-0.4, 0.4, n)], axis=1)
+    prev = np.stack([rng.uniform(-10, 10, n), rng.uniform(-2, 2, n)], axis=1)
+    has_prev = rng.random(n) < 0.7
+    goals = np.stack([rng.uniform(-9, 9, n), rng.uniform(-9, 9, n)], axis=1)
+    conds, acts, noises, maps = [], [], [], []
+    for i in range(n):
+        net = _RecordingNet()
+        smp = _ref_sampler(net)
+        lm = ref_mu.create_local_map(maze, states[i, 0], states[i, 1], states[i, 2], 20, 0.2, 1.0, (10.0, 10.0))
+        torch.manual_seed(1000 + i)
+        # history of 3 observations: only the last one may matter (obs_history = 1)
+        hist = np.stack([states[(i + 1) % n], states[(i + 2) % n], states[i]])[None]
+        pa = np.stack([prev[(i + 1) % n], prev[i]])[None] if has_prev[i] else None
+        a = smp(hist, prev_actions=pa, goal=goals[i], local_map=torch.tensor(lm))
+        c = net.calls[0]
+        assert float(c["timestep"][0]) == 0.0 and len(net.calls) == 1
+        assert (c["local_map"].numpy() == OS.scale_local_map(lm)).all()
+        conds.append(c["cond"].numpy()[0])
+        noises.append(c["sample"].numpy()[0])
+        acts.append(a[0])
+        maps.append(lm[0])
+    conds, acts, noises = np.array(conds), np.array(acts), np.array(noises)
+    mine = OS.car_cond_vector(states, prev, has_prev, goals)
+    err = np.abs(mine - conds).max()
+    assert err < 2e-7, err
+    x1 = noises + (0.25 * noises + 0.5) * 1.0
+    assert np.abs(OS.unnormalize_actions(x1.astype(np.float32)) - acts).max() < 1e-6
+    out.update(sampler_states=states, sampler_prev=prev, sampler_has_prev=has_prev, sampler_goals=goals,
+               sampler_cond_expected=conds, sampler_noise=noises, sampler_actions_expected=acts)
+    print(f"sampler pre/post: oracle vs reference max |d cond| = {err:.2e}")
+
+
+def gen_timesteps(out_json):
+    res = {}
+    for k in (1, 2, 4, 5, 8, 16):
+        t0, dt = ref_get_timesteps("exp", k, 4.0)
+        m0, md = OS.get_timesteps("exp", k, 4.0)
+        assert torch.equal(t0, m0) and torch.equal(dt, md)
+        res[str(k)] = {"t0": [float(v) for v in t0], "dt": [float(v) for v in dt]}
+    out_json["get_timesteps_exp_4"] = res
+    print("get_timesteps: oracle == reference")
+
+
+def gen_unet(out):
+    for tag, (inp, gcd, P) in {"car": (2, 407, 64), "ant": (8, 497, 16)}.items():
+        torch.manual_seed(7)
+        ref = RefUnet(input_dim=inp, global_cond_dim=gcd, down_dims=[512, 1024, 2048]).eval()
+        torch.manual_seed(7)
+        mine = OD.OracleUnet1D(inp, gcd).eval()
+        rs, ms = ref.state_dict(), mine.state_dict()
+        assert set(rs) == set(ms), set(rs) ^ set(ms)
+        for k in rs:
+            assert torch.equal(rs[k], ms[k]), k
+        g = torch.Generator().manual_seed(11)
+        B = 4
+        x = torch.randn(B, P, inp, generator=g)
+        cond = torch.randn(B, gcd, generator=g) * 0.5
+        ts = torch.tensor([0.0, 0.0, 3.7, 12.5])
+        with torch.no_grad():
+            y_ref = ref(x, ts, global_cond=cond)
+            y_mine = mine(x, ts, cond)
+        err = (y_ref - y_mine).abs().max().item()
+        assert err < 1e-5, err
+        n_par = sum(p.numel() for p in ref.parameters())
+        cks = {k: float(v.double().sum()) for k, v in list(rs.items())[:8]}
+        out[f"unet_{tag}_x"] = x.numpy()
+        out[f"unet_{tag}_cond"] = cond.numpy()
+        out[f"unet_{tag}_t"] = ts.numpy()
+        out[f"unet_{tag}_y_expected"] = y_ref.numpy()
+        out[f"unet_{tag}_nparams"] = np.array(n_par)
+        out[f"unet_{tag}_wsum"] = np.array(sum(float(v.double().sum()) for v in rs.values()))
+        print(f"unet {tag}: {n_par} params, seeded weights identical, max |dy| = {err:.2e}", cks and "")
+        del ref, mine
+
+
+def gen_lidar(out):
+    rng = np.random.default_rng(104)
+    maze = load_maze("boxes")
+    lid = RefLidar()
+    assert (lid.angles_deg == G.LIDAR_ANGLES_DEG).all()
+    free = np.argwhere(maze == 0)
+    pick = free[rng.choice(len(free), 64, replace=False)]
+    poses = np.stack([pick[:, 1] + rng.uniform(0.05, 0.95, 64), pick[:, 0] + rng.uniform(0.05, 0.95, 64),
+                      rng.uniform(-np.pi, np.pi, 64)], axis=1)
+    D, E, V, Hh = [], [], [], []
+    for p in poses:
+        d, e, v = lid.scan(p, maze)
+        md, me, mv, mh = G.lidar_scan(p, maze)
+        assert np.array_equal(d, md) and np.array_equal(e, me) and np.array_equal(v, mv)
+        D.append(d), E.append(e), Hh.append(mh)
+        vis = np.zeros(maze.shape, dtype=np.uint8)
+        vis[v[:, 1], v[:, 0]] = 1
+        V.append(vis)
+    out.update(lidar_boxes_poses=poses, lidar_boxes_dist=np.array(D), lidar_boxes_end=np.array(E),
+               lidar_boxes_visited=np.packbits(np.array(V), axis=None), lidar_boxes_hit=np.array(Hh))
+    # the reference's own demo map, lidar_2d_sim.py:137-148
+    demo = np.zeros((100, 100))
+    demo[30:70, 40] = 1
+    demo[50, 20:80] = 1
+    demo[10:20, 10:20] = 1
+    p = np.array([10.0, 80.0, 90.0])
+    d, e, v = lid.scan(p, demo)
+    md, me, mv, _ = G.lidar_scan(p, demo)
+    assert np.array_equal(d, md) and np.array_equal(e, me) and np.array_equal(v, mv)
+    out.update(lidar_demo_dist=d, lidar_demo_end=e)
+    print("lidar: oracle == reference (64 poses on boxes + demo map)")
+
+
+def gen_kdtree(out):
+    from scipy.spatial import KDTree
+    rng = np.random.default_rng(105)
+    for n in (1, 17, 1000):
+        nodes = rng.uniform(-10, 10, (n, 2))
+        q = rng.uniform(-10, 10, (1024, 2))
+        _, idx = KDTree(nodes).query(q, k=1)
+        mine = G.nn_argmin(q, nodes)
+        assert (idx == mine).all()
+        out[f"kdtree_{n}_nodes"] = nodes
+        out[f"kdtree_{n}_queries"] = q
+        out[f"kdtree_{n}_expected"] = idx.astype(np.int32)
+    print("kd-tree nearest: oracle == scipy KDTree")
+
+
+def gen_dynamics(out):
+    """Independent FP64 evaluation of car_env.py:376-390 written with python floats and
+    math.* (not the numpy oracle).  Self-referential: car_env cannot execute here."""
+    import math
+    rng = np.random.default_rng(106)
+
+    def step(s, a):
+        x, y, psi, v, D, dl = s
+        a0 = min(max(a[0], -10.0), 10.0)
+        a1 = min(max(a[1], -2.0), 2.0)
+        Fxd = (0.28 - 0.05 * v) * D - 0.006 * (v ** 2) - 0.011 * math.tanh(5.0 * v)
+        dot = [v * math.cos(psi + 0.5 * dl), v * math.sin(psi + 0.5 * dl), v * 15.5 * dl,
+               (Fxd / 0.043) * math.cos(0.5 * dl), a0, a1]
+        return [s[i] + (1.0 / 50.0) * dot[i] for i in range(6)]
+
+    S0 = np.stack([rng.uniform(-5, 5, 32), rng.uniform(-5, 5, 32), rng.uniform(-np.pi, np.pi, 32),
+                   rng.uniform(-2, 5, 32), rng.uniform(-1, 1, 32), rng.uniform(-0.4, 0.4, 32)], axis=1)
+    S0[0, 3:] = 0.0                      # v = 0: only D, delta change
+    S0[1, 5] = 0.0                       # delta = 0: straight line
+    Aseq = np.stack([rng.uniform(-12, 12, (32, 64)), rng.uniform(-3, 3, (32, 64))], axis=2)
+    traj = np.zeros((32, 65, 6))
+    for b in range(32):
+        s = list(S0[b])
+        traj[b, 0] = s
+        for i in range(64):
+            s = step(s, Aseq[b, i])
+            traj[b, i + 1] = s
+    mine = np.zeros_like(traj)
+    cur = S0.copy()
+    mine[:, 0] = cur
+    for i in range(64):
+        cur = G.car_step(cur, Aseq[:, i])
+        mine[:, i + 1] = cur
+    err = np.abs(mine - traj).max()
+    assert err < 1e-9, err
+    # closed forms
+    s1 = G.car_step(S0[0], Aseq[0, 0])
+    assert s1[0] == S0[0, 0] and s1[1] == S0[0, 1] and s1[2] == S0[0, 2] and s1[3] == 0.0
+    out.update(dyn_s0=S0, dyn_actions=Aseq, dyn_traj_expected=traj)
+    print(f"dynamics known-answer: oracle vs independent evaluation max err {err:.2e} (self-referential)")
+
+
+# --------------------------------------------------------------------------- planner traces
+class _TapeSampler(torch.nn.Module):
+    """nn.Module so that BasePlanner keeps it (base_planner.py:56-57)."""
+
+    def __init__(self, tape: ActionTape, counter):
+        super().__init__()
+        self.tape, self.counter = tape, counter
+        self.chunk = 0
+        self.last_cand = -1
+
+    def forward(self, prev_states, prev_actions=None, goal=None, local_map=None):
+        cand = self.counter["cand"] - 1
+        if cand != self.last_cand:
+            self.chunk, self.last_cand = 0, cand
+        a = self.tape.actions(np.array([cand]), self.chunk)
+        self.chunk += 1
+        return a
+
+
+def run_reference_planner(scn, n_candidates, tape_seed):
+    name, maze_name, sr, sc, sdeg, gr, gc = scn
+    maze = load_maze(maze_name)
+    env = ORRT.OracleCarEnv(maze_map=maze, collision_checking=False)
+    start_xy = env.cell_rowcol_to_xy(np.array([sr, sc]))
+    goal_xy = env.cell_rowcol_to_xy(np.array([gr, gc]))
+    start = np.array([start_xy[0], start_xy[1], np.deg2rad(float(sdeg)), 0.0, 0.0, 0.0])
+    goal = np.array([goal_xy[0], goal_xy[1], 0.0, 0.0, 0.0, 0.0])
+    counter = {"cand": 0}
+    tape = ActionTape(tape_seed)
+    smp = _TapeSampler(tape, counter)
+    import random
+    random.seed(42)
+    np.random.seed(42)
+    planner = ref_rrt.RRT_Planner(start, goal, env_id="carmaze", environment=env, sampler=smp,
+                                  prediction_type="actions", action_horizon=8, local_map_size=20,
+                                  local_map_scale=0.2, global_map_scale=1.0, goal_conditioning_bias=0.85,
+                                  prop_duration=[64], time_budget=n_candidates, max_iter=300, verbose=False)
+    planner.device = "cpu"
+    orig_sample = planner.random_node_sample
+
+    def counted_sample(*a, **k):
+        counter["cand"] += 1
+        return orig_sample(*a, **k)
+    planner.random_node_sample = counted_sample
+    real_time = ref_rrt.time.time
+    ref_rrt.time.time = lambda: float(counter["cand"])       # budget = number of candidates
+    try:
+        planner.reset()
+        # planner.reset re-seeds nothing; seed again so the tape starts at the plan
+        random.seed(42)
+        np.random.seed(42)
+        path, actions = planner.plan()
+    finally:
+        ref_rrt.time.time = real_time
+    nodes = planner.node_list
+    index = {id(n): i for i, n in enumerate(nodes)}
+    parents = np.array([-1 if n.parent is None else index[id(n.parent)] for n in nodes], dtype=np.int32)
+    states = np.array([n.state for n in nodes])
+    reached = bool(env.done) and path is not None and bool(G.goal_reached(states[-1], env.goal))
+    return dict(maze=maze, start=start, goal=goal, parents=parents, states=states, reached=reached,
+                path=path, actions=actions, iterations=planner.results["iterations"],
+                candidates=counter["cand"])
+
+
+def gen_traces(out):
+    scns = {
+        "race": ("Race Track", "Race_Track", 1, 1, 270, 1, 10),
+        "boxes": ("boxes", "boxes", 17, 2, 45, 2, 17),
+        "rlarge2": ("random large2", "random_large", 1, 3, 0, 7, 10),
+        "easy": ("easy (build-defined)", "val_maze_7", 1, 1, 0, 1, 4),
+    }
+    budgets = {"race": 400, "boxes": 400, "rlarge2": 400, "easy": 600}
+    for tag, scn in scns.items():
+        seed = 2026
+        r = run_reference_planner(scn, budgets[tag], seed)
+        # the oracle planner on the same tapes, B = 1
+        pl = ORRT.OraclePlanner(r["maze"], r["start"], r["goal"], ActionTape(seed).sampler())
+        reached, path, actions = pl.plan(ORRT.RandomTape(42), budgets[tag], batch=1)
+        assert not pl.sticky_triggered, "trace hit the sticky-done defect; pick another seed"
+        t = pl.tree
+        assert reached == r["reached"], (tag, reached, r["reached"])
+        assert np.array_equal(np.array(t.parents, dtype=np.int32), r["parents"]), tag
+        assert np.array_equal(np.array(t.states), r["states"]), tag
+        assert pl.iterations == r["iterations"], (pl.iterations, r["iterations"])
+        assert np.array_equal(path, r["path"]) and np.array_equal(actions, r["actions"]), tag
+        out[f"trace_{tag}_scenario"] = np.array(scn[2:], dtype=np.int64)
+        out[f"trace_{tag}_maze_name"] = np.array(scn[1])
+        out[f"trace_{tag}_budget"] = np.array(budgets[tag])
+        out[f"trace_{tag}_tape_seed"] = np.array(seed)
+        out[f"trace_{tag}_parents"] = r["parents"]
+        out[f"trace_{tag}_states"] = r["states"]
+        out[f"trace_{tag}_reached"] = np.array(r["reached"])
+        out[f"trace_{tag}_path"] = r["path"]
+        out[f"trace_{tag}_actions"] = r["actions"]
+        out[f"trace_{tag}_iterations"] = np.array(r["iterations"])
+        print(f"trace {tag}: {len(r['parents'])} nodes, reached={r['reached']}, "
+              f"{r['iterations']} chunk-iterations, oracle planner == reference planner")
+
+
+def main():
+    geo, net, traces, meta = {}, {}, {}, {}
+    gen_collision(geo)
+    gen_local_map(geo)
+    gen_lidar(geo)
+    gen_kdtree(geo)
+    gen_dynamics(geo)
+    gen_sampler(net)
+    gen_timesteps(meta)
+    gen_unet(net)
+    gen_traces(traces)
+    np.savez_compressed(os.path.join(HERE, "geometry.npz"), **geo)
+    np.savez_compressed(os.path.join(HERE, "network.npz"), **net)
+    np.savez_compressed(os.path.join(HERE, "traces.npz"), **traces)
+    with open(os.path.join(HERE, "timesteps.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote golden fixtures to", HERE)
+
+
+if __name__ == "__main__":
+    main()
