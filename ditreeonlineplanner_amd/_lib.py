@@ -1,0 +1,103 @@
+"""ctypes binding of libditree_hip.so (include/ditree.h).
+
+The HIP library is the product path: there is no CPU fallback.  Importing this module
+never touches the GPU; ``lib()`` raises ``DitreeLibraryError`` when the shared object is
+missing or does not export every symbol of the header.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libditree_hip.so")
+
+ST_NOT_RUN, ST_OK, ST_GOAL, ST_COLLIDED = -1, 0, 1, 2
+ST_FLAG_GOAL_AT_COLLISION = 0x100
+PREC_BF16, PREC_F32 = 0, 1
+
+
+class DitreeLibraryError(RuntimeError):
+    pass
+
+
+class DitreeError(RuntimeError):
+    pass
+
+
+class Tree(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("n_chunks", C.c_int32), ("A", C.c_int32),
+                ("state", C.c_void_p), ("xy", C.c_void_p), ("parent", C.c_void_p),
+                ("last_action", C.c_void_p), ("has_prev", C.c_void_p), ("num_visit", C.c_void_p),
+                ("edge_states", C.c_void_p), ("edge_actions", C.c_void_p),
+                ("edge_nstates", C.c_void_p), ("edge_nactions", C.c_void_p), ("counters", C.c_void_p)]
+
+
+class Round(C.Structure):
+    _fields_ = [("B", C.c_int32), ("parent", C.c_void_p), ("status", C.c_void_p),
+                ("chunks_run", C.c_void_p), ("end_state", C.c_void_p), ("states", C.c_void_p),
+                ("actions", C.c_void_p), ("chunk_steps", C.c_void_p), ("node_id", C.c_void_p)]
+
+
+class RoundParams(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("samples", C.c_void_p), ("cond_goal", C.c_void_p),
+                ("noise", C.c_void_p), ("inject_actions", C.c_void_p), ("P", C.c_int32), ("K", C.c_int32),
+                ("t0", C.POINTER(C.c_float)), ("dt", C.POINTER(C.c_float)), ("norm", C.POINTER(C.c_double)),
+                ("goal_xy", C.POINTER(C.c_double)), ("axis", C.POINTER(C.c_double)), ("lm_n", C.c_int32),
+                ("lm_size", C.c_double), ("s_global", C.c_double)]
+
+
+_vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+_pd, _pf = C.POINTER(C.c_double), C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); must list every symbol include/ditree.h declares
+SIGNATURES = {
+    "ditree_version": (_i32, []),
+    "ditree_ctx_create": (_i32, [_i32, C.POINTER(_vp)]),
+    "ditree_ctx_destroy": (None, [_vp]),
+    "ditree_last_error": (C.c_char_p, [_vp]),
+    "ditree_upload_maze": (_i32, [_vp, _pf, _i32, _i32, _vp]),
+    "ditree_nn_argmin": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ditree_local_map": (_i32, [_vp, _vp, _vp, _i32, _i32, _pd, _f64, _i32, _vp, _vp]),
+    "ditree_cond_vector": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _pd, _f64, _vp, _vp]),
+    "ditree_car_rollout": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _pd, _vp, _i64, _vp, _i64, _vp, _vp,
+                                  _vp, _vp]),
+    "ditree_lidar_scan": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ditree_accept": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), _i32, _vp]),
+    "ditree_load_weights": (_i32, [_vp, _vp, _i64, C.c_char_p, _vp]),
+    "ditree_denoise_reserve": (_i32, [_vp, _i32, _i32]),
+    "ditree_denoise": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _pf, _pf, _pd, _vp, _vp, _vp]),
+    "ditree_expand_round": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), C.POINTER(RoundParams), _vp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; fail loudly if it is not there."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise DitreeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m ditreeonlineplanner_amd.build` "
+            "(hipcc, gfx950).  There is no CPU fallback for the expansion path.")
+    try:
+        h = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise DitreeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(h, name)
+        except AttributeError as e:
+            raise DitreeLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = h
+    return h
+
+
+def check(ctx_handle, rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().ditree_last_error(ctx_handle)
+        raise DitreeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

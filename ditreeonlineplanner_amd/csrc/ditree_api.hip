@@ -1,0 +1,280 @@
+// C-ABI entry points of libditree_hip.so (see include/ditree.h for the contract and the
+// reference call sites each entry point replaces).
+#include <cstdio>
+#include <cstring>
+
+#include "ditree_internal.h"
+
+void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double* state_io, const double* actions,
+                           int64_t act_stride, int32_t* status_io, int B, int A, double gx, double gy,
+                           double* states_out, int64_t states_stride, double* actions_out, int64_t actout_stride,
+                           int32_t* steps_out, int64_t steps_stride, int32_t* chunks_run, double* prev_action_io,
+                           uint8_t* has_prev_io, hipStream_t s);
+int denoise_run(ditree_ctx* ctx, const float* noise, const float* local_map, const float* cond, int B, int K,
+                const float* t0, const float* dt, const double* act_norm, double* actions, float* x_out,
+                hipStream_t s);
+void denoise_destroy(ditree_ctx* ctx);
+
+int set_err(ditree_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+extern "C" {
+
+int32_t ditree_version(void) { return DITREE_VERSION; }
+
+int32_t ditree_ctx_create(int32_t device, ditree_ctx** out) {
+  if (!out) return DITREE_E_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return DITREE_E_HIP;
+  if (hipSetDevice(device) != hipSuccess) return DITREE_E_HIP;
+  ditree_ctx* c = new (std::nothrow) ditree_ctx();
+  if (!c) return DITREE_E_NOMEM;
+  c->device = device;
+  *out = c;
+  return DITREE_OK;
+}
+
+void ditree_ctx_destroy(ditree_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  denoise_destroy(ctx);
+  if (ctx->maze) hipFree(ctx->maze);
+  if (ctx->cur_state) hipFree(ctx->cur_state);
+  if (ctx->prev_action) hipFree(ctx->prev_action);
+  if (ctx->has_prev) hipFree(ctx->has_prev);
+  if (ctx->lmap) hipFree(ctx->lmap);
+  if (ctx->cond) hipFree(ctx->cond);
+  if (ctx->act64) hipFree(ctx->act64);
+  delete ctx;
+}
+
+const char* ditree_last_error(ditree_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int32_t ditree_upload_maze(ditree_ctx* ctx, const float* maze, int32_t rows, int32_t cols, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!maze || rows <= 0 || cols <= 0 || (int64_t)rows * cols > 60000)
+    return set_err(ctx, DITREE_E_ARG, "upload_maze: need 0 < rows*cols <= 60000 (LDS-staged)");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t n = (size_t)rows * cols;
+  if (ctx->maze_cap < n) {
+    if (ctx->maze) HIP_TRY(ctx, hipFree(ctx->maze));
+    ctx->maze = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->maze, n));
+    ctx->maze_cap = n;
+  }
+  // host-side conversion to byte cell codes (same rule as maze_convert_kernel), then one async copy
+  std::vector<unsigned char> codes(n);
+  for (size_t i = 0; i < n; ++i) {
+    float v = maze[i];
+    int c = (int)v;
+    codes[i] = (v == (float)c && c >= 0 && c < 256) ? (unsigned char)c : (unsigned char)255;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->maze, codes.data(), n, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));       // `codes` is a temporary; the maze changes rarely
+  ctx->rows = rows;
+  ctx->cols = cols;
+  return DITREE_OK;
+}
+
+int32_t ditree_nn_argmin(ditree_ctx* ctx, const double* queries, int32_t q_stride, int32_t B, const double* node_xy,
+                         int32_t N, int32_t* out_idx, const double* node_state, const double* node_last_action,
+                         const uint8_t* node_has_prev, double* out_state, double* out_prev_action,
+                         uint8_t* out_has_prev, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!queries || !node_xy || !out_idx || B < 0 || N <= 0 || q_stride < 2)
+    return set_err(ctx, DITREE_E_ARG, "nn_argmin: bad argument");
+  if (node_state && (!node_last_action || !node_has_prev || !out_state || !out_prev_action || !out_has_prev))
+    return set_err(ctx, DITREE_E_ARG, "nn_argmin: gather outputs incomplete");
+  if (B == 0) return DITREE_OK;
+  launch_nn_argmin(queries, q_stride, B, node_xy, N, out_idx, node_state, node_last_action, node_has_prev, out_state,
+                   out_prev_action, out_has_prev, (hipStream_t)stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+static int fill_axis(ditree_ctx* ctx, const double* axis, int n, AxisArg* a) {
+  if (!axis || n <= 0 || n > DITREE_MAX_AXIS) return set_err(ctx, DITREE_E_ARG, "local map size must be 1..64");
+  for (int i = 0; i < n; ++i) a->v[i] = axis[i];
+  for (int i = n; i < DITREE_MAX_AXIS; ++i) a->v[i] = 0.0;
+  return DITREE_OK;
+}
+
+int32_t ditree_local_map(ditree_ctx* ctx, const double* state, const int32_t* active, int32_t B, int32_t n,
+                         const double* axis, double s_global, int32_t scaled, float* out, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!ctx->maze) return set_err(ctx, DITREE_E_STATE, "local_map: no maze uploaded");
+  if (!state || !out || B < 0) return set_err(ctx, DITREE_E_ARG, "local_map: bad argument");
+  AxisArg a;
+  int rc = fill_axis(ctx, axis, n, &a);
+  if (rc) return rc;
+  if (B == 0) return DITREE_OK;
+  launch_local_map(ctx->maze, ctx->rows, ctx->cols, state, active, B, n, a, s_global, scaled, out,
+                   (hipStream_t)stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+static void fill_norm(const double* norm, NormArg* nm) {
+  for (int i = 0; i < 6; ++i) nm->obs_mean[i] = norm[i];
+  for (int i = 0; i < 6; ++i) nm->obs_std[i] = norm[6 + i];
+  for (int i = 0; i < 2; ++i) nm->act_mean[i] = norm[12 + i];
+  for (int i = 0; i < 2; ++i) nm->act_std[i] = norm[14 + i];
+}
+
+int32_t ditree_cond_vector(ditree_ctx* ctx, const double* state, const double* prev_action, const uint8_t* has_prev,
+                           const double* cond_goal, int32_t B, const double* norm, double local_map_size, float* out,
+                           void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!state || !prev_action || !has_prev || !cond_goal || !norm || !out || B < 0)
+    return set_err(ctx, DITREE_E_ARG, "cond_vector: bad argument");
+  if (B == 0) return DITREE_OK;
+  NormArg nm;
+  fill_norm(norm, &nm);
+  launch_cond_vector(state, prev_action, has_prev, cond_goal, B, nm, local_map_size, out, (hipStream_t)stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+int32_t ditree_car_rollout(ditree_ctx* ctx, double* state_io, const double* actions, int64_t act_stride,
+                           int32_t* status_io, int32_t B, int32_t A, const double* goal_xy, double* states_out,
+                           int64_t states_stride, double* actions_out, int64_t actout_stride, int32_t* steps_out,
+                           double* prev_action_io, uint8_t* has_prev_io, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!ctx->maze) return set_err(ctx, DITREE_E_STATE, "car_rollout: no maze uploaded");
+  if (!state_io || !actions || !status_io || !goal_xy || B < 0 || A <= 0 || act_stride < 2 * (int64_t)A)
+    return set_err(ctx, DITREE_E_ARG, "car_rollout: bad argument");
+  if (states_out && states_stride < 6 * (int64_t)(A + 1)) return set_err(ctx, DITREE_E_ARG, "car_rollout: states_stride");
+  if (actions_out && actout_stride < 2 * (int64_t)A) return set_err(ctx, DITREE_E_ARG, "car_rollout: actout_stride");
+  if (B == 0) return DITREE_OK;
+  launch_car_rollout(ctx->maze, ctx->rows, ctx->cols, state_io, actions, act_stride, status_io, B, A, goal_xy[0],
+                     goal_xy[1], states_out, states_stride, actions_out, actout_stride, steps_out, prev_action_io,
+                     has_prev_io, (hipStream_t)stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+int32_t ditree_lidar_scan(ditree_ctx* ctx, const double* poses, int32_t B, const float* maze, int32_t rows,
+                          int32_t cols, double* dist, double* endpoints, uint8_t* hit, uint8_t* visited,
+                          void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!poses || !maze || !dist || !endpoints || !hit || B < 0 || rows <= 0 || cols <= 0 ||
+      (int64_t)rows * cols > 30000)
+    return set_err(ctx, DITREE_E_ARG, "lidar_scan: bad argument (rows*cols <= 30000)");
+  if (B == 0) return DITREE_OK;
+  launch_lidar_scan(poses, B, maze, rows, cols, dist, endpoints, hit, visited, (hipStream_t)stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+static int check_tree(ditree_ctx* ctx, const ditree_tree* t) {
+  if (!t || !t->state || !t->xy || !t->parent || !t->last_action || !t->has_prev || !t->num_visit ||
+      !t->edge_states || !t->edge_actions || !t->edge_nstates || !t->edge_nactions || !t->counters ||
+      t->capacity <= 0 || t->n_chunks <= 0 || t->A <= 0)
+    return set_err(ctx, DITREE_E_ARG, "tree descriptor incomplete");
+  return DITREE_OK;
+}
+static int check_round(ditree_ctx* ctx, const ditree_round* r) {
+  if (!r || r->B < 0 || !r->parent || !r->status || !r->chunks_run || !r->end_state || !r->states || !r->actions ||
+      !r->chunk_steps || !r->node_id)
+    return set_err(ctx, DITREE_E_ARG, "round descriptor incomplete");
+  return DITREE_OK;
+}
+
+int32_t ditree_accept(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round, int32_t emulate_sticky,
+                      void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  int rc = check_tree(ctx, tree);
+  if (rc) return rc;
+  rc = check_round(ctx, round);
+  if (rc) return rc;
+  if (round->B == 0) return DITREE_OK;
+  launch_accept(*tree, *round, emulate_sticky, (hipStream_t)stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+static int ensure_scratch(ditree_ctx* ctx, int B, int lm_n, int P) {
+  if (B <= ctx->scratch_B && lm_n <= ctx->scratch_lm && P <= ctx->scratch_P) return DITREE_OK;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  void** ptrs[] = {(void**)&ctx->cur_state, (void**)&ctx->prev_action, (void**)&ctx->has_prev, (void**)&ctx->lmap,
+                   (void**)&ctx->cond, (void**)&ctx->act64};
+  for (auto p : ptrs) {
+    if (*p) HIP_TRY(ctx, hipFree(*p));
+    *p = nullptr;
+  }
+  int nb = B > ctx->scratch_B ? B : ctx->scratch_B;
+  int nl = lm_n > ctx->scratch_lm ? lm_n : ctx->scratch_lm;
+  int np = P > ctx->scratch_P ? P : ctx->scratch_P;
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->cur_state, (size_t)nb * 6 * sizeof(double)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->prev_action, (size_t)nb * 2 * sizeof(double)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->has_prev, (size_t)nb));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->lmap, (size_t)nb * nl * nl * sizeof(float)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->cond, (size_t)nb * 7 * sizeof(float)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->act64, (size_t)nb * np * 2 * sizeof(double)));
+  ctx->scratch_B = nb;
+  ctx->scratch_lm = nl;
+  ctx->scratch_P = np;
+  return DITREE_OK;
+}
+
+int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
+                            const ditree_round_params* p, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  int rc = check_tree(ctx, tree);
+  if (rc) return rc;
+  rc = check_round(ctx, round);
+  if (rc) return rc;
+  if (!ctx->maze) return set_err(ctx, DITREE_E_STATE, "expand_round: no maze uploaded");
+  if (!p || !p->samples || !p->cond_goal || !p->norm || !p->goal_xy || !p->axis || p->n_nodes <= 0 ||
+      p->n_nodes > tree->capacity || p->P < tree->A || (!p->noise && !p->inject_actions))
+    return set_err(ctx, DITREE_E_ARG, "expand_round: bad parameters");
+  if (!p->inject_actions && (!p->t0 || !p->dt || p->K <= 0))
+    return set_err(ctx, DITREE_E_ARG, "expand_round: flow schedule missing");
+  const int B = round->B, A = tree->A, nC = tree->n_chunks, P = p->P;
+  if (B == 0) return DITREE_OK;
+  hipStream_t s = (hipStream_t)stream;
+  rc = ensure_scratch(ctx, B, p->lm_n, P);
+  if (rc) return rc;
+  AxisArg ax;
+  rc = fill_axis(ctx, p->axis, p->lm_n, &ax);
+  if (rc) return rc;
+  NormArg nm;
+  fill_norm(p->norm, &nm);
+  launch_round_begin(round->status, round->chunks_run, round->chunk_steps, B, nC, s);
+  launch_nn_argmin(p->samples, 6, B, tree->xy, p->n_nodes, round->parent, tree->state, tree->last_action,
+                   tree->has_prev, ctx->cur_state, ctx->prev_action, ctx->has_prev, s);
+  const int64_t st_stride = (int64_t)nC * (A + 1) * 6, ac_stride = (int64_t)nC * A * 2;
+  for (int j = 0; j < nC; ++j) {
+    const double* acts;
+    int64_t act_stride;
+    if (p->inject_actions) {
+      acts = p->inject_actions + (size_t)j * P * 2;
+      act_stride = (int64_t)nC * P * 2;
+    } else {
+      launch_local_map(ctx->maze, ctx->rows, ctx->cols, ctx->cur_state, round->status, B, p->lm_n, ax, p->s_global,
+                       1, ctx->lmap, s);
+      launch_cond_vector(ctx->cur_state, ctx->prev_action, ctx->has_prev, p->cond_goal, B, nm, p->lm_size,
+                         ctx->cond, s);
+      double an[4] = {p->norm[12], p->norm[13], p->norm[14], p->norm[15]};
+      rc = denoise_run(ctx, p->noise + (size_t)j * P * 2, ctx->lmap, ctx->cond, B, p->K, p->t0, p->dt, an,
+                       ctx->act64, nullptr, s);
+      if (rc) return rc;
+      acts = ctx->act64;
+      act_stride = (int64_t)P * 2;
+    }
+    launch_car_rollout_ex(ctx->maze, ctx->rows, ctx->cols, ctx->cur_state, acts, act_stride, round->status, B, A,
+                          p->goal_xy[0], p->goal_xy[1], round->states + (size_t)j * (A + 1) * 6, st_stride,
+                          round->actions + (size_t)j * A * 2, ac_stride, round->chunk_steps + j, nC,
+                          round->chunks_run, ctx->prev_action, ctx->has_prev, s);
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(round->end_state, ctx->cur_state, (size_t)B * 6 * sizeof(double),
+                              hipMemcpyDeviceToDevice, s));
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+}  // extern "C"

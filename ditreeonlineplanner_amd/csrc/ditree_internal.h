@@ -1,0 +1,73 @@
+// Internal declarations shared by the HIP translation units of libditree_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ditree.h"
+
+#define DITREE_MAX_AXIS 64
+#define DITREE_LIDAR_RAYS 181
+
+struct AxisArg {
+  double v[DITREE_MAX_AXIS];
+};
+struct NormArg {
+  double obs_mean[6], obs_std[6], act_mean[2], act_std[2];
+};
+
+struct DenoiserState;   // denoise_host.hip
+
+struct ditree_ctx {
+  int device = 0;
+  std::string err;
+  // known maze (u8 cell codes) on the device
+  unsigned char* maze = nullptr;
+  int rows = 0, cols = 0;
+  size_t maze_cap = 0;
+  // expand-round scratch (sized for scratch_B candidates)
+  int scratch_B = 0;
+  double* cur_state = nullptr;      // (B,6)
+  double* prev_action = nullptr;    // (B,2)
+  uint8_t* has_prev = nullptr;      // (B,)
+  float* lmap = nullptr;            // (B,n,n)
+  float* cond = nullptr;            // (B,7)
+  double* act64 = nullptr;          // (B,P,2)
+  int scratch_lm = 0, scratch_P = 0;
+  DenoiserState* dn = nullptr;
+};
+
+int set_err(ditree_ctx* ctx, int code, const std::string& msg);
+#define HIP_TRY(ctx, expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess)                                                               \
+      return set_err(ctx, DITREE_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+// geom_kernels.hip launchers (all asynchronous on `s`)
+void launch_maze_convert(const float* src, unsigned char* dst, int n, hipStream_t s);
+void launch_nn_argmin(const double* queries, int q_stride, int B, const double* node_xy, int N,
+                      int32_t* out_idx, const double* node_state, const double* node_last_action,
+                      const uint8_t* node_has_prev, double* out_state, double* out_prev_action,
+                      uint8_t* out_has_prev, hipStream_t s);
+void launch_local_map(const unsigned char* maze, int rows, int cols, const double* state,
+                      const int32_t* active, int B, int n, const AxisArg& axis, double s_global,
+                      int scaled, float* out, hipStream_t s);
+void launch_cond_vector(const double* state, const double* prev_action, const uint8_t* has_prev,
+                        const double* cond_goal, int B, const NormArg& nm, double lm_size, float* out,
+                        hipStream_t s);
+void launch_car_rollout(const unsigned char* maze, int rows, int cols, double* state_io,
+                        const double* actions, int64_t act_stride, int32_t* status_io, int B, int A,
+                        double gx, double gy, double* states_out, int64_t states_stride,
+                        double* actions_out, int64_t actout_stride, int32_t* steps_out,
+                        double* prev_action_io, uint8_t* has_prev_io, hipStream_t s);
+void launch_lidar_scan(const double* poses, int B, const float* maze, int rows, int cols, double* dist,
+                       double* endpoints, uint8_t* hit, uint8_t* visited, hipStream_t s);
+void launch_round_begin(int32_t* status, int32_t* chunks_run, int32_t* chunk_steps, int B, int n_chunks,
+                        hipStream_t s);
+void launch_round_chunk_end(const int32_t* chunk_status_in, int32_t* status, int32_t* chunks_run,
+                            const double* cur_state, double* end_state, int B, hipStream_t s);
+void launch_accept(const ditree_tree& t, const ditree_round& r, int emulate_sticky, hipStream_t s);

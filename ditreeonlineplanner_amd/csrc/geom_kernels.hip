@@ -1,0 +1,605 @@
+// Per-candidate kinodynamic kernels of the DiTree expansion path (gfx950, FP64).
+//
+// This translation unit is compiled with -ffp-contract=off: the reference computes
+// every expression with separately rounded numpy operations, and flags / parent
+// indices must be bit-exact against the CPU oracle, so no a*b+c may be fused here
+// except where the reference's LAPACK does (lidar border solve, explicit fma()).
+//
+// Reference sites (paths relative to the reference root):
+//   nn_argmin      planners/RRT.py:49-51 (KDTree.query k=1 on state[:2])
+//   local_map      common/map_utils.py:391-459
+//   cond_vector    policies/fm_policy.py:60-143 (car branch)
+//   car_rollout    planners/base_planner.py:257-320, car_env.py:341-396,
+//                  common/map_utils.py:103-115,221-329
+//   lidar_scan     lidar_sim/lidar_2d_sim.py:18-98
+//   accept/commit  planners/RRT.py:179-217
+#include "ditree_internal.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------- maze
+__global__ void maze_convert_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    float v = src[i];
+    int c = (int)v;
+    dst[i] = (v == (float)c && c >= 0 && c < 256) ? (unsigned char)c : (unsigned char)255;
+  }
+}
+void launch_maze_convert(const float* src, unsigned char* dst, int n, hipStream_t s) {
+  hipLaunchKernelGGL(maze_convert_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n);
+}
+
+// Stage the maze into LDS (cells are single bytes; every shipped maze is <= 31x31).
+__device__ __forceinline__ void stage_maze(unsigned char* lds, const unsigned char* __restrict__ g, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = g[i];
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------- nearest node
+// One wave per group of QPW queries; lanes stride the node array (coalesced 16-B loads),
+// then a 64-lane arg-min reduction carrying (distance, index); ties -> lowest index.
+#define NN_QPW 4
+__global__ void __launch_bounds__(256)
+nn_argmin_kernel(const double* __restrict__ queries, int q_stride, int B, const double2* __restrict__ node_xy,
+                 int N, int32_t* __restrict__ out_idx, const double* __restrict__ node_state,
+                 const double* __restrict__ node_last_action, const uint8_t* __restrict__ node_has_prev,
+                 double* __restrict__ out_state, double* __restrict__ out_prev_action,
+                 uint8_t* __restrict__ out_has_prev) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int q0 = wave * NN_QPW;
+  if (q0 >= B) return;
+  double qx[NN_QPW], qy[NN_QPW], best[NN_QPW];
+  int bidx[NN_QPW];
+#pragma unroll
+  for (int k = 0; k < NN_QPW; ++k) {
+    int q = min(q0 + k, B - 1);
+    qx[k] = queries[(size_t)q * q_stride + 0];
+    qy[k] = queries[(size_t)q * q_stride + 1];
+    best[k] = __builtin_huge_val();
+    bidx[k] = 0x7fffffff;
+  }
+  for (int i = lane; i < N; i += WAVE) {
+    double2 p = node_xy[i];
+#pragma unroll
+    for (int k = 0; k < NN_QPW; ++k) {
+      double dx = qx[k] - p.x, dy = qy[k] - p.y;
+      double d = dx * dx + dy * dy;
+      if (d < best[k]) { best[k] = d; bidx[k] = i; }     // strict: keeps the lowest index per lane
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NN_QPW; ++k) {
+    double d = best[k];
+    int ix = bidx[k];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      double od = __shfl_xor(d, m);
+      int oi = __shfl_xor(ix, m);
+      if (od < d || (od == d && oi < ix)) { d = od; ix = oi; }
+    }
+    // NaN distances never win a '<'; an all-NaN scan leaves 0x7fffffff -> clamp to node 0
+    if (ix == 0x7fffffff) ix = 0;
+    int q = q0 + k;
+    if (q < B) {
+      if (lane == 0) out_idx[q] = ix;
+      if (node_state != nullptr) {
+        if (lane < 6) out_state[(size_t)q * 6 + lane] = node_state[(size_t)ix * 6 + lane];
+        if (lane >= 8 && lane < 10) out_prev_action[(size_t)q * 2 + (lane - 8)] = node_last_action[(size_t)ix * 2 + (lane - 8)];
+        if (lane == 16) out_has_prev[q] = node_has_prev[ix];
+      }
+    }
+  }
+}
+void launch_nn_argmin(const double* queries, int q_stride, int B, const double* node_xy, int N, int32_t* out_idx,
+                      const double* node_state, const double* node_last_action, const uint8_t* node_has_prev,
+                      double* out_state, double* out_prev_action, uint8_t* out_has_prev, hipStream_t s) {
+  int waves = (B + NN_QPW - 1) / NN_QPW;
+  int blocks = (waves + 3) / 4;
+  hipLaunchKernelGGL(nn_argmin_kernel, dim3(blocks), dim3(256), 0, s, queries, q_stride, B,
+                     (const double2*)node_xy, N, out_idx, node_state, node_last_action, node_has_prev, out_state,
+                     out_prev_action, out_has_prev);
+}
+
+// ------------------------------------------------------------------------- local map
+// One workgroup per candidate; maze staged in LDS; one thread per output cell.
+__global__ void __launch_bounds__(256)
+local_map_kernel(const unsigned char* __restrict__ maze, int rows, int cols, const double* __restrict__ state,
+                 const int32_t* __restrict__ active, int n, AxisArg axis, double s_global, int scaled,
+                 float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int b = blockIdx.x;
+  if (active != nullptr && active[b] != DITREE_ST_OK) return;      // block-uniform
+  stage_maze(lds, maze, rows * cols);
+  const double x = state[(size_t)b * 6 + 0], y = state[(size_t)b * 6 + 1], th = state[(size_t)b * 6 + 2];
+  const double c = cos(th), sn = sin(th);
+  // base_planner.py:113-114 with maze_size_scaling = 1: centre = (W/2, H/2); RRT.py:166
+  const double cx = (double)cols / 2.0, cy = (double)rows / 2.0;
+  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+    int i = idx / n, j = idx - i * n;                               // meshgrid: x_local[i][j] = xs[j], y_local = ys[i]
+    double xl = axis.v[j], yl = axis.v[i];
+    double xg = c * xl - sn * yl + x;                               // map_utils.py:443
+    double yg = sn * xl + c * yl + y;                               // :444
+    double fy = floor((cy - yg) / s_global);                        // :447
+    double fx = floor((xg + cx) / s_global);                        // :448
+    // np.clip after astype(int): NaN / huge values become INT64_MIN in numpy -> clip to 0
+    int yi = (fy >= 0.0) ? ((fy < (double)rows) ? (int)fy : rows - 1) : 0;
+    int xi = (fx >= 0.0) ? ((fx < (double)cols) ? (int)fx : cols - 1) : 0;
+    float m = (float)lds[yi * cols + xi];
+    out[(size_t)b * n * n + idx] = scaled ? (m * 2.0f - 1.0f) : m;
+  }
+}
+void launch_local_map(const unsigned char* maze, int rows, int cols, const double* state, const int32_t* active,
+                      int B, int n, const AxisArg& axis, double s_global, int scaled, float* out, hipStream_t s) {
+  size_t lds = ((size_t)rows * cols + 15) & ~(size_t)15;
+  hipLaunchKernelGGL(local_map_kernel, dim3(B), dim3(256), lds, s, maze, rows, cols, state, active, n, axis,
+                     s_global, scaled, out);
+}
+
+// ------------------------------------------------------------------------- conditioning vector
+__global__ void cond_vector_kernel(const double* __restrict__ state, const double* __restrict__ prev_action,
+                                   const uint8_t* __restrict__ has_prev, const double* __restrict__ cond_goal, int B,
+                                   NormArg nm, double lm_size, float* __restrict__ out) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* st = state + (size_t)b * 6;
+  float* o = out + (size_t)b * 7;
+  // fm_policy.py:76,108,110,112: normalise in f64, drop x,y,psi, cast to f32
+#pragma unroll
+  for (int k = 0; k < 3; ++k) o[k] = (float)((st[3 + k] - nm.obs_mean[3 + k]) / nm.obs_std[3 + k]);
+  // :113-123: zeros stay un-normalised when prev_actions is None
+  if (has_prev[b]) {
+    o[3] = (float)((prev_action[(size_t)b * 2 + 0] - nm.act_mean[0]) / nm.act_std[0]);
+    o[4] = (float)((prev_action[(size_t)b * 2 + 1] - nm.act_mean[1]) / nm.act_std[1]);
+  } else {
+    o[3] = 0.0f;
+    o[4] = 0.0f;
+  }
+  // :125-143 in f32: g = float(goal - pos); R(-yaw) g; tanh(g / lm_size)
+  float gx = (float)(cond_goal[(size_t)b * 2 + 0] - st[0]);
+  float gy = (float)(cond_goal[(size_t)b * 2 + 1] - st[1]);
+  float yaw = (float)st[2];
+  float c = cosf(yaw), sn = sinf(yaw);
+  float rx = c * gx + sn * gy;
+  float ry = (-sn) * gx + c * gy;
+  float sc = (float)lm_size;
+  o[5] = tanhf(rx / sc);
+  o[6] = tanhf(ry / sc);
+}
+void launch_cond_vector(const double* state, const double* prev_action, const uint8_t* has_prev,
+                        const double* cond_goal, int B, const NormArg& nm, double lm_size, float* out,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(cond_vector_kernel, dim3((B + 255) / 256), dim3(256), 0, s, state, prev_action, has_prev,
+                     cond_goal, B, nm, lm_size, out);
+}
+
+// ------------------------------------------------------------------------- collision
+// common/map_utils.py:221-329 for one ball (maze_size_scaling = 1, radius 0.1).
+__device__ __forceinline__ bool ball_collides(double x, double y, const unsigned char* mz, int H, int W) {
+  const double s = 1.0, r = 0.1;
+  const double xc = (double)W / 2.0 * s, yc = (double)H / 2.0 * s;
+  double fr = floor((yc - y) / s), fc = floor((x + xc) / s);
+  // numpy's astype(int) maps NaN/inf to INT64_MIN -> out of bounds -> collision (:255-259)
+  if (!(fr >= 0.0) || !(fr < (double)H) || !(fc >= 0.0) || !(fc < (double)W)) return true;
+  const int row = (int)fr, col = (int)fc;
+  bool coll = mz[row * W + col] == 1;                                            // :262
+  const double cell_x = ((double)col + 0.5) * s - xc, cell_y = yc - ((double)row + 0.5) * s;
+  const double half = s / 2.0;
+  const double x_min = cell_x - half, x_max = cell_x + half, y_min = cell_y - half, y_max = cell_y + half;
+  const int cr = min(col + 1, W - 1), cl = max(col - 1, 0), rt = max(row - 1, 0), rb = min(row + 1, H - 1);
+  coll |= (x + r > x_max) && (mz[row * W + cr] == 1);                            // right  :288-292
+  coll |= (x - r < x_min) && (mz[row * W + cl] == 1);                            // left   :294-298
+  coll |= (y + r > y_max) && (mz[rt * W + col] == 1);                            // top    :300-304
+  coll |= (y - r < y_min) && (mz[rb * W + col] == 1);                            // bottom :306-310
+  // corners :315-327; invalid neighbour => collision; column clipped with map_length (sic, :326)
+  const int ci[4] = {row - 1, row - 1, row + 1, row + 1};
+  const int cj[4] = {col + 1, col - 1, col + 1, col - 1};
+  const double kx[4] = {x_max, x_min, x_max, x_min};
+  const double ky[4] = {y_max, y_max, y_min, y_min};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    bool invalid = ci[k] < 0 || ci[k] >= H || cj[k] < 0 || cj[k] >= W;
+    int i2 = min(max(ci[k], 0), H - 1);
+    int j2 = min(min(max(cj[k], 0), H - 1), W - 1);
+    double dist = hypot(kx[k] - x, ky[k] - y);
+    coll |= invalid || ((dist < r) && (mz[i2 * W + j2] == 1));
+  }
+  return coll;
+}
+
+// common/map_utils.py:103-115: two balls +-0.075 m along the heading.
+__device__ __forceinline__ bool car_collides(double x, double y, double psi, const unsigned char* mz, int H, int W) {
+  const double off = 0.15 * 0.5;
+  double ox = off * cos(psi), oy = off * sin(psi);
+  bool f = ball_collides(x + ox, y + oy, mz, H, W);
+  bool b = ball_collides(x - ox, y - oy, mz, H, W);
+  return f || b;
+}
+
+// ------------------------------------------------------------------------- rollout
+// One thread per candidate: A Euler steps, each with goal + collision test, early exit.
+__global__ void __launch_bounds__(256)
+car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, double* __restrict__ state_io,
+                   const double* __restrict__ actions, int64_t act_stride, int32_t* __restrict__ status_io, int B,
+                   int A, double gx, double gy, double* __restrict__ states_out, int64_t states_stride,
+                   double* __restrict__ actions_out, int64_t actout_stride, int32_t* __restrict__ steps_out,
+                   int64_t steps_stride, int32_t* __restrict__ chunks_run, double* __restrict__ prev_action_io,
+                   uint8_t* __restrict__ has_prev_io) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  stage_maze(lds, maze, rows * cols);
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (status_io[b] != DITREE_ST_OK) return;
+  double s[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) s[k] = state_io[(size_t)b * 6 + k];
+  const double* act = actions + (size_t)b * act_stride;
+  double* so = states_out ? states_out + (size_t)b * states_stride : nullptr;
+  double* ao = actions_out ? actions_out + (size_t)b * actout_stride : nullptr;
+  if (so) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) so[k] = s[k];                                   // states_sequence[0] = state
+  }
+  // car_env.py:32,47-53
+  const double dt = 1.0 / 50.0, m = 0.043, C1 = 0.5, C2 = 15.5, Cm1 = 0.28, Cm2 = 0.05, Cr0 = 0.011, Cr2 = 0.006;
+  int status = DITREE_ST_OK;
+  int steps = 0;
+  double la0 = 0.0, la1 = 0.0;
+  int i = 0;
+  for (; i < A; ++i) {
+    const double a0r = act[2 * i], a1r = act[2 * i + 1];
+    // np.clip(action, [-10,-2], [10,2]) car_env.py:371; NaN propagates like numpy
+    double a0 = a0r < -10.0 ? -10.0 : (a0r > 10.0 ? 10.0 : a0r);
+    double a1 = a1r < -2.0 ? -2.0 : (a1r > 2.0 ? 2.0 : a1r);
+    const double psi = s[2], v = s[3], D = s[4], dl = s[5];
+    double Fxd = (Cm1 - Cm2 * v) * D - Cr2 * (v * v) - Cr0 * tanh(5.0 * v);     // :380
+    double ang = psi + C1 * dl;
+    double d0 = v * cos(ang), d1 = v * sin(ang), d2 = v * C2 * dl, d3 = (Fxd / m) * cos(C1 * dl);
+    s[0] = s[0] + dt * d0;
+    s[1] = s[1] + dt * d1;
+    s[2] = s[2] + dt * d2;
+    s[3] = s[3] + dt * d3;
+    s[4] = s[4] + dt * a0;
+    s[5] = s[5] + dt * a1;
+    steps = i + 1;
+    if (so) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) so[(size_t)(i + 1) * 6 + k] = s[k];
+    }
+    if (ao) { ao[2 * i] = a0r; ao[2 * i + 1] = a1r; }
+    la0 = a0r; la1 = a1r;
+    double ex = s[0] - gx, ey = s[1] - gy;
+    bool done = sqrt(fma(ey, ey, ex * ex)) < 0.5;   // np.linalg.norm (ddot rounds as one fma), car_env.py:346-351
+    bool coll = car_collides(s[0], s[1], s[2], lds, rows, cols);                 // base_planner.py:306
+    if (coll) {
+      status = DITREE_ST_COLLIDED | (done ? DITREE_ST_FLAG_GOAL_AT_COLLISION : 0);
+      ++i;
+      break;
+    }
+    if (done) {                                                                   // :314-317
+      status = DITREE_ST_GOAL;
+      ++i;
+      break;
+    }
+  }
+  // rows after the last executed step stay zero (states :282; actions zeroed :315)
+  for (int r = i; r < A; ++r) {
+    if (so) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) so[(size_t)(r + 1) * 6 + k] = 0.0;
+    }
+    if (ao) { ao[2 * r] = 0.0; ao[2 * r + 1] = 0.0; }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) state_io[(size_t)b * 6 + k] = s[k];
+  status_io[b] = status;
+  if (steps_out) steps_out[(size_t)b * steps_stride] = steps;
+  if (chunks_run) chunks_run[b] += 1;
+  if (status == DITREE_ST_OK && prev_action_io) {                                 // RRT.py:188
+    prev_action_io[(size_t)b * 2 + 0] = la0;
+    prev_action_io[(size_t)b * 2 + 1] = la1;
+    if (has_prev_io) has_prev_io[b] = 1;
+  }
+}
+void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double* state_io, const double* actions,
+                           int64_t act_stride, int32_t* status_io, int B, int A, double gx, double gy,
+                           double* states_out, int64_t states_stride, double* actions_out, int64_t actout_stride,
+                           int32_t* steps_out, int64_t steps_stride, int32_t* chunks_run, double* prev_action_io,
+                           uint8_t* has_prev_io, hipStream_t s) {
+  size_t lds = ((size_t)rows * cols + 15) & ~(size_t)15;
+  hipLaunchKernelGGL(car_rollout_kernel, dim3((B + 255) / 256), dim3(256), lds, s, maze, rows, cols, state_io,
+                     actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out,
+                     actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io);
+}
+void launch_car_rollout(const unsigned char* maze, int rows, int cols, double* state_io, const double* actions,
+                        int64_t act_stride, int32_t* status_io, int B, int A, double gx, double gy,
+                        double* states_out, int64_t states_stride, double* actions_out, int64_t actout_stride,
+                        int32_t* steps_out, double* prev_action_io, uint8_t* has_prev_io, hipStream_t s) {
+  launch_car_rollout_ex(maze, rows, cols, state_io, actions, act_stride, status_io, B, A, gx, gy, states_out,
+                        states_stride, actions_out, actout_stride, steps_out, 1, nullptr, prev_action_io,
+                        has_prev_io, s);
+}
+
+// ------------------------------------------------------------------------- lidar
+// One workgroup per pose, one thread per ray (181 rays -> 192 threads).  The maze (f32
+// {0,1}) is staged into LDS as bytes; visited cells are OR-ed into an LDS bitmap.
+__device__ __forceinline__ bool border_solve(double rx, double ry, double dx, double dy, double b0, double b1,
+                                             double* t, double* s) {
+  // np.linalg.solve([[rx, -dx], [ry, -dy]], b) as OpenBLAS evaluates it (verified bit-exact on
+  // the build host): partial pivoting, multiplier scaled by the reciprocal pivot, FMA updates,
+  // true divisions in the back substitution.  lidar_2d_sim.py:69-77.
+  double a00 = rx, a01 = -dx, a10 = ry, a11 = -dy;
+  if (fabs(a10) > fabs(a00)) {
+    double t0 = a00; a00 = a10; a10 = t0;
+    t0 = a01; a01 = a11; a11 = t0;
+    t0 = b0; b0 = b1; b1 = t0;
+  }
+  if (a00 == 0.0) return false;
+  double l = a10 * (1.0 / a00);
+  double u11 = fma(-l, a01, a11);
+  if (u11 == 0.0) return false;                          // LinAlgError: singular (ray parallel to border)
+  double y1 = fma(-l, b0, b1);
+  double x1 = y1 / u11;
+  double x0 = fma(-a01, x1, b0) / a00;
+  *t = x0;
+  *s = x1;
+  return true;
+}
+
+__global__ void __launch_bounds__(192)
+lidar_scan_kernel(const double* __restrict__ poses, const float* __restrict__ maze, int rows, int cols,
+                  double* __restrict__ dist, double* __restrict__ endpoints, uint8_t* __restrict__ hit,
+                  uint8_t* __restrict__ visited) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int ncell = rows * cols;
+  unsigned char* mz = lds;
+  unsigned char* vis = lds + ((ncell + 15) & ~15);
+  for (int i = threadIdx.x; i < ncell; i += blockDim.x) {
+    mz[i] = (maze[i] == 1.0f) ? 1 : 0;
+    vis[i] = 0;
+  }
+  __syncthreads();
+  const int b = blockIdx.x;
+  const int ray = threadIdx.x;
+  const double x0 = poses[(size_t)b * 3 + 0], y0 = poses[(size_t)b * 3 + 1], yaw = poses[(size_t)b * 3 + 2];
+  // maze_width, maze_height = maze_data.shape (sic, :51): "width" = rows
+  const double mw = (double)rows, mh = (double)cols;
+  if (ray < DITREE_LIDAR_RAYS) {
+    const double angle = -180.0 + 2.0 * (double)ray;                 // np.arange(-180, 182, 2)
+    const double ang = (yaw + angle) * (M_PI / 180.0);               // np.deg2rad(yaw + angle) (:53-54)
+    const double rx = cos(ang), ry = sin(ang);
+    // borders Left, Right, Bottom, Top (:57-62): origin b0, direction d
+    const double bx[4] = {0.0, mw, 0.0, 0.0}, by[4] = {0.0, 0.0, 0.0, mh};
+    const double dxs[4] = {0.0, 0.0, mw, mw}, dys[4] = {mh, mh, 0.0, 0.0};
+    double lx = x0, ly = y0;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (found) continue;
+      double t, s;
+      if (border_solve(rx, ry, dxs[k], dys[k], bx[k] - x0, by[k] - y0, &t, &s)) {
+        if (t >= 0.0 && s <= 1.0 && s >= 0.0) {                        // :74
+          lx = t * rx + x0;
+          ly = t * ry + y0;
+          found = true;
+        }
+      }
+    }
+    const double vx = lx - x0, vy = ly - y0;
+    const double len = sqrt(fma(vy, vy, vx * vx));                     // np.linalg.norm (ddot = one fma)
+    const double step = 0.1 / len;                                     // :85
+    // len(np.arange(0, 1, step)) = ceil((1 - 0) / step)
+    double nf = ceil(1.0 / step);
+    long long n = (found && nf > 0.0 && nf < 1e9) ? (long long)nf : 0;
+    bool h = false;
+    double ox = lx, oy = ly;
+    for (long long i = 0; i < n; ++i) {
+      double t = (double)i * step;                                     // arange value start + i*delta
+      double px = x0 + t * vx, py = y0 + t * vy;                       // :86
+      double fx = floor(px), fy = floor(py);
+      int qx = fx >= 0.0 ? (fx < mw ? (int)fx : rows - 1) : 0;         // clip to [0, maze_width-1]  (:89)
+      int qy = fy >= 0.0 ? (fy < mh ? (int)fy : cols - 1) : 0;         // clip to [0, maze_height-1]
+      // maze_data[q_y, q_x] (:91): q_y indexes rows.  On non-square maps the reference's swapped
+      // clip bounds can index past the array (IndexError); clamp so the device never faults.
+      int rr = min(qy, rows - 1), cc = min(qx, cols - 1);
+      if (mz[rr * cols + cc] == 1) {
+        h = true;
+        ox = px;
+        oy = py;
+        break;
+      }
+      vis[rr * cols + cc] = 1;                                         // benign race: all writers store 1
+    }
+    double ex = ox - x0, ey = oy - y0;
+    double d = sqrt(fma(ey, ey, ex * ex));                             // :96
+    d = d < 0.0 ? 0.0 : (d > 300.0 ? 300.0 : d);                       // scan(): np.clip(d, 0, max_range) (:33)
+    dist[(size_t)b * DITREE_LIDAR_RAYS + ray] = d;
+    endpoints[((size_t)b * DITREE_LIDAR_RAYS + ray) * 2 + 0] = x0 + d * rx;   // :36-39
+    endpoints[((size_t)b * DITREE_LIDAR_RAYS + ray) * 2 + 1] = y0 + d * ry;
+    hit[(size_t)b * DITREE_LIDAR_RAYS + ray] = h ? 1 : 0;
+  }
+  if (visited != nullptr) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncell; i += blockDim.x) visited[(size_t)b * ncell + i] = vis[i];
+  }
+}
+void launch_lidar_scan(const double* poses, int B, const float* maze, int rows, int cols, double* dist,
+                       double* endpoints, uint8_t* hit, uint8_t* visited, hipStream_t s) {
+  size_t n = ((size_t)rows * cols + 15) & ~(size_t)15;
+  hipLaunchKernelGGL(lidar_scan_kernel, dim3(B), dim3(192), 2 * n, s, poses, maze, rows, cols, dist, endpoints,
+                     hit, visited);
+}
+
+// ------------------------------------------------------------------------- round bookkeeping
+__global__ void round_begin_kernel(int32_t* status, int32_t* chunks_run, int32_t* chunk_steps, int B, int n_chunks) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  status[b] = DITREE_ST_OK;
+  chunks_run[b] = 0;
+  for (int j = 0; j < n_chunks; ++j) chunk_steps[(size_t)b * n_chunks + j] = 0;
+}
+void launch_round_begin(int32_t* status, int32_t* chunks_run, int32_t* chunk_steps, int B, int n_chunks,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(round_begin_kernel, dim3((B + 255) / 256), dim3(256), 0, s, status, chunks_run, chunk_steps, B,
+                     n_chunks);
+}
+
+// ------------------------------------------------------------------------- accept + commit
+// Phase 1 (one workgroup): the reference's sequential accept order (RRT.py:179-217) as a
+// scan.  counters: [0] n_nodes [1] goal node [2] env.done latched [3] chunk iterations
+// [4] candidates [5] sticky triggered [6] capacity overflow [7] phantom candidate (scratch).
+__global__ void __launch_bounds__(1024)
+accept_scan_kernel(ditree_tree t, ditree_round r, int emulate_sticky) {
+  __shared__ int s_first_goal, s_first_gac, s_total, s_iters;
+  __shared__ int s_wave_sum[16];
+  const int B = r.B;
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_first_goal = 0x7fffffff; s_first_gac = 0x7fffffff; s_total = 0; s_iters = 0; }
+  __syncthreads();
+  for (int b = tid; b < B; b += blockDim.x) {
+    int st = r.status[b];
+    if ((st & 0xff) == DITREE_ST_GOAL) atomicMin(&s_first_goal, b);
+    if (emulate_sticky && (st & 0xff) == DITREE_ST_COLLIDED && (st & DITREE_ST_FLAG_GOAL_AT_COLLISION))
+      atomicMin(&s_first_gac, b);
+  }
+  __syncthreads();
+  const int g = s_first_goal, c = s_first_gac;
+  const bool latched_in = emulate_sticky && t.counters[2] != 0;
+  int last = B - 1, phantom = -1, goal_cand = -1;
+  bool latch_out = latched_in;
+  if (latched_in) {
+    phantom = 0; last = 0; goal_cand = 0;
+  } else if (c != 0x7fffffff && (g == 0x7fffffff || g > c)) {
+    if (c + 1 < B) { phantom = c + 1; last = c + 1; goal_cand = c + 1; latch_out = true; }
+    else { latch_out = true; }
+  } else if (g != 0x7fffffff) {
+    last = g; goal_cand = g;
+  }
+  const int n0 = t.counters[0];
+  // ordered prefix sum of accepted flags over candidates 0..last, 1024 at a time
+  int base = 0;
+  for (int start = 0; start <= last; start += blockDim.x) {
+    int b = start + tid;
+    int acc = 0, it = 0;
+    if (b <= last) {
+      int st = r.status[b] & 0xff;
+      acc = (b == phantom) ? 1 : (st != DITREE_ST_COLLIDED);
+      it = (b == phantom) ? 1 : r.chunks_run[b];
+      atomicAdd(&t.num_visit[r.parent[b]], 1);
+    }
+    // wave inclusive scan
+    int v = acc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int o = __shfl_up(v, d);
+      if ((tid & 63) >= d) v += o;
+    }
+    int itw = it;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) itw += __shfl_xor(itw, m);
+    if ((tid & 63) == 63) s_wave_sum[tid >> 6] = v;
+    if ((tid & 63) == 0) atomicAdd(&s_iters, itw);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < (tid >> 6); ++w) woff += s_wave_sum[w];
+    int chunk_total = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) chunk_total += s_wave_sum[w];
+    if (b <= last) {
+      int rank = base + woff + v - acc;                 // exclusive rank
+      int id = acc ? (n0 + rank) : -1;
+      if (id >= t.capacity) id = -1;
+      r.node_id[b] = id;
+    }
+    base += chunk_total;
+    __syncthreads();
+  }
+  for (int b = last + 1 + tid; b < B; b += blockDim.x) r.node_id[b] = -1;
+  __syncthreads();
+  if (tid == 0) {
+    int total = base;
+    int n1 = n0 + total;
+    if (n1 > t.capacity) { n1 = t.capacity; t.counters[6] = 1; }
+    t.counters[0] = n1;
+    if (goal_cand >= 0) {
+      int gid = r.node_id[goal_cand];
+      t.counters[1] = gid;
+    }
+    t.counters[2] = (emulate_sticky && latch_out && phantom < 0) ? 1 : ((phantom >= 0) ? 1 : t.counters[2]);
+    t.counters[3] += s_iters;
+    t.counters[4] += last + 1;
+    if (phantom >= 0) t.counters[5] = 1;
+    t.counters[7] = phantom;
+  }
+}
+
+// Phase 2: one wave per candidate copies the accepted edge into its node slot, dropping
+// all-zero rows (RRT.py:196-199).
+__global__ void __launch_bounds__(64)
+accept_commit_kernel(ditree_tree t, ditree_round r) {
+  const int b = blockIdx.x;
+  const int id = r.node_id[b];
+  if (id < 0) return;
+  const int lane = threadIdx.x;
+  const int A = t.A, nC = t.n_chunks;
+  const int phantom = t.counters[7];
+  const int par = r.parent[b];
+  const size_t es_cap = (size_t)nC * (A + 1), ea_cap = (size_t)nC * A;
+  double* es = t.edge_states + (size_t)id * es_cap * 6;
+  double* ea = t.edge_actions + (size_t)id * ea_cap * 2;
+  const double* cs = r.states + (size_t)b * es_cap * 6;
+  const double* ca = r.actions + (size_t)b * ea_cap * 2;
+  int ns = 0, na = 0;
+  double endst[6];
+  if (b == phantom) {
+    // frozen env step (car_env.py:254): the edge is [s, s] and the first sampled action
+    for (int k = 0; k < 6; ++k) endst[k] = t.state[(size_t)par * 6 + k];
+    bool zero = true;
+    for (int k = 0; k < 6; ++k) zero &= (endst[k] == 0.0);
+    if (!zero) {
+      if (lane < 6) { es[lane] = endst[lane]; es[6 + lane] = endst[lane]; }
+      ns = 2;
+    }
+    if (!(ca[0] == 0.0 && ca[1] == 0.0)) {
+      if (lane < 2) ea[lane] = ca[lane];
+      na = 1;
+    }
+  } else {
+    for (int k = 0; k < 6; ++k) endst[k] = r.end_state[(size_t)b * 6 + k];
+    const int run = r.chunks_run[b];
+    const int rows_s = run * (A + 1), rows_a = run * A;
+    // serial compaction per wave: rows are few (<= 72) and tiny
+    for (int row = 0; row < rows_s; ++row) {
+      const double* p = cs + (size_t)row * 6;
+      bool zero = true;
+      for (int k = 0; k < 6; ++k) zero &= (p[k] == 0.0);
+      if (!zero) {
+        if (lane < 6) es[(size_t)ns * 6 + lane] = p[lane];
+        ++ns;
+      }
+    }
+    for (int row = 0; row < rows_a; ++row) {
+      const double* p = ca + (size_t)row * 2;
+      if (!(p[0] == 0.0 && p[1] == 0.0)) {
+        if (lane < 2) ea[(size_t)na * 2 + lane] = p[lane];
+        ++na;
+      }
+    }
+  }
+  if (lane < 6) t.state[(size_t)id * 6 + lane] = endst[lane];
+  if (lane < 2) t.xy[(size_t)id * 2 + lane] = endst[lane];
+  if (lane == 0) {
+    t.parent[id] = par;
+    t.has_prev[id] = 1;
+    t.num_visit[id] = 0;
+    t.edge_nstates[id] = ns;
+    t.edge_nactions[id] = na;
+  }
+  __syncthreads();
+  if (lane < 2) t.last_action[(size_t)id * 2 + lane] = (na > 0) ? ea[(size_t)(na - 1) * 2 + lane] : 0.0;
+}
+
+void launch_accept(const ditree_tree& t, const ditree_round& r, int emulate_sticky, hipStream_t s) {
+  hipLaunchKernelGGL(accept_scan_kernel, dim3(1), dim3(1024), 0, s, t, r, emulate_sticky);
+  hipLaunchKernelGGL(accept_commit_kernel, dim3(r.B), dim3(64), 0, s, t, r);
+}

@@ -1,0 +1,232 @@
+"""Device-resident tree + round driver of the DiTree expansion engine.
+
+The reference keeps a Python list of ``Node`` objects (planners/base_planner.py:24-34)
+and expands one candidate at a time (planners/RRT.py:131-219).  Here the tree is a
+struct of arrays in HBM and a *round* expands B candidates against the tree snapshot:
+nearest node -> n_chunks x [local map -> conditioning -> denoiser -> 8-step rollout with
+goal / collision tests] -> accept in candidate order.  B = 1 is the reference loop.
+
+With ``world_size > 1`` (one process per GPU, torch.distributed / RCCL) each rank expands
+a contiguous block of the round's candidates and the candidate records are all-gathered
+before the (replicated, deterministic) accept step, so every rank holds the same tree.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Round, RoundParams, Tree, check, lib
+from .ops import CAR_NORM, Context, _dbl, _flt, _ptr, local_axis
+
+CNT_NODES, CNT_GOAL, CNT_LATCH, CNT_ITERS, CNT_CANDS, CNT_STICKY, CNT_OVERFLOW, CNT_PHANTOM = range(8)
+
+
+class DeviceTree:
+    def __init__(self, ctx: Context, capacity: int, n_chunks: int, A: int):
+        dev = ctx.device
+        self.capacity, self.n_chunks, self.A = capacity, n_chunks, A
+        f64, i32, u8 = torch.float64, torch.int32, torch.uint8
+        self.state = torch.zeros(capacity, 6, dtype=f64, device=dev)
+        self.xy = torch.zeros(capacity, 2, dtype=f64, device=dev)
+        self.parent = torch.full((capacity,), -1, dtype=i32, device=dev)
+        self.last_action = torch.zeros(capacity, 2, dtype=f64, device=dev)
+        self.has_prev = torch.zeros(capacity, dtype=u8, device=dev)
+        self.num_visit = torch.zeros(capacity, dtype=i32, device=dev)
+        self.edge_states = torch.zeros(capacity, n_chunks * (A + 1), 6, dtype=f64, device=dev)
+        self.edge_actions = torch.zeros(capacity, n_chunks * A, 2, dtype=f64, device=dev)
+        self.edge_nstates = torch.zeros(capacity, dtype=i32, device=dev)
+        self.edge_nactions = torch.zeros(capacity, dtype=i32, device=dev)
+        self.counters = torch.zeros(8, dtype=i32, device=dev)
+        self.desc = Tree(capacity, n_chunks, A, *[t.data_ptr() for t in (
+            self.state, self.xy, self.parent, self.last_action, self.has_prev, self.num_visit,
+            self.edge_states, self.edge_actions, self.edge_nstates, self.edge_nactions, self.counters)])
+        self.n_nodes_host = 0
+
+    def reset(self, start_state):
+        s = torch.as_tensor(np.asarray(start_state, dtype=np.float64), device=self.state.device)
+        self.state[0] = s
+        self.xy[0] = s[:2]
+        self.parent[0] = -1
+        self.last_action[0] = 0
+        self.has_prev[0] = 0
+        self.num_visit.zero_()
+        self.edge_nstates[0] = 0
+        self.edge_nactions[0] = 0
+        self.counters.zero_()
+        self.counters[CNT_NODES] = 1
+        self.counters[CNT_GOAL] = -1
+        self.counters[CNT_PHANTOM] = -1
+        self.n_nodes_host = 1
+
+    def read_counters(self):
+        c = self.counters.cpu().numpy()
+        self.n_nodes_host = int(c[CNT_NODES])
+        return c
+
+
+class RoundBuffers:
+    def __init__(self, ctx: Context, B: int, n_chunks: int, A: int):
+        dev = ctx.device
+        self.B = B
+        f64, i32 = torch.float64, torch.int32
+        self.parent = torch.zeros(B, dtype=i32, device=dev)
+        self.status = torch.zeros(B, dtype=i32, device=dev)
+        self.chunks_run = torch.zeros(B, dtype=i32, device=dev)
+        self.end_state = torch.zeros(B, 6, dtype=f64, device=dev)
+        self.states = torch.zeros(B, n_chunks, A + 1, 6, dtype=f64, device=dev)
+        self.actions = torch.zeros(B, n_chunks, A, 2, dtype=f64, device=dev)
+        self.chunk_steps = torch.zeros(B, n_chunks, dtype=i32, device=dev)
+        self.node_id = torch.full((B,), -1, dtype=i32, device=dev)
+
+    def fields(self):
+        return (self.parent, self.status, self.chunks_run, self.end_state, self.states, self.actions,
+                self.chunk_steps, self.node_id)
+
+    def desc(self, lo=0, n=None):
+        n = self.B - lo if n is None else n
+        return Round(n, *[t[lo:lo + n].data_ptr() if n > 0 else t.data_ptr() for t in self.fields()])
+
+
+class ExpansionEngine:
+    """Batched RRT expansion on one GPU (optionally one shard of a multi-GPU round)."""
+
+    def __init__(self, ctx: Context, maze, start_state, goal_state, edge_length=64, action_horizon=8,
+                 pred_horizon=64, local_map_size=20, local_map_scale=0.2, s_global=1.0, batch=1024,
+                 capacity=65536, k_steps=1, emulate_sticky_done=True, norm=CAR_NORM, rank=0, world_size=1,
+                 process_group=None):
+        self.ctx = ctx
+        self.maze = np.asarray(maze, dtype=np.float32)
+        self.H, self.A, self.P = edge_length, action_horizon, pred_horizon
+        self.n_chunks = edge_length // action_horizon
+        self.lm_n, self.lm_scale, self.s_global = local_map_size, local_map_scale, s_global
+        self.batch = batch
+        self.k_steps = k_steps
+        self.sticky = int(bool(emulate_sticky_done))
+        self.norm = np.ascontiguousarray(norm, dtype=np.float64)
+        self.rank, self.world, self.pg = rank, world_size, process_group
+        self.tree = DeviceTree(ctx, capacity, self.n_chunks, self.A)
+        self.rb = RoundBuffers(ctx, batch, self.n_chunks, self.A)
+        self.axis = local_axis(local_map_size, local_map_scale)
+        from .common.fm_utils import get_timesteps
+        t0, dt = get_timesteps("exp", k_steps, 4.0)
+        self.t0, self.dt = t0.numpy().copy(), dt.numpy().copy()
+        ctx.upload_maze(self.maze)
+        self.reset(start_state, goal_state)
+
+    # ------------------------------------------------------------------ state
+    def reset(self, start_state, goal_state):
+        self.start_state = np.asarray(start_state, dtype=np.float64).copy()
+        self.goal_state = np.asarray(goal_state, dtype=np.float64).copy()
+        H, W = self.maze.shape
+        # planner.reset -> env.reset(options): env.goal = centre of the goal cell (car_env.py:189-201,225-226)
+        gi = np.floor((H / 2 - self.goal_state[1]) / 1.0)
+        gj = np.floor((self.goal_state[0] + W / 2) / 1.0)
+        self.env_goal = np.array([(gj + 0.5) * 1.0 - W / 2, H / 2 - (gi + 0.5) * 1.0])
+        self.tree.reset(self.start_state)
+
+    def update_maze(self, maze):
+        self.maze = np.asarray(maze, dtype=np.float32)
+        self.ctx.upload_maze(self.maze)
+
+    def shard(self, B):
+        """Contiguous candidate block of this rank."""
+        per = (B + self.world - 1) // self.world
+        lo = min(self.rank * per, B)
+        hi = min(lo + per, B)
+        return lo, hi, per
+
+    # ------------------------------------------------------------------ one round
+    def expand_round(self, samples, cond_goal, noise=None, inject_actions=None, accept=True):
+        """samples (B,6) f64, cond_goal (B,2) f64 [device tensors, all candidates of the round];
+        noise (B, n_chunks, P, 2) f32 or inject_actions (B, n_chunks, P, 2) f64 for this round."""
+        B = samples.shape[0]
+        if B > self.rb.B:
+            raise ValueError(f"round of {B} candidates exceeds engine batch {self.rb.B}")
+        lo, hi, per = self.shard(B)
+        n = hi - lo
+        rp = RoundParams()
+        rp.n_nodes = self.tree.n_nodes_host
+        rp.samples = samples[lo:hi].data_ptr() if n else None
+        rp.cond_goal = cond_goal[lo:hi].data_ptr() if n else None
+        rp.noise = noise[lo:hi].data_ptr() if (noise is not None and n) else None
+        rp.inject_actions = inject_actions[lo:hi].data_ptr() if (inject_actions is not None and n) else None
+        rp.P, rp.K = self.P, self.k_steps
+        keep = []
+        for name, arr, conv in (("t0", self.t0, _flt), ("dt", self.dt, _flt), ("norm", self.norm, _dbl),
+                                ("goal_xy", self.env_goal, _dbl), ("axis", self.axis, _dbl)):
+            a, p = conv(arr)
+            keep.append(a)
+            setattr(rp, name, p)
+        rp.lm_n, rp.lm_size, rp.s_global = self.lm_n, float(self.lm_n), float(self.s_global)
+        if n > 0:
+            rd = self.rb.desc(lo, n)
+            check(self.ctx._h, lib().ditree_expand_round(self.ctx._h, C.byref(self.tree.desc), C.byref(rd),
+                                                          C.byref(rp), self.ctx.stream), "expand_round")
+        if self.world > 1:
+            self._allgather_round(B, per)
+        if accept:
+            self.accept(B)
+
+    def _allgather_round(self, B, per):
+        """One fixed-stride all-gather per record field (RCCL over xGMI when the backend is nccl)."""
+        import torch.distributed as dist
+        for t in self.rb.fields()[:-1]:
+            flat = t[: per * self.world]
+            if flat.shape[0] < per * self.world:
+                raise ValueError("engine batch must be >= ceil(B / world) * world")
+            lo = self.rank * per
+            dist.all_gather_into_tensor(flat, flat[lo:lo + per].clone(), group=self.pg)
+
+    def accept(self, B):
+        rd = self.rb.desc(0, B)
+        check(self.ctx._h, lib().ditree_accept(self.ctx._h, C.byref(self.tree.desc), C.byref(rd), self.sticky,
+                                                self.ctx.stream), "accept")
+        return self.tree.read_counters()          # one small D2H per round: n_nodes / goal
+
+    # ------------------------------------------------------------------ results
+    @property
+    def goal_node(self):
+        g = int(self.tree.counters[CNT_GOAL].item())
+        return None if g < 0 else g
+
+    def fallback_node(self):
+        """planners/RRT.py:233-237 (run_type 0): among nodes 1.., nearest to goal_state xy."""
+        n = self.tree.n_nodes_host
+        if n < 2:
+            return None
+        d = self.tree.xy[1:n].cpu().numpy() - self.goal_state[:2]          # once per plan, host side
+        return 1 + int(np.argmin(np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])))
+
+    def path_to(self, node):
+        """planners/base_planner.py:342-363: float32 path (edge states + node states) and actions."""
+        t = self.tree
+        parents = t.parent[: t.n_nodes_host].cpu().numpy()
+        chain = []
+        n = int(node)
+        while n != -1:
+            chain.append(n)
+            n = int(parents[n])
+        chain = chain[::-1]
+        idx = torch.as_tensor(chain, device=t.state.device, dtype=torch.long)
+        st = t.state[idx].cpu().numpy()
+        es = t.edge_states[idx].cpu().numpy()
+        ea = t.edge_actions[idx].cpu().numpy()
+        ns = t.edge_nstates[idx].cpu().numpy()
+        na = t.edge_nactions[idx].cpu().numpy()
+        path, actions = [], []
+        for k, nd in enumerate(chain):
+            if nd != 0:
+                path.extend(es[k, : ns[k]])
+                actions.extend(ea[k, : na[k]])
+            path.append(st[k])
+        path = np.array(path, dtype=np.float32) if path else None
+        actions = np.array(actions, dtype=np.float32) if actions else None
+        return path, actions
+
+    def tree_snapshot(self):
+        n = self.tree.n_nodes_host
+        return dict(parents=self.tree.parent[:n].cpu().numpy(), states=self.tree.state[:n].cpu().numpy(),
+                    counters=self.tree.counters.cpu().numpy())

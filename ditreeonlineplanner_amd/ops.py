@@ -1,0 +1,175 @@
+"""Torch-tensor front end of the C-ABI (one ``Context`` per process and device).
+
+Tensors are containers only: every method passes ``data_ptr()`` of caller-owned CUDA
+tensors plus sizes to libditree_hip.so and enqueues on torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Round, RoundParams, Tree, check, lib
+
+LIDAR_RAYS = 181
+
+# metadata/carmaze.pt (reference) -- Observations_mean/std, Actions_mean/std; see DESIGN.md
+CAR_NORM = np.array([0.0, 0.0, 0.0, 5.0, 0.5, 0.0,
+                     5.0, 5.0, 3.141592653589793, 5.0, 0.5, 0.4,
+                     0.45102226669605805, 0.0,
+                     1.0061299587120194, 0.9234329966426903], dtype=np.float64)
+
+
+def local_axis(n: int, scale: float) -> np.ndarray:
+    """The reference's np.linspace(-L/2 + s/2, L/2 - s/2, n) (common/map_utils.py:422-423)."""
+    L = n * scale
+    return np.linspace(-L / 2 + scale / 2, L / 2 - scale / 2, n)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype, name, dev):
+    if not isinstance(t, torch.Tensor) or t.dtype != dtype or not t.is_contiguous() or t.device != dev:
+        raise TypeError(f"{name}: need a contiguous {dtype} tensor on {dev}")
+
+
+def _dbl(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _flt(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Context:
+    """Owns a ``ditree_ctx`` on one GPU."""
+
+    def __init__(self, device: int | torch.device | None = None):
+        if not torch.cuda.is_available():
+            raise _lib.DitreeLibraryError("no GPU visible: the expansion engine has no CPU path")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else device.index or 0)
+        self._h = C.c_void_p()
+        rc = lib().ditree_ctx_create(self.device.index, C.byref(self._h))
+        if rc != 0:
+            raise _lib.DitreeError(f"ditree_ctx_create failed ({rc})")
+        self.maze_shape = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ditree_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ maze
+    def upload_maze(self, maze):
+        m = np.ascontiguousarray(np.asarray(maze, dtype=np.float32))
+        if m.ndim != 2:
+            raise ValueError("maze must be 2-D")
+        check(self._h, lib().ditree_upload_maze(self._h, m.ctypes.data_as(C.POINTER(C.c_float)), m.shape[0],
+                                                 m.shape[1], self.stream), "upload_maze")
+        self.maze_shape = m.shape
+
+    # ------------------------------------------------------------------ nearest node
+    def nn_argmin(self, queries, node_xy, n_nodes=None, gather=None):
+        """queries (B, >=2) f64, node_xy (N, 2) f64 -> idx (B,) i32.  ``gather`` =
+        (node_state, node_last_action, node_has_prev) also returns the gathered rows."""
+        dev = self.device
+        _chk(queries, torch.float64, "queries", dev)
+        _chk(node_xy, torch.float64, "node_xy", dev)
+        B = queries.shape[0]
+        N = node_xy.shape[0] if n_nodes is None else int(n_nodes)
+        idx = torch.empty(B, dtype=torch.int32, device=dev)
+        if gather is None:
+            args = [None] * 6
+            outs = None
+        else:
+            ns, na, nh = gather
+            _chk(ns, torch.float64, "node_state", dev)
+            _chk(na, torch.float64, "node_last_action", dev)
+            _chk(nh, torch.uint8, "node_has_prev", dev)
+            outs = (torch.empty(B, 6, dtype=torch.float64, device=dev),
+                    torch.empty(B, 2, dtype=torch.float64, device=dev),
+                    torch.empty(B, dtype=torch.uint8, device=dev))
+            args = [_ptr(ns), _ptr(na), _ptr(nh), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2])]
+        check(self._h, lib().ditree_nn_argmin(self._h, _ptr(queries), queries.shape[1], B, _ptr(node_xy), N,
+                                               _ptr(idx), *args, self.stream), "nn_argmin")
+        return idx if outs is None else (idx, *outs)
+
+    # ------------------------------------------------------------------ local map
+    def local_map(self, state, n=20, scale=0.2, s_global=1.0, scaled=False, active=None, out=None):
+        dev = self.device
+        _chk(state, torch.float64, "state", dev)
+        B = state.shape[0]
+        if out is None:
+            out = torch.empty(B, n, n, dtype=torch.float32, device=dev)
+        ax, axp = _dbl(local_axis(n, scale))
+        check(self._h, lib().ditree_local_map(self._h, _ptr(state), _ptr(active), B, n, axp, float(s_global),
+                                               int(bool(scaled)), _ptr(out), self.stream), "local_map")
+        return out
+
+    # ------------------------------------------------------------------ cond vector
+    def cond_vector(self, state, prev_action, has_prev, cond_goal, local_map_size=20, norm=CAR_NORM):
+        dev = self.device
+        _chk(state, torch.float64, "state", dev)
+        _chk(prev_action, torch.float64, "prev_action", dev)
+        _chk(has_prev, torch.uint8, "has_prev", dev)
+        _chk(cond_goal, torch.float64, "cond_goal", dev)
+        B = state.shape[0]
+        out = torch.empty(B, 7, dtype=torch.float32, device=dev)
+        nm, nmp = _dbl(norm)
+        check(self._h, lib().ditree_cond_vector(self._h, _ptr(state), _ptr(prev_action), _ptr(has_prev),
+                                                 _ptr(cond_goal), B, nmp, float(local_map_size), _ptr(out),
+                                                 self.stream), "cond_vector")
+        return out
+
+    # ------------------------------------------------------------------ rollout
+    def car_rollout(self, state, actions, goal_xy, A=8, status=None, prev_action=None, has_prev=None):
+        """state (B,6) f64 [updated in place], actions (B, n>=A, 2) f64.
+        Returns (status, states (B,A+1,6), actions_out (B,A,2), steps)."""
+        dev = self.device
+        _chk(state, torch.float64, "state", dev)
+        _chk(actions, torch.float64, "actions", dev)
+        B = state.shape[0]
+        if status is None:
+            status = torch.zeros(B, dtype=torch.int32, device=dev)
+        states = torch.zeros(B, A + 1, 6, dtype=torch.float64, device=dev)
+        aout = torch.zeros(B, A, 2, dtype=torch.float64, device=dev)
+        steps = torch.zeros(B, dtype=torch.int32, device=dev)
+        g, gp = _dbl(goal_xy)
+        check(self._h, lib().ditree_car_rollout(self._h, _ptr(state), _ptr(actions), actions.shape[1] * 2,
+                                                 _ptr(status), B, A, gp, _ptr(states), (A + 1) * 6, _ptr(aout),
+                                                 A * 2, _ptr(steps), _ptr(prev_action), _ptr(has_prev),
+                                                 self.stream), "car_rollout")
+        return status, states, aout, steps
+
+    # ------------------------------------------------------------------ lidar
+    def lidar_scan(self, poses, maze_dev, want_visited=True):
+        dev = self.device
+        _chk(poses, torch.float64, "poses", dev)
+        _chk(maze_dev, torch.float32, "maze", dev)
+        B = poses.shape[0]
+        rows, cols = maze_dev.shape
+        dist = torch.empty(B, LIDAR_RAYS, dtype=torch.float64, device=dev)
+        ends = torch.empty(B, LIDAR_RAYS, 2, dtype=torch.float64, device=dev)
+        hit = torch.empty(B, LIDAR_RAYS, dtype=torch.uint8, device=dev)
+        vis = torch.empty(B, rows, cols, dtype=torch.uint8, device=dev) if want_visited else None
+        check(self._h, lib().ditree_lidar_scan(self._h, _ptr(poses), B, _ptr(maze_dev), rows, cols, _ptr(dist),
+                                                _ptr(ends), _ptr(hit), _ptr(vis), self.stream), "lidar_scan")
+        return dist, ends, hit, vis

@@ -1,0 +1,220 @@
+/*
+ * ditree.h -- C-ABI of the MI355X-native DiTree expansion engine (libditree_hip.so).
+ *
+ * The reference (JJKK1313/DiTreeOnlinePlanner) is pure Python and has no FFI; its
+ * "plugin boundary" for the hot path is the Python object surface that
+ * run_scenarios*.py uses.  This header is the boundary the
+ * build defines underneath that surface: every entry point below replaces the
+ * numpy / scipy / PyTorch call site cited next to it (paths relative to the
+ * reference root).  The Python facades in ditreeonlineplanner_amd/ bind these
+ * symbols with ctypes (INTEGRATION.md shows the stub) and keep the reference's class
+ * and argument names.
+ *
+ * Conventions
+ *   - One ditree_ctx per (process, device).  A ctx is not re-entrant.
+ *   - Every pointer argument marked [dev] is a caller-owned DEVICE pointer
+ *     (e.g. torch.Tensor.data_ptr()); [host] is host memory read before return.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work
+ *     is enqueued asynchronously on it; nothing synchronises the device.
+ *   - Return value: 0 = ok, negative = DITREE_E_*; ditree_last_error(ctx) gives text
+ *     valid until the next call on that ctx.  No exceptions, no exit().
+ *   - Layouts are the reference's: states (.., 6) f64 = x, y, psi, v, D, delta;
+ *     actions (.., 2) f64 = dD, ddelta; mazes row-major (rows, cols) f32 in {0, 1}.
+ */
+#ifndef DITREE_H
+#define DITREE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DITREE_VERSION 100          /* 0.1.0 */
+
+#define DITREE_OK 0
+#define DITREE_E_ARG (-1)           /* bad argument (null pointer, size out of range) */
+#define DITREE_E_HIP (-2)           /* a HIP runtime call failed */
+#define DITREE_E_STATE (-3)         /* call order (no maze / no weights uploaded) */
+#define DITREE_E_NOMEM (-4)
+
+/* per-chunk / per-candidate status codes written by the rollout kernels */
+#define DITREE_ST_NOT_RUN (-1)
+#define DITREE_ST_OK 0              /* chunk finished: neither goal nor collision */
+#define DITREE_ST_GOAL 1            /* planners/base_planner.py:300,314-317  (done is True) */
+#define DITREE_ST_COLLIDED 2        /* planners/base_planner.py:306-312      (done is None) */
+#define DITREE_ST_FLAG_GOAL_AT_COLLISION 0x100  /* the colliding step was inside the goal radius */
+
+typedef struct ditree_ctx ditree_ctx;
+
+int32_t ditree_version(void);
+int32_t ditree_ctx_create(int32_t device, ditree_ctx** out);
+void ditree_ctx_destroy(ditree_ctx* ctx);
+const char* ditree_last_error(ditree_ctx* ctx);
+
+/* The planner's *known* occupancy grid (planners/base_planner.py:118 `self.maze`,
+ * planners/RRT.py:57-59 update_maze).  Copies rows*cols floats host->device on
+ * `stream`; used by ditree_local_map / ditree_car_rollout / ditree_expand_round. */
+int32_t ditree_upload_maze(ditree_ctx* ctx, const float* maze /*[host] rows*cols*/,
+                           int32_t rows, int32_t cols, void* stream);
+
+/* planners/RRT.py:49-51 nearest_node (scipy KDTree.query, k = 1, first two dims) plus
+ * the gather of the chosen node's fields (RRT.py:139-146).
+ *   queries   [dev] (B, q_stride) f64, xy in columns 0..1
+ *   node_xy   [dev] (N, 2) f64
+ * Outputs (any may be NULL except out_idx):
+ *   out_idx   [dev] (B,) i32  argmin_n ||q - node_n||^2, ties -> lowest n
+ *   when node_state != NULL: out_state (B,6) = node_state[idx],
+ *   out_prev_action (B,2) = node_last_action[idx], out_has_prev (B,) u8. */
+int32_t ditree_nn_argmin(ditree_ctx* ctx, const double* queries, int32_t q_stride, int32_t B,
+                         const double* node_xy, int32_t N, int32_t* out_idx,
+                         const double* node_state, const double* node_last_action,
+                         const uint8_t* node_has_prev, double* out_state,
+                         double* out_prev_action, uint8_t* out_has_prev, void* stream);
+
+/* common/map_utils.py:391-459 create_local_map on the uploaded maze.
+ *   state [dev] (B, 6) f64 (x, y, psi used); active [dev] (B,) i32 or NULL: rows with
+ *   active[b] != DITREE_ST_OK are skipped;  axis [host] n doubles = the reference's
+ *   np.linspace(-L/2 + s/2, L/2 - s/2, n) (map_utils.py:422-423), uploaded into ctx.
+ *   out [dev] (B, n, n) f32; values m, or 2m-1 when scaled != 0 (policies/fm_policy.py:152). */
+int32_t ditree_local_map(ditree_ctx* ctx, const double* state, const int32_t* active, int32_t B,
+                         int32_t n, const double* axis, double s_global, int32_t scaled,
+                         float* out, void* stream);
+
+/* policies/fm_policy.py:60-143 (car): conditioning vector (B, 7) f32 =
+ * [(v-5)/5, (D-.5)/.5, delta/.4 | (a_prev-mu)/sigma or 0,0 | tanh(R(-psi)(g-p)/lm_size)].
+ *   norm [host] 16 doubles: obs_mean[6], obs_std[6], act_mean[2], act_std[2]. */
+int32_t ditree_cond_vector(ditree_ctx* ctx, const double* state, const double* prev_action,
+                           const uint8_t* has_prev, const double* cond_goal, int32_t B,
+                           const double* norm, double local_map_size, float* out, void* stream);
+
+/* planners/base_planner.py:257-320 propagate_action_sequence_env for B candidates:
+ * A Euler steps of car_env.py:356-396, each followed by the goal test
+ * (car_env.py:341-354) and the two-ball collision test (common/map_utils.py:103-115,
+ * :221-329) against the uploaded maze.
+ *   state_io   [dev] (B,6) f64  in: start state, out: end state (`obs`)
+ *   actions    [dev] (B, act_stride) f64, rows of 2; the first A rows are used
+ *   status_io  [dev] (B,) i32   in: rows != DITREE_ST_OK are skipped; out: chunk result
+ *   states_out [dev] (B, states_stride) f64: (A+1, 6) rows; rows after the last
+ *              executed step stay zero (base_planner.py:282)
+ *   actions_out[dev] (B, actout_stride) f64: (A, 2) copy with rows after the goal step
+ *              zeroed (base_planner.py:314-317)
+ *   steps_out  [dev] (B,) i32 env steps executed (the colliding step counts)
+ *   prev_action_io / has_prev_io: on DITREE_ST_OK updated to the chunk's last action
+ *              (planners/RRT.py:188), may be NULL. */
+int32_t ditree_car_rollout(ditree_ctx* ctx, double* state_io, const double* actions,
+                           int64_t act_stride, int32_t* status_io, int32_t B, int32_t A,
+                           const double* goal_xy /*[host] 2*/, double* states_out,
+                           int64_t states_stride, double* actions_out, int64_t actout_stride,
+                           int32_t* steps_out, double* prev_action_io, uint8_t* has_prev_io,
+                           void* stream);
+
+/* lidar_sim/lidar_2d_sim.py:18-98 Lidar2DSim.scan for B poses (pose = x_col, y_row, yaw
+ * in cell units) against `maze` [dev] (rows, cols) f32 (the *true* world, which may
+ * differ from the uploaded known maze).  181 rays, arange(-180, 182, 2) degrees.
+ *   dist [dev] (B,181) f64; endpoints [dev] (B,181,2) f64; hit [dev] (B,181) u8;
+ *   visited [dev] (B, rows*cols) u8 or NULL: 1 where a ray sample fell before its hit. */
+int32_t ditree_lidar_scan(ditree_ctx* ctx, const double* poses, int32_t B, const float* maze,
+                          int32_t rows, int32_t cols, double* dist, double* endpoints,
+                          uint8_t* hit, uint8_t* visited, void* stream);
+
+/* ------------------------------------------------------------------ tree + rounds */
+
+/* Device-resident tree (planners/base_planner.py:24-34 Node as SoA; all [dev]). */
+typedef struct {
+  int32_t capacity;          /* node slots */
+  int32_t n_chunks, A;       /* edge_length / action_horizon, action_horizon */
+  double* state;             /* (cap, 6) */
+  double* xy;                /* (cap, 2)  copy of state[:, :2] for the NN scan */
+  int32_t* parent;           /* (cap,) */
+  double* last_action;       /* (cap, 2)  last row of parent_action_seq */
+  uint8_t* has_prev;         /* (cap,)    parent_action_seq is not None and not empty */
+  int32_t* num_visit;        /* (cap,) */
+  double* edge_states;       /* (cap, n_chunks*(A+1), 6)  zero-row-filtered, RRT.py:198-199 */
+  double* edge_actions;      /* (cap, n_chunks*A, 2)      zero-row-filtered, RRT.py:196-197 */
+  int32_t* edge_nstates;     /* (cap,) rows kept */
+  int32_t* edge_nactions;    /* (cap,) */
+  int32_t* counters;         /* [0] n_nodes, [1] goal node (-1 none), [2] env.done latched
+                                (car_env.py:254,266 "sticky done"), [3] chunk iterations,
+                                [4] candidates processed, [5] sticky-done triggered */
+} ditree_tree;
+
+/* Per-round candidate records (all [dev]); B rows, written by ditree_expand_round or
+ * by the individual ops, consumed by ditree_accept. */
+typedef struct {
+  int32_t B;
+  int32_t* parent;           /* (B,) */
+  int32_t* status;           /* (B,) final DITREE_ST_* (| FLAG_GOAL_AT_COLLISION) */
+  int32_t* chunks_run;       /* (B,) */
+  double* end_state;         /* (B, 6) */
+  double* states;            /* (B, n_chunks, A+1, 6) */
+  double* actions;           /* (B, n_chunks, A, 2) */
+  int32_t* chunk_steps;      /* (B, n_chunks) */
+  int32_t* node_id;          /* (B,) out: assigned node index or -1 */
+} ditree_round;
+
+/* planners/RRT.py:179-217: accept candidates in index order (collided edges dropped,
+ * lowest goal-reaching accepted index ends the plan, later candidates dropped),
+ * filter all-zero rows, append nodes.  emulate_sticky != 0 reproduces the latched
+ * env.done defect described in DESIGN.md. */
+int32_t ditree_accept(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
+                      int32_t emulate_sticky, void* stream);
+
+/* ------------------------------------------------------------------ denoiser */
+
+/* Upload the denoiser weights (reference: run_scenarios.py:157-185, state-dict keys
+ * `encoder.resnet18.*`, `unet.*`).  `blob` [host] is the flat fp32 parameter blob and
+ * `manifest` [host] a NUL-terminated text table "name offset n_elems dims...\n" built by
+ * ditreeonlineplanner_amd/weights.py; the library repacks into MFMA-friendly bf16
+ * (and, for the f32 parity instantiation, fp32) tiles on the device. */
+int32_t ditree_load_weights(ditree_ctx* ctx, const float* blob, int64_t n_floats,
+                            const char* manifest, void* stream);
+
+/* Allocate the activation workspace for up to max_batch candidates. */
+int32_t ditree_denoise_reserve(ditree_ctx* ctx, int32_t max_batch, int32_t precision);
+#define DITREE_PREC_BF16 0          /* bf16 MFMA inputs, fp32 accumulate (throughput path) */
+#define DITREE_PREC_F32 1           /* fp32 MFMA (v_mfma_f32_32x32x2_f32), parity path */
+
+/* policies/fm_policy.py:155-203 + local_map_encoder.py:101-109 +
+ * model/diffusion/conditional_unet1d.py:268-347: K flow steps of
+ * x <- x + net(x, map, 20*t0[k], cond) * dt[k], then a = x*sigma + mu.
+ *   noise     [dev] (B, P, 2) f32   x0 ~ N(0, I)
+ *   local_map [dev] (B, 20, 20) f32 already scaled to {-1, +1}
+ *   cond      [dev] (B, 7) f32
+ *   t0, dt    [host] K floats (common/fm_utils.py:4-17)
+ *   act_norm  [host] 4 doubles mu[2], sigma[2]
+ *   actions   [dev] (B, P, 2) f64   un-normalised actions
+ *   x_out     [dev] (B, P, 2) f32 or NULL: the normalised sample after the last step */
+int32_t ditree_denoise(ditree_ctx* ctx, const float* noise, const float* local_map,
+                       const float* cond, int32_t B, int32_t K, const float* t0, const float* dt,
+                       const double* act_norm, double* actions, float* x_out, void* stream);
+
+/* One expansion round for B candidates (planners/RRT.py:131-194 batched):
+ * nearest node -> n_chunks x [local map -> cond -> denoise (or injected actions)
+ * -> rollout].  Fills `round`; does not modify the tree (call ditree_accept, after
+ * the cross-rank all-gather when sharded). */
+typedef struct {
+  int32_t n_nodes;               /* tree size to search */
+  const double* samples;         /* [dev] (B, 6) */
+  const double* cond_goal;       /* [dev] (B, 2) */
+  const float* noise;            /* [dev] (B, n_chunks, P, 2) f32, or NULL with inject_actions */
+  const double* inject_actions;  /* [dev] (B, n_chunks, P, 2) f64 or NULL: bypass the denoiser */
+  int32_t P;                     /* pred_horizon */
+  int32_t K;                     /* flow steps */
+  const float* t0;               /* [host] K */
+  const float* dt;               /* [host] K */
+  const double* norm;            /* [host] 16 doubles, see ditree_cond_vector */
+  const double* goal_xy;         /* [host] 2: env.goal = centre of the goal cell */
+  const double* axis;            /* [host] local-map axis, n doubles */
+  int32_t lm_n;                  /* local_map_size */
+  double lm_size;                /* the divisor of the goal conditioning (local_map_size) */
+  double s_global;
+} ditree_round_params;
+
+int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
+                            const ditree_round_params* p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DITREE_H */

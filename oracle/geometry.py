@@ -16,6 +16,8 @@ Reference sites (relative to /root/reference):
 """
 from __future__ import annotations
 
+import ctypes
+
 import numpy as np
 
 # --------------------------------------------------------------------------- constants
@@ -89,10 +91,25 @@ def car_step(state: np.ndarray, action: np.ndarray) -> np.ndarray:
     return state + CAR_DT * dot                                                           # :390
 
 
+_libm = ctypes.CDLL("libm.so.6")
+_libm.fma.restype = ctypes.c_double
+_libm.fma.argtypes = [ctypes.c_double] * 3
+_fma = np.frompyfunc(_libm.fma, 3, 1)
+
+
+def norm2(dx, dy):
+    """np.linalg.norm of a 2-vector as numpy evaluates it (1-D path: sqrt(x.dot(x)), and the
+    BLAS ddot of two elements rounds as fma(x1, x1, x0*x0) -- checked bit for bit against
+    np.linalg.norm on 2e5 random vectors in the build container)."""
+    dx = np.asarray(dx, dtype=np.float64)
+    dy = np.asarray(dy, dtype=np.float64)
+    return np.sqrt(_fma(dy, dy, dx * dx).astype(np.float64))
+
+
 def goal_reached(state: np.ndarray, goal_xy: np.ndarray) -> np.ndarray:
-    """car_env.py:341-354: ||xy - goal|| < 0.5 (np.linalg.norm = sqrt(dx^2 + dy^2))."""
+    """car_env.py:341-354: np.linalg.norm(xy - goal) < 0.5."""
     d = np.asarray(state)[..., :2] - np.asarray(goal_xy)
-    return np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) < GOAL_RADIUS
+    return norm2(d[..., 0], d[..., 1]) < GOAL_RADIUS
 
 
 # --------------------------------------------------------------------------- collision

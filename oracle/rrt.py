@@ -228,7 +228,7 @@ class OraclePlanner:
             return None
         xy = self.tree.xy()[1:]
         d = xy - self.goal_state[:2]
-        dist = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])
+        dist = G.norm2(d[:, 0], d[:, 1])
         return 1 + int(np.argmin(dist))
 
     def path_to(self, node):
