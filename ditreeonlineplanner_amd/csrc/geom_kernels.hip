@@ -289,7 +289,13 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
 #pragma unroll
       for (int k = 0; k < 6; ++k) so[(size_t)(r + 1) * 6 + k] = 0.0;
     }
-    if (ao) { ao[2 * r] = 0.0; ao[2 * r + 1] = 0.0; }
+    if (ao) {
+      // only the goal branch zeroes the remaining actions (:314-317); a collided edge is discarded
+      // by the caller, its untouched tail is copied through like the reference's array
+      const bool z = (status == DITREE_ST_GOAL);
+      ao[2 * r] = z ? 0.0 : act[2 * r];
+      ao[2 * r + 1] = z ? 0.0 : act[2 * r + 1];
+    }
   }
 #pragma unroll
   for (int k = 0; k < 6; ++k) state_io[(size_t)b * 6 + k] = s[k];
