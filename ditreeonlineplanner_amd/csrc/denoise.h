@@ -1,0 +1,52 @@
+// Internal interface between the denoiser's host orchestration and its kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { MODE_BIAS = 0, MODE_GN_MISH = 1, MODE_GN_MISH_FILM = 2, MODE_GN_MISH_RES = 3 };
+
+// One implicit-GEMM launch (see denoise_kernels.hip).  All counts are in elements of the
+// activation type (bf16 or f32); pointers are device pointers.
+struct ConvGemmParams {
+  const void* A;      // activations, channels contiguous
+  int lda;            // elements per A row
+  int in_Lp;          // A rows per sample (L_in + 2 for padded conv inputs)
+  int in_stride;      // row(b, l, tap) = b*in_Lp + l*in_stride + tap + in_off
+  int in_off;
+  int taps, Cin;      // K = taps * Cin, Cin a multiple of 64
+  const void* W;      // [ceil(N/256)*256][taps*Cin], row co = [tap][ci]
+  void* Out;
+  int ldc;            // elements per output row
+  int out_Lp, out_stride, out_off;   // out row(b, l) = b*out_Lp + l*out_stride + out_off
+  int out_coff;       // channel offset inside the output row (concat halves)
+  int L;              // positions per sample in this GEMM; M = samples * L
+  int M, N;
+  const float* bias;  // [N] or null
+  int mode;
+  const float* gamma; // [N] GroupNorm affine
+  const float* beta;
+  int group_ch;       // channels per group (N / 8)
+  float eps;
+  const float* film;  // [samples][film_ld] f32: scale at film_off + c, bias at film_off + N + c
+  int film_ld, film_off;
+  const void* Res;    // residual, activation type
+  int ldres, res_Lp, res_off;
+  int out_f32;        // store f32 regardless of the activation type
+};
+
+void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s);
+void launch_prep_sample(const float* x, void* A0, int B, int P, int D, int prec, hipStream_t s);
+void launch_time_embed(float t, const float* W1, const float* b1, const float* W2, const float* b2, float* out,
+                       hipStream_t s);
+void launch_prep_cond(const float* temb, const float* map_emb, int E, const float* cond, int G, void* out, int B,
+                      int Kpad, int prec, hipStream_t s);
+void launch_final_proj_flow(const void* Y, int C, int Lp, const float* W, const float* bias, int D, float* x, float dt,
+                            const double* act_norm, double* actions, int B, int P, int prec, hipStream_t s);
+void launch_im2col2d(const void* in, bool src_f32, void* out, int B, int H, int W, int C, int KH, int KW, int stride,
+                     int pad, int OH, int OW, int Kpad, int prec, hipStream_t s);
+void launch_gn2d(const float* in, const float* gamma, const float* beta, const void* res, int relu, void* out, int B,
+                 int HW, int C, float eps, int prec, hipStream_t s);
+void launch_maxpool2d(const void* in, void* out, int B, int H, int W, int C, int OH, int OW, int prec, hipStream_t s);
+void launch_avgpool2d(const void* in, void* out, int B, int HW, int C, int prec, hipStream_t s);
+void launch_unpack_act(const void* in, int ld, int coff, int Lp, int roff, float* out, int B, int L, int C, int prec,
+                       hipStream_t s);

@@ -1,17 +1,694 @@
-// placeholder: replaced by the MFMA denoiser host code
+// Host side of the denoiser: weight repacking, activation workspace, launch sequence.
+//
+// Reference structure reproduced layer for layer:
+//   local_map_encoder.py:101-122   encoder(local_map) -> 400-d, cat with obs_cond
+//   conditional_unet1d.py:268-347  time MLP, down [CRB,CRB,Down] x3 (last Identity),
+//                                  mid 2 x CRB, up [cat skip, CRB, CRB, Up] x2, final conv
+//   policies/fm_policy.py:183-203  flow steps x <- x + v*dt[k]; a = x*sigma + mu
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <sstream>
+#include <thread>
+
+#include "denoise.h"
 #include "ditree_internal.h"
-int denoise_run(ditree_ctx* ctx, const float*, const float*, const float*, int, int, const float*, const float*,
-                const double*, double*, float*, hipStream_t) {
-  return set_err(ctx, DITREE_E_STATE, "denoiser weights not loaded");
+
+namespace {
+
+struct HostParam {
+  std::vector<int64_t> dims;
+  const float* data = nullptr;
+  int64_t n = 0;
+};
+
+struct Act {             // channels-last activation view
+  void* p = nullptr;
+  int L = 0, C = 0;      // positions per sample, channels of this view
+  int ld = 0, coff = 0;  // row stride (elements), channel offset of the view
+  bool padded = true;    // rows per sample = L + 2 (one zero row each side)
+  int Lp() const { return padded ? L + 2 : L; }
+};
+
+inline uint16_t f2bf_host(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);     // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
 }
-void denoise_destroy(ditree_ctx*) {}
+
+}  // namespace
+
+struct DenoiserState {
+  ditree_ctx* ctx = nullptr;
+  std::vector<float> blob;
+  std::map<std::string, HostParam> params;
+  // architecture (derived from the parameter shapes)
+  int D = 2, P = 64, E = 400, G = 7, cond_dim = 663, lm = 20;
+  int dims[3] = {512, 1024, 2048};
+  bool loaded = false;
+  // workspace
+  int prec = -1, Bmax = 0;
+  std::vector<void*> allocs;
+  std::map<std::string, Act> named;
+  std::map<std::string, void*> dev_w;       // packed GEMM weights by name
+  std::map<std::string, float*> dev_f;      // f32 vectors (bias, gamma, beta, small matrices)
+  std::vector<std::function<void(int, int, hipStream_t)>> enc_ops, unet_ops;   // (B, Bp, stream)
+  std::function<void(int, int, hipStream_t)> film_op;
+  float* x_cur = nullptr;        // (Bmax, P, D) f32
+  float* temb = nullptr;         // (256,) f32
+  float* map_emb = nullptr;      // (Bmax, E) f32
+  float* film = nullptr;         // (Bp, film_cols) f32
+  void* condA = nullptr;         // (Bp, condK)
+  int condK = 0, film_cols = 0;
+  Act final_h;                   // input of the final 1x1 projection
+  const float* lm_ptr = nullptr; // caller's scaled local map of the current call
+  int es() const { return prec == 0 ? 2 : 4; }
+
+  const HostParam& P_(const std::string& name) const {
+    auto it = params.find(name);
+    if (it == params.end()) throw std::runtime_error("missing parameter " + name);
+    return it->second;
+  }
+  bool has(const std::string& name) const { return params.count(name) != 0; }
+
+  void* dalloc(size_t bytes, bool zero = true) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) throw std::runtime_error("hipMalloc failed");
+    if (zero && hipMemset(p, 0, bytes ? bytes : 16) != hipSuccess) throw std::runtime_error("hipMemset failed");
+    allocs.push_back(p);
+    return p;
+  }
+  void free_workspace() {
+    for (void* p : allocs) hipFree(p);
+    allocs.clear();
+    named.clear();
+    dev_w.clear();
+    dev_f.clear();
+    enc_ops.clear();
+    unet_ops.clear();
+    film_op = nullptr;
+    prec = -1;
+    Bmax = 0;
+  }
+
+  float* upload_f32(const std::string& key, const float* src, int64_t n) {
+    auto it = dev_f.find(key);
+    if (it != dev_f.end()) return it->second;
+    float* d = (float*)dalloc((size_t)n * 4, false);
+    if (hipMemcpy(d, src, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("memcpy");
+    dev_f[key] = d;
+    return d;
+  }
+  float* vec(const std::string& name) {
+    const HostParam& hp = P_(name);
+    return upload_f32(name, hp.data, hp.n);
+  }
+
+  // Pack a GEMM weight [Npad][T*Cin_pad] in the activation type from get(n, t, ci).
+  template <class F>
+  void* pack(const std::string& key, int N, int T, int Cin_pad, F get) {
+    auto it = dev_w.find(key);
+    if (it != dev_w.end()) return it->second;
+    const int Npad = (N + 255) / 256 * 256;
+    const size_t K = (size_t)T * Cin_pad, total = (size_t)Npad * K;
+    std::vector<uint8_t> host(total * es(), 0);
+    const int nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (int ti = 0; ti < nthreads; ++ti) {
+      th.emplace_back([&, ti]() {
+        for (int n = ti; n < N; n += nthreads) {
+          for (int t = 0; t < T; ++t)
+            for (int ci = 0; ci < Cin_pad; ++ci) {
+              const float v = get(n, t, ci);
+              const size_t idx = (size_t)n * K + (size_t)t * Cin_pad + ci;
+              if (prec == 0) ((uint16_t*)host.data())[idx] = f2bf_host(v);
+              else ((float*)host.data())[idx] = v;
+            }
+        }
+      });
+    }
+    for (auto& t : th) t.join();
+    void* d = dalloc(total * es(), false);
+    if (hipMemcpy(d, host.data(), total * es(), hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("memcpy");
+    dev_w[key] = d;
+    return d;
+  }
+
+  Act make_act(const std::string& name, int L, int C, bool padded = true) {
+    Act a;
+    a.L = L; a.C = C; a.ld = C; a.coff = 0; a.padded = padded;
+    a.p = dalloc((size_t)Bmax * a.Lp() * C * es());
+    named[name] = a;
+    return a;
+  }
+  static Act view(const Act& base, int coff, int C, const char* = nullptr) {
+    Act v = base;
+    v.coff = coff;
+    v.C = C;
+    return v;
+  }
+  const char* aptr(const Act& a) const { return (const char*)a.p + (size_t)a.coff * es(); }
+
+  // ------------------------------------------------------------------ GEMM op builders
+  // Conv1d(k = 3, pad 1) [+ GroupNorm(8) + Mish (+ FiLM | + residual)] on padded activations.
+  void add_conv3(std::vector<std::function<void(int, int, hipStream_t)>>& ops, const std::string& wname, const Act& in,
+                 const Act& out, int mode, const std::string& gn, int film_off, const Act* res) {
+    const HostParam& w = P_(wname + ".weight");
+    const int Cout = (int)w.dims[0], Cin = (int)w.dims[1];
+    const float* wd = w.data;
+    void* wp = pack(wname, Cout, 3, Cin, [=](int n, int t, int ci) { return wd[((size_t)n * Cin + ci) * 3 + t]; });
+    ConvGemmParams p{};
+    p.A = aptr(in); p.lda = in.ld; p.in_Lp = in.Lp(); p.in_stride = 1; p.in_off = 0; p.taps = 3; p.Cin = Cin;
+    p.W = wp;
+    p.Out = (void*)aptr(out); p.ldc = out.ld; p.out_Lp = out.Lp(); p.out_stride = 1; p.out_off = 1; p.out_coff = 0;
+    p.L = in.L; p.N = Cout; p.bias = vec(wname + ".bias"); p.mode = mode; p.eps = 1e-5f;
+    if (mode >= MODE_GN_MISH) {
+      p.gamma = vec(gn + ".weight"); p.beta = vec(gn + ".bias"); p.group_ch = Cout / 8;
+    }
+    if (mode == MODE_GN_MISH_FILM) { p.film = film; p.film_ld = film_cols; p.film_off = film_off; }
+    if (mode == MODE_GN_MISH_RES) {
+      p.Res = aptr(*res); p.ldres = res->ld; p.res_Lp = res->Lp(); p.res_off = res->padded ? 1 : 0;
+    }
+    const int L = in.L, pr = prec;
+    ops.push_back([p, L, pr](int, int Bp, hipStream_t s) mutable {
+      p.M = Bp * L;
+      launch_conv_gemm(p, pr, s);
+    });
+  }
+  // Conv1d(k = 1) residual projection.
+  void add_conv1(std::vector<std::function<void(int, int, hipStream_t)>>& ops, const std::string& wname, const Act& in,
+                 const Act& out) {
+    const HostParam& w = P_(wname + ".weight");
+    const int Cout = (int)w.dims[0], Cin = (int)w.dims[1];
+    const float* wd = w.data;
+    void* wp = pack(wname, Cout, 1, Cin, [=](int n, int, int ci) { return wd[(size_t)n * Cin + ci]; });
+    ConvGemmParams p{};
+    p.A = aptr(in); p.lda = in.ld; p.in_Lp = in.Lp(); p.in_stride = 1; p.in_off = 1; p.taps = 1; p.Cin = Cin;
+    p.W = wp;
+    p.Out = (void*)aptr(out); p.ldc = out.ld; p.out_Lp = out.Lp(); p.out_stride = 1; p.out_off = 1;
+    p.L = in.L; p.N = Cout; p.bias = vec(wname + ".bias"); p.mode = MODE_BIAS;
+    const int L = in.L, pr = prec;
+    ops.push_back([p, L, pr](int, int Bp, hipStream_t s) mutable {
+      p.M = Bp * L;
+      launch_conv_gemm(p, pr, s);
+    });
+  }
+  // Downsample1d: Conv1d(C, C, 3, stride 2, pad 1)  (conv1d_components.py:7-13)
+  void add_down(std::vector<std::function<void(int, int, hipStream_t)>>& ops, const std::string& wname, const Act& in,
+                const Act& out) {
+    const HostParam& w = P_(wname + ".weight");
+    const int Cout = (int)w.dims[0], Cin = (int)w.dims[1];
+    const float* wd = w.data;
+    void* wp = pack(wname, Cout, 3, Cin, [=](int n, int t, int ci) { return wd[((size_t)n * Cin + ci) * 3 + t]; });
+    ConvGemmParams p{};
+    p.A = aptr(in); p.lda = in.ld; p.in_Lp = in.Lp(); p.in_stride = 2; p.in_off = 0; p.taps = 3; p.Cin = Cin;
+    p.W = wp;
+    p.Out = (void*)aptr(out); p.ldc = out.ld; p.out_Lp = out.Lp(); p.out_stride = 1; p.out_off = 1;
+    p.L = out.L; p.N = Cout; p.bias = vec(wname + ".bias"); p.mode = MODE_BIAS;
+    const int L = out.L, pr = prec;
+    ops.push_back([p, L, pr](int, int Bp, hipStream_t s) mutable {
+      p.M = Bp * L;
+      launch_conv_gemm(p, pr, s);
+    });
+  }
+  // Upsample1d: ConvTranspose1d(C, C, 4, 2, 1) as two 2-tap GEMMs (even / odd outputs)
+  // out[2m] = W1^T x[m] + W3^T x[m-1];  out[2m+1] = W0^T x[m+1] + W2^T x[m]   (conv1d_components.py:15-21)
+  void add_up(std::vector<std::function<void(int, int, hipStream_t)>>& ops, const std::string& wname, const Act& in,
+              const Act& out) {
+    const HostParam& w = P_(wname + ".weight");                  // [Cin][Cout][4]
+    const int Cin = (int)w.dims[0], Cout = (int)w.dims[1];
+    const float* wd = w.data;
+    for (int par = 0; par < 2; ++par) {
+      const int k0 = par == 0 ? 3 : 2, k1 = par == 0 ? 1 : 0;     // tap 0 -> earlier input row
+      void* wp = pack(wname + (par ? ".odd" : ".even"), Cout, 2, Cin, [=](int n, int t, int ci) {
+        return wd[((size_t)ci * Cout + n) * 4 + (t == 0 ? k0 : k1)];
+      });
+      ConvGemmParams p{};
+      p.A = aptr(in); p.lda = in.ld; p.in_Lp = in.Lp(); p.in_stride = 1; p.in_off = par; p.taps = 2; p.Cin = Cin;
+      p.W = wp;
+      p.Out = (void*)aptr(out); p.ldc = out.ld; p.out_Lp = out.Lp(); p.out_stride = 2; p.out_off = 1 + par;
+      p.L = in.L; p.N = Cout; p.bias = vec(wname + ".bias"); p.mode = MODE_BIAS;
+      const int L = in.L, pr = prec;
+      ops.push_back([p, L, pr](int, int Bp, hipStream_t s) mutable {
+        p.M = Bp * L;
+        launch_conv_gemm(p, pr, s);
+      });
+    }
+  }
+
+  // ConditionalResidualBlock1D (conditional_unet1d.py:41-142)
+  void add_crb(const std::string& pre, const Act& in, const Act& out, int& film_cursor, const std::string& tag) {
+    const int Cout = (int)P_(pre + ".blocks.0.block.0.weight").dims[0];
+    Act h = make_act(tag + ".h", in.L, Cout);
+    const int film_off = film_cursor;
+    film_cursor += 2 * Cout;
+    add_conv3(unet_ops, pre + ".blocks.0.block.0", in, h, MODE_GN_MISH_FILM, pre + ".blocks.0.block.1", film_off, nullptr);
+    Act res = in;
+    if (has(pre + ".residual_conv.weight")) {
+      res = make_act(tag + ".res", in.L, Cout);
+      add_conv1(unet_ops, pre + ".residual_conv", in, res);
+    }
+    add_conv3(unet_ops, pre + ".blocks.1.block.0", h, out, MODE_GN_MISH_RES, pre + ".blocks.1.block.1", 0, &res);
+  }
+
+  void build(int prec_, int Bmax_);
+};
+
+void DenoiserState::build(int prec_, int Bmax_) {
+  free_workspace();
+  prec = prec_;
+  Bmax = (Bmax_ + 15) / 16 * 16;
+  const int C0 = dims[0], C1 = dims[1], C2 = dims[2];
+  const int L0 = P, L1 = P / 2, L2 = P / 4;
+  if (P % 64 != 0) throw std::runtime_error("pred_horizon must be a multiple of 64");
+  x_cur = (float*)dalloc((size_t)Bmax * P * D * 4);
+  temb = (float*)dalloc(256 * 4);
+  map_emb = (float*)dalloc((size_t)Bmax * E * 4);
+  condK = (cond_dim + 63) / 64 * 64;
+  condA = dalloc((size_t)Bmax * condK * es());
+
+  // ---------------- FiLM: all cond_encoder Linear layers batched into one GEMM -------------------------
+  std::vector<std::string> crbs = {"unet.down_modules.0.0", "unet.down_modules.0.1", "unet.down_modules.1.0",
+                                   "unet.down_modules.1.1", "unet.down_modules.2.0", "unet.down_modules.2.1",
+                                   "unet.mid_modules.0",    "unet.mid_modules.1",    "unet.up_modules.0.0",
+                                   "unet.up_modules.0.1",   "unet.up_modules.1.0",   "unet.up_modules.1.1"};
+  film_cols = 0;
+  std::vector<int> film_offs;
+  for (auto& c : crbs) {
+    film_offs.push_back(film_cols);
+    film_cols += (int)P_(c + ".cond_encoder.1.weight").dims[0];
+  }
+  film = (float*)dalloc((size_t)Bmax * film_cols * 4);
+  {
+    std::vector<const float*> wsrc, bsrc;
+    std::vector<int> rows;
+    for (auto& c : crbs) {
+      wsrc.push_back(P_(c + ".cond_encoder.1.weight").data);
+      bsrc.push_back(P_(c + ".cond_encoder.1.bias").data);
+      rows.push_back((int)P_(c + ".cond_encoder.1.weight").dims[0]);
+    }
+    std::vector<int> start(rows.size());
+    for (size_t i = 0, a = 0; i < rows.size(); ++i) { start[i] = (int)a; a += rows[i]; }
+    const int cd = cond_dim;
+    void* wp = pack("film.all", film_cols, 1, condK, [=](int n, int, int ci) {
+      size_t i = std::upper_bound(start.begin(), start.end(), n) - start.begin() - 1;
+      return ci < cd ? wsrc[i][(size_t)(n - start[i]) * cd + ci] : 0.0f;
+    });
+    std::vector<float> ball(film_cols);
+    for (size_t i = 0; i < rows.size(); ++i) std::memcpy(ball.data() + start[i], bsrc[i], (size_t)rows[i] * 4);
+    float* bd = upload_f32("film.bias", ball.data(), film_cols);
+    ConvGemmParams p{};
+    p.A = condA; p.lda = condK; p.in_Lp = 0; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = condK;
+    p.W = wp; p.Out = film; p.ldc = film_cols; p.out_Lp = 0; p.out_stride = 1; p.out_off = 0;
+    p.N = film_cols; p.bias = bd; p.mode = MODE_BIAS; p.out_f32 = 1;
+    const int pr = prec;
+    film_op = [p, pr](int, int Bp, hipStream_t s) mutable {
+      p.M = Bp; p.L = Bp; p.in_Lp = Bp; p.out_Lp = Bp;
+      launch_conv_gemm(p, pr, s);
+    };
+  }
+
+  // ---------------- U-Net ----------------------------------------------------------------------------
+  int fc = 0;   // film cursor follows `crbs` order
+  // first layer input: im2col rows [x[l-1], x[l], x[l+1]] padded to 64 columns, unpadded rows
+  Act a0;
+  a0.L = L0; a0.C = 64; a0.ld = 64; a0.coff = 0; a0.padded = false;
+  a0.p = dalloc((size_t)Bmax * L0 * 64 * es());
+  named["a0"] = a0;
+  {
+    // down 0, block 1: Conv1d(D, C0, 3) as a 1-tap GEMM over the im2col rows
+    const std::string pre = "unet.down_modules.0.0";
+    const HostParam& w = P_(pre + ".blocks.0.block.0.weight");
+    const float* wd = w.data;
+    const int Dd = D;
+    void* wp = pack(pre + ".blocks.0.block.0", C0, 1, 64, [=](int n, int, int ci) {
+      if (ci >= 3 * Dd) return 0.0f;
+      const int t = ci / Dd, d = ci - t * Dd;
+      return wd[((size_t)n * Dd + d) * 3 + t];
+    });
+    Act h = make_act("d0b1.h", L0, C0);
+    ConvGemmParams p{};
+    p.A = a0.p; p.lda = 64; p.in_Lp = L0; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = 64;
+    p.W = wp; p.Out = h.p; p.ldc = h.ld; p.out_Lp = h.Lp(); p.out_stride = 1; p.out_off = 1;
+    p.L = L0; p.N = C0; p.bias = vec(pre + ".blocks.0.block.0.bias"); p.mode = MODE_GN_MISH_FILM; p.eps = 1e-5f;
+    p.gamma = vec(pre + ".blocks.0.block.1.weight"); p.beta = vec(pre + ".blocks.0.block.1.bias"); p.group_ch = C0 / 8;
+    p.film = film; p.film_ld = film_cols; p.film_off = film_offs[0];
+    const int pr = prec, L = L0;
+    unet_ops.push_back([p, L, pr](int, int Bp, hipStream_t s) mutable { p.M = Bp * L; launch_conv_gemm(p, pr, s); });
+    // residual Conv1d(D, C0, 1): centre-tap columns of the same rows
+    const HostParam& wr = P_(pre + ".residual_conv.weight");
+    const float* wrd = wr.data;
+    void* wrp = pack(pre + ".residual_conv", C0, 1, 64, [=](int n, int, int ci) {
+      return (ci >= Dd && ci < 2 * Dd) ? wrd[(size_t)n * Dd + (ci - Dd)] : 0.0f;
+    });
+    Act res = make_act("d0b1.res", L0, C0);
+    ConvGemmParams q{};
+    q.A = a0.p; q.lda = 64; q.in_Lp = L0; q.in_stride = 1; q.in_off = 0; q.taps = 1; q.Cin = 64;
+    q.W = wrp; q.Out = res.p; q.ldc = res.ld; q.out_Lp = res.Lp(); q.out_stride = 1; q.out_off = 1;
+    q.L = L0; q.N = C0; q.bias = vec(pre + ".residual_conv.bias"); q.mode = MODE_BIAS;
+    unet_ops.push_back([q, L, pr](int, int Bp, hipStream_t s) mutable { q.M = Bp * L; launch_conv_gemm(q, pr, s); });
+    Act o = make_act("d0b1.out", L0, C0);
+    add_conv3(unet_ops, pre + ".blocks.1.block.0", h, o, MODE_GN_MISH_RES, pre + ".blocks.1.block.1", 0, &res);
+    fc = film_offs[1];
+  }
+  Act cat1 = make_act("cat1", L1, 2 * C1);        // [x_up (C1) | skip1 (C1)] at L1
+  Act cat0 = make_act("cat0", L2, 2 * C2);        // [x_mid (C2) | skip2 (C2)] at L2
+  Act d0o = named["d0b1.out"];
+  Act skip0 = make_act("skip0", L0, C0);
+  add_crb("unet.down_modules.0.1", d0o, skip0, fc, "d0b2");
+  Act d1in = make_act("d1.in", L1, C0);
+  add_down(unet_ops, "unet.down_modules.0.2.conv", skip0, d1in);
+  Act d1o = make_act("d1b1.out", L1, C1);
+  add_crb("unet.down_modules.1.0", d1in, d1o, fc, "d1b1");
+  Act skip1 = view(cat1, C1, C1);
+  named["skip1"] = skip1;
+  add_crb("unet.down_modules.1.1", d1o, skip1, fc, "d1b2");
+  Act d2in = make_act("d2.in", L2, C1);
+  add_down(unet_ops, "unet.down_modules.1.2.conv", skip1, d2in);
+  Act d2o = make_act("d2b1.out", L2, C2);
+  add_crb("unet.down_modules.2.0", d2in, d2o, fc, "d2b1");
+  Act skip2 = view(cat0, C2, C2);
+  named["skip2"] = skip2;
+  add_crb("unet.down_modules.2.1", d2o, skip2, fc, "d2b2");
+  Act m1 = make_act("mid1.out", L2, C2);
+  add_crb("unet.mid_modules.0", skip2, m1, fc, "mid1");
+  Act m2 = view(cat0, 0, C2);
+  named["mid2.out"] = m2;
+  add_crb("unet.mid_modules.1", m1, m2, fc, "mid2");
+  Act u0a = make_act("u0b1.out", L2, C1);
+  add_crb("unet.up_modules.0.0", cat0, u0a, fc, "u0b1");
+  Act u0b = make_act("u0b2.out", L2, C1);
+  add_crb("unet.up_modules.0.1", u0a, u0b, fc, "u0b2");
+  Act up0 = view(cat1, 0, C1);
+  named["up0.out"] = up0;
+  add_up(unet_ops, "unet.up_modules.0.2.conv", u0b, up0);
+  Act u1a = make_act("u1b1.out", L1, C0);
+  add_crb("unet.up_modules.1.0", cat1, u1a, fc, "u1b1");
+  Act u1b = make_act("u1b2.out", L1, C0);
+  add_crb("unet.up_modules.1.1", u1a, u1b, fc, "u1b2");
+  Act fin = make_act("final.in", L0, C0);
+  add_up(unet_ops, "unet.up_modules.1.2.conv", u1b, fin);
+  final_h = make_act("final.h", L0, C0);
+  add_conv3(unet_ops, "unet.final_conv.0.block.0", fin, final_h, MODE_GN_MISH, "unet.final_conv.0.block.1", 0, nullptr);
+  vec("unet.final_conv.1.weight");
+  vec("unet.final_conv.1.bias");
+  vec("unet.diffusion_step_encoder.1.weight");
+  vec("unet.diffusion_step_encoder.1.bias");
+  vec("unet.diffusion_step_encoder.3.weight");
+  vec("unet.diffusion_step_encoder.3.bias");
+
+  // ---------------- encoder: ResNet-18 with GroupNorm(C/16), NHWC, im2col + GEMM + GN kernels ------------
+  {
+    const std::string R = "encoder.resnet18.";
+    const int pr = prec;
+    const size_t col_elems = (size_t)Bmax * 25 * 576 > (size_t)Bmax * 100 * 64 ? (size_t)Bmax * 25 * 576 : (size_t)Bmax * 100 * 64;
+    void* col = dalloc(std::max(col_elems, (size_t)Bmax * 4608) * es());
+    float* gout = (float*)dalloc((size_t)Bmax * 100 * 64 * 4 > (size_t)Bmax * 512 * 4 ? (size_t)Bmax * 100 * 64 * 4 : (size_t)Bmax * 512 * 4);
+    auto ebuf = [&](const std::string& name, int HW, int C) {
+      Act a;
+      a.L = HW; a.C = C; a.ld = C; a.coff = 0; a.padded = false;
+      a.p = dalloc((size_t)Bmax * HW * C * es());
+      named[name] = a;
+      return a;
+    };
+    // conv -> f32 GEMM output in `gout`
+    auto conv2d = [&](const std::string& wname, const void* in, bool in_f32, int H, int W, int Cin, int Cout, int k,
+                      int stride, int pad, int OH, int OW, bool fold_in) {
+      const HostParam& w = P_(wname + ".weight");
+      const float* wd = w.data;
+      const int Cw = (int)w.dims[1];
+      const int K = k * k * Cin, Kpad = (K + 63) / 64 * 64;
+      void* wp = pack(wname, Cout, 1, Kpad, [=](int n, int, int kk) {
+        if (kk >= K) return 0.0f;
+        const int c = kk % Cin, t = kk / Cin, kw = t % k, kh = t / k;
+        if (!fold_in) return wd[(((size_t)n * Cw + c) * k + kh) * k + kw];
+        float s = 0.f;                                       // x.repeat(1,3,1,1): identical channels fold into one
+        for (int cc = 0; cc < Cw; ++cc) s += wd[(((size_t)n * Cw + cc) * k + kh) * k + kw];
+        return s;
+      });
+      enc_ops.push_back([=](int B, int, hipStream_t s) {
+        launch_im2col2d(in, in_f32, col, B, H, W, Cin, k, k, stride, pad, OH, OW, Kpad, pr, s);
+        ConvGemmParams p{};
+        const int M = B * OH * OW;
+        p.A = col; p.lda = Kpad; p.in_Lp = M; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = Kpad;
+        p.W = wp; p.Out = gout; p.ldc = Cout; p.out_Lp = M; p.out_stride = 1; p.out_off = 0;
+        p.L = M; p.M = M; p.N = Cout; p.mode = MODE_BIAS; p.out_f32 = 1;
+        launch_conv_gemm(p, pr, s);
+      });
+    };
+    auto gn = [&](const std::string& gname, const Act& out, const Act* res, bool relu) {
+      float* ga = vec(gname + ".weight");
+      float* be = vec(gname + ".bias");
+      const void* rp = res ? res->p : nullptr;
+      void* op = out.p;
+      const int HW = out.L, C = out.C;
+      enc_ops.push_back([=](int B, int, hipStream_t s) { launch_gn2d(gout, ga, be, rp, relu ? 1 : 0, op, B, HW, C, 1e-5f, pr, s); });
+    };
+    const int H0 = lm;
+    auto osz = [](int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; };
+    const int H1 = osz(H0, 7, 2, 3);                  // 10
+    const int H2 = osz(H1, 3, 2, 1);                  // 5
+    Act c1 = ebuf("enc.c1", H1 * H1, 64);
+    // stem: the f32 local map is read directly by im2col (C = 1 after folding the 3-channel repeat)
+    {
+      const HostParam& w = P_(R + "conv1.weight");
+      const float* wd = w.data;
+      const int Cw = (int)w.dims[1];
+      void* wp = pack(R + "conv1", 64, 1, 64, [=](int n, int, int kk) {
+        if (kk >= 49) return 0.0f;
+        const int kw = kk % 7, kh = kk / 7;
+        float s = 0.f;
+        for (int cc = 0; cc < Cw; ++cc) s += wd[(((size_t)n * Cw + cc) * 7 + kh) * 7 + kw];
+        return s;
+      });
+      const int HH = H0, OO = H1;
+      const float** lm_slot = &lm_ptr;
+      enc_ops.push_back([=](int B, int, hipStream_t s) {
+        launch_im2col2d(*lm_slot, true, col, B, HH, HH, 1, 7, 7, 2, 3, OO, OO, 64, pr, s);
+        ConvGemmParams p{};
+        const int M = B * OO * OO;
+        p.A = col; p.lda = 64; p.in_Lp = M; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = 64;
+        p.W = wp; p.Out = gout; p.ldc = 64; p.out_Lp = M; p.out_stride = 1; p.out_off = 0;
+        p.L = M; p.M = M; p.N = 64; p.mode = MODE_BIAS; p.out_f32 = 1;
+        launch_conv_gemm(p, pr, s);
+      });
+    }
+    gn(R + "bn1", c1, nullptr, true);
+    Act pool = ebuf("enc.pool", H2 * H2, 64);
+    {
+      void* ip = c1.p; void* op = pool.p;
+      const int a = H1, b2 = H2;
+      enc_ops.push_back([=](int B, int, hipStream_t s) { launch_maxpool2d(ip, op, B, a, a, 64, b2, b2, pr, s); });
+    }
+    Act cur = pool;
+    int Hc = H2, Cc = 64;
+    const int chans[4] = {64, 128, 256, 512};
+    for (int li = 0; li < 4; ++li) {
+      for (int bi = 0; bi < 2; ++bi) {
+        const std::string pre = R + "layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+        const int Cout = chans[li];
+        const int stride = (bi == 0 && li > 0) ? 2 : 1;
+        const int Ho = osz(Hc, 3, stride, 1);
+        const std::string tag = "enc.l" + std::to_string(li + 1) + "." + std::to_string(bi);
+        Act t1 = ebuf(tag + ".t", Ho * Ho, Cout);
+        conv2d(pre + ".conv1", cur.p, false, Hc, Hc, Cc, Cout, 3, stride, 1, Ho, Ho, false);
+        gn(pre + ".bn1", t1, nullptr, true);
+        Act idt = cur;
+        if (has(pre + ".downsample.0.weight")) {
+          Act ds = ebuf(tag + ".ds", Ho * Ho, Cout);
+          conv2d(pre + ".downsample.0", cur.p, false, Hc, Hc, Cc, Cout, 1, stride, 0, Ho, Ho, false);
+          gn(pre + ".downsample.1", ds, nullptr, false);
+          idt = ds;
+        }
+        Act o = ebuf(tag + ".out", Ho * Ho, Cout);
+        conv2d(pre + ".conv2", t1.p, false, Ho, Ho, Cout, Cout, 3, 1, 1, Ho, Ho, false);
+        gn(pre + ".bn2", o, &idt, true);
+        cur = o;
+        Hc = Ho;
+        Cc = Cout;
+      }
+    }
+    Act pooled = ebuf("enc.avg", 1, Cc);
+    {
+      void* ip = cur.p; void* op = pooled.p;
+      const int HW = Hc * Hc, C = Cc;
+      enc_ops.push_back([=](int B, int, hipStream_t s) { launch_avgpool2d(ip, op, B, HW, C, pr, s); });
+    }
+    {
+      const HostParam& w = P_(R + "fc.weight");
+      const float* wd = w.data;
+      const int Kf = (int)w.dims[1], Nf = (int)w.dims[0];
+      void* wp = pack(R + "fc", Nf, 1, Kf, [=](int n, int, int ci) { return wd[(size_t)n * Kf + ci]; });
+      float* bd = vec(R + "fc.bias");
+      void* ip = pooled.p;
+      float* op = map_emb;
+      enc_ops.push_back([=](int B, int, hipStream_t s) {
+        ConvGemmParams p{};
+        p.A = ip; p.lda = Kf; p.in_Lp = B; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = Kf;
+        p.W = wp; p.Out = op; p.ldc = Nf; p.out_Lp = B; p.out_stride = 1; p.out_off = 0;
+        p.L = B; p.M = B; p.N = Nf; p.bias = bd; p.mode = MODE_BIAS; p.out_f32 = 1;
+        launch_conv_gemm(p, pr, s);
+      });
+    }
+  }
+  if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("sync after build failed");
+}
+
+// ------------------------------------------------------------------------------------- glue
+static int parse_manifest(DenoiserState* st, const char* manifest, int64_t n_floats) {
+  std::istringstream in(manifest);
+  std::string line;
+  while (std::getline(in, line)) {
+    if (line.empty()) continue;
+    std::istringstream ls(line);
+    std::string name;
+    int64_t off, n;
+    int nd;
+    if (!(ls >> name >> off >> n >> nd)) return -1;
+    HostParam hp;
+    int64_t prod = 1;
+    for (int i = 0; i < nd; ++i) {
+      int64_t d;
+      if (!(ls >> d)) return -1;
+      hp.dims.push_back(d);
+      prod *= d;
+    }
+    if (prod != n || off < 0 || off + n > n_floats) return -1;
+    hp.data = st->blob.data() + off;
+    hp.n = n;
+    st->params[name] = hp;
+  }
+  return 0;
+}
+
+int denoise_run(ditree_ctx* ctx, const float* noise, const float* local_map, const float* cond, int B, int K,
+                const float* t0, const float* dt, const double* act_norm, double* actions, float* x_out,
+                hipStream_t s) {
+  DenoiserState* st = ctx->dn;
+  if (!st || !st->loaded) return set_err(ctx, DITREE_E_STATE, "denoise: weights not loaded");
+  if (st->prec < 0) return set_err(ctx, DITREE_E_STATE, "denoise: call ditree_denoise_reserve first");
+  if (B <= 0 || B > st->Bmax) return set_err(ctx, DITREE_E_ARG, "denoise: batch exceeds the reserved workspace");
+  if (!noise || !local_map || !cond || !t0 || !dt || !act_norm || K <= 0 || (!actions && !x_out))
+    return set_err(ctx, DITREE_E_ARG, "denoise: bad argument");
+  const int Bp = (B + 15) / 16 * 16;
+  const int pr = st->prec;
+  HIP_TRY(ctx, hipMemcpyAsync(st->x_cur, noise, (size_t)B * st->P * st->D * 4, hipMemcpyDeviceToDevice, s));
+  st->lm_ptr = local_map;
+  for (auto& op : st->enc_ops) op(B, Bp, s);
+  for (int k = 0; k < K; ++k) {
+    const float t = t0[k] * 20.0f;                                      // pos_emb_scale, fm_policy.py:187
+    launch_time_embed(t, st->dev_f["unet.diffusion_step_encoder.1.weight"], st->dev_f["unet.diffusion_step_encoder.1.bias"],
+                      st->dev_f["unet.diffusion_step_encoder.3.weight"], st->dev_f["unet.diffusion_step_encoder.3.bias"],
+                      st->temb, s);
+    launch_prep_cond(st->temb, st->map_emb, st->E, cond, st->G, st->condA, B, st->condK, pr, s);
+    st->film_op(B, Bp, s);
+    launch_prep_sample(st->x_cur, st->named["a0"].p, Bp, st->P, st->D, pr, s);
+    for (auto& op : st->unet_ops) op(B, Bp, s);
+    const bool last = (k == K - 1);
+    launch_final_proj_flow(st->final_h.p, st->final_h.C, st->final_h.Lp(), st->dev_f["unet.final_conv.1.weight"],
+                           st->dev_f["unet.final_conv.1.bias"], st->D, st->x_cur, dt[k], act_norm,
+                           (last && actions) ? actions : nullptr, B, st->P, pr, s);
+  }
+  if (x_out) HIP_TRY(ctx, hipMemcpyAsync(x_out, st->x_cur, (size_t)B * st->P * st->D * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+void denoise_destroy(ditree_ctx* ctx) {
+  if (ctx->dn) {
+    ctx->dn->free_workspace();
+    delete ctx->dn;
+    ctx->dn = nullptr;
+  }
+}
+
 extern "C" {
-int32_t ditree_load_weights(ditree_ctx* ctx, const float*, int64_t, const char*, void*) {
-  return set_err(ctx, DITREE_E_STATE, "not built");
+
+int32_t ditree_load_weights(ditree_ctx* ctx, const float* blob, int64_t n_floats, const char* manifest, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!blob || !manifest || n_floats <= 0) return set_err(ctx, DITREE_E_ARG, "load_weights: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  denoise_destroy(ctx);
+  DenoiserState* st = new (std::nothrow) DenoiserState();
+  if (!st) return set_err(ctx, DITREE_E_NOMEM, "load_weights: out of memory");
+  st->ctx = ctx;
+  try {
+    st->blob.assign(blob, blob + n_floats);
+    if (parse_manifest(st, manifest, n_floats) != 0) throw std::runtime_error("malformed manifest");
+    const HostParam& w0 = st->P_("unet.down_modules.0.0.blocks.0.block.0.weight");
+    st->D = (int)w0.dims[1];
+    for (int i = 0; i < 3; ++i)
+      st->dims[i] = (int)st->P_("unet.down_modules." + std::to_string(i) + ".0.blocks.0.block.0.weight").dims[0];
+    if (st->has("unet.down_modules.3.0.blocks.0.block.0.weight")) throw std::runtime_error("only 3 U-Net levels supported");
+    st->cond_dim = (int)st->P_("unet.down_modules.0.0.cond_encoder.1.weight").dims[1];
+    st->E = (int)st->P_("encoder.resnet18.fc.weight").dims[0];
+    st->G = st->cond_dim - 256 - st->E;
+    if (st->G < 0 || 3 * st->D > 64 || st->D > 2) throw std::runtime_error("unsupported dimensions (car config: action_dim 2)");
+    if (st->P_("unet.diffusion_step_encoder.1.weight").dims[1] != 256) throw std::runtime_error("diffusion_step_embed_dim must be 256");
+    for (int i = 0; i < 3; ++i)
+      if (st->dims[i] % 512 != 0 || st->dims[i] > 2048) throw std::runtime_error("down_dims must be multiples of 512, <= 2048");
+  } catch (const std::exception& e) {
+    delete st;
+    return set_err(ctx, DITREE_E_ARG, std::string("load_weights: ") + e.what());
+  }
+  st->loaded = true;
+  ctx->dn = st;
+  (void)stream;
+  return DITREE_OK;
 }
-int32_t ditree_denoise_reserve(ditree_ctx* ctx, int32_t, int32_t) { return set_err(ctx, DITREE_E_STATE, "not built"); }
-int32_t ditree_denoise(ditree_ctx* ctx, const float*, const float*, const float*, int32_t, int32_t, const float*,
-                       const float*, const double*, double*, float*, void*) {
-  return set_err(ctx, DITREE_E_STATE, "not built");
+
+int32_t ditree_denoise_reserve(ditree_ctx* ctx, int32_t max_batch, int32_t precision) {
+  if (!ctx) return DITREE_E_ARG;
+  DenoiserState* st = ctx->dn;
+  if (!st || !st->loaded) return set_err(ctx, DITREE_E_STATE, "denoise_reserve: weights not loaded");
+  if (max_batch <= 0 || (precision != DITREE_PREC_BF16 && precision != DITREE_PREC_F32))
+    return set_err(ctx, DITREE_E_ARG, "denoise_reserve: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (st->prec == precision && st->Bmax >= max_batch) return DITREE_OK;
+  try {
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    st->build(precision, max_batch);
+  } catch (const std::exception& e) {
+    st->free_workspace();
+    return set_err(ctx, DITREE_E_NOMEM, std::string("denoise_reserve: ") + e.what());
+  }
+  return DITREE_OK;
 }
+
+int32_t ditree_denoise(ditree_ctx* ctx, const float* noise, const float* local_map, const float* cond, int32_t B,
+                       int32_t K, const float* t0, const float* dt, const double* act_norm, double* actions,
+                       float* x_out, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  return denoise_run(ctx, noise, local_map, cond, B, K, t0, dt, act_norm, actions, x_out, (hipStream_t)stream);
 }
+
+int32_t ditree_denoise_debug_read(ditree_ctx* ctx, const char* name, int32_t B, float* out, int64_t capacity,
+                                  int32_t* dims3, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  DenoiserState* st = ctx->dn;
+  if (!st || st->prec < 0 || !name || !out || !dims3) return set_err(ctx, DITREE_E_STATE, "debug_read: no workspace");
+  hipStream_t s = (hipStream_t)stream;
+  std::string nm(name);
+  if (nm == "film" || nm == "map_emb") {
+    const int cols = nm == "film" ? st->film_cols : st->E;
+    const float* src = nm == "film" ? st->film : st->map_emb;
+    if ((int64_t)B * cols > capacity) return set_err(ctx, DITREE_E_ARG, "debug_read: capacity");
+    HIP_TRY(ctx, hipMemcpyAsync(out, src, (size_t)B * cols * 4, hipMemcpyDeviceToDevice, s));
+    dims3[0] = B; dims3[1] = 1; dims3[2] = cols;
+    return DITREE_OK;
+  }
+  auto it = st->named.find(nm);
+  if (it == st->named.end()) return set_err(ctx, DITREE_E_ARG, "debug_read: unknown buffer " + nm);
+  const Act& a = it->second;
+  if ((int64_t)B * a.L * a.C > capacity) return set_err(ctx, DITREE_E_ARG, "debug_read: capacity");
+  launch_unpack_act(a.p, a.ld, a.coff, a.Lp(), a.padded ? 1 : 0, out, B, a.L, a.C, st->prec, s);
+  dims3[0] = B; dims3[1] = a.L; dims3[2] = a.C;
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+}  // extern "C"

@@ -173,3 +173,49 @@ class Context:
         check(self._h, lib().ditree_lidar_scan(self._h, _ptr(poses), B, _ptr(maze_dev), rows, cols, _ptr(dist),
                                                 _ptr(ends), _ptr(hit), _ptr(vis), self.stream), "lidar_scan")
         return dist, ends, hit, vis
+
+
+# ---------------------------------------------------------------------- denoiser front end
+def _ctx_load_weights(self, blob, manifest):
+    blob = np.ascontiguousarray(blob, dtype=np.float32)
+    check(self._h, lib().ditree_load_weights(self._h, C.c_void_p(blob.ctypes.data), blob.size,
+                                             manifest.encode(), self.stream), "load_weights")
+
+
+def _ctx_denoise_reserve(self, max_batch, precision=_lib.PREC_BF16):
+    check(self._h, lib().ditree_denoise_reserve(self._h, int(max_batch), int(precision)), "denoise_reserve")
+
+
+def _ctx_denoise(self, noise, local_map, cond, t0=None, dt=None, act_norm=None, want_actions=True):
+    """noise (B,P,D) f32, local_map (B,n,n) f32 scaled to {-1,1}, cond (B,G) f32 [device].
+    Returns actions (B,P,D) f64 when want_actions else the normalised sample x_K (f32)."""
+    dev = self.device
+    _chk(noise, torch.float32, "noise", dev)
+    _chk(local_map, torch.float32, "local_map", dev)
+    _chk(cond, torch.float32, "cond", dev)
+    B = noise.shape[0]
+    t0 = np.zeros(1, dtype=np.float32) if t0 is None else t0
+    dt = np.ones(1, dtype=np.float32) if dt is None else dt
+    t0a, t0p = _flt(t0)
+    dta, dtp = _flt(dt)
+    an, anp = _dbl(CAR_NORM[12:16] if act_norm is None else act_norm)
+    actions = torch.empty(noise.shape, dtype=torch.float64, device=dev) if want_actions else None
+    xout = None if want_actions else torch.empty_like(noise)
+    check(self._h, lib().ditree_denoise(self._h, _ptr(noise), _ptr(local_map), _ptr(cond), B, len(t0a), t0p, dtp,
+                                        anp, _ptr(actions), _ptr(xout), self.stream), "denoise")
+    return actions if want_actions else xout
+
+
+def _ctx_debug_read(self, name, B, capacity=1 << 26):
+    out = torch.empty(capacity, dtype=torch.float32, device=self.device)
+    dims = (C.c_int32 * 3)()
+    check(self._h, lib().ditree_denoise_debug_read(self._h, name.encode(), B, _ptr(out), capacity, dims,
+                                                   self.stream), "debug_read")
+    n = dims[0] * dims[1] * dims[2]
+    return out[:n].reshape(dims[0], dims[1], dims[2]).clone()
+
+
+Context.load_weights = _ctx_load_weights
+Context.denoise_reserve = _ctx_denoise_reserve
+Context.denoise = _ctx_denoise
+Context.debug_read = _ctx_debug_read

@@ -189,6 +189,12 @@ int32_t ditree_denoise(ditree_ctx* ctx, const float* noise, const float* local_m
                        const float* cond, int32_t B, int32_t K, const float* t0, const float* dt,
                        const double* act_norm, double* actions, float* x_out, void* stream);
 
+/* Test / debug support: copy a named internal activation of the last ditree_denoise call
+ * (e.g. "d0b1.out", "skip2", "mid2.out", "final.h", "film", "map_emb") as f32
+ * (B, L, C) into out [dev]; dims3 [host] receives (B, L, C). */
+int32_t ditree_denoise_debug_read(ditree_ctx* ctx, const char* name, int32_t B, float* out,
+                                  int64_t capacity, int32_t* dims3, void* stream);
+
 /* One expansion round for B candidates (planners/RRT.py:131-194 batched):
  * nearest node -> n_chunks x [local map -> cond -> denoise (or injected actions)
  * -> rollout].  Fills `round`; does not modify the tree (call ditree_accept, after
