@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Candidate tree-expansions/sec (carmaze, H = 32) on N MI355X -- the BASELINE.json metric.
+
+One *step* = one expansion round of the hot path over a batch of synthetic candidates:
+nearest node over an N0-node tree snapshot -> 4 chunks x [local map -> conditioning vector ->
+denoiser (ResNet-18-GN encoder + FiLM U-Net, one flow step) -> 8 bicycle-model steps with goal
+and two-ball collision tests] -> accept/append (plus the RCCL all-gather of candidate records
+when N > 1).  Per-GPU batch is fixed (weak scaling); every candidate runs all 4 denoiser calls
+(no early-exit compaction), so one candidate = 23.72 GFLOP of algorithmic denoiser work
+(SURVEY.md section 8(d)).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+MAC_PER_CALL = 2_939_097_088 + 26_327_808          # U-Net + encoder MACs per denoiser call
+PEAK_BF16_TFLOPS = 2500.0                          # dense bf16 MFMA peak, MI355X_MICROARCH.md
+H, A, P = 32, 8, 64
+N0 = 1024                                          # tree snapshot size
+
+
+def load_maze(name):
+    return np.loadtxt(os.path.join(REPO, "ditreeonlineplanner_amd", "data", f"{name}.csv"), delimiter=",")
+
+
+def synth_inputs(maze, B_total, seed=20260104):
+    """Seeded synthetic round inputs."""
+    rng = np.random.default_rng(seed)
+    Hh, W = maze.shape
+    free = np.argwhere(maze[1:-1, 1:-1] == 0) + 1
+    cell = free[rng.integers(0, len(free), N0)]
+    # inside the cell with margin 0.25: the two balls (0.075 + 0.1) never reach a neighbour cell
+    x = (cell[:, 1] + 0.5) - W / 2 + rng.uniform(-0.25, 0.25, N0)
+    y = Hh / 2 - (cell[:, 0] + 0.5) + rng.uniform(-0.25, 0.25, N0)
+    nodes = np.stack([x, y, rng.uniform(-np.pi, np.pi, N0), rng.uniform(0, 4, N0), rng.uniform(0, 1, N0),
+                      rng.uniform(-0.4, 0.4, N0)], axis=1)
+    goal = np.array([(17 + 0.5) - W / 2, Hh / 2 - (2 + 0.5), 0, 0, 0, 0.0])
+    # samples as base_planner.py:162-207 (0.15 goal rate), conditioning coin as RRT.py:153-156
+    is_goal = rng.random(B_total) <= 0.15
+    samples = np.stack([rng.uniform(-W / 2, W / 2, B_total), rng.uniform(-Hh / 2, Hh / 2, B_total),
+                        rng.uniform(-np.pi, np.pi, B_total), rng.uniform(-5, 5, B_total),
+                        rng.uniform(-1, 1, B_total), rng.uniform(-0.4, 0.4, B_total)], axis=1)
+    samples[is_goal] = goal
+    coin = rng.random(B_total) > 0.85
+    cond = np.where(coin[:, None], samples[:, :2], goal[None, :2])
+    g = torch.Generator().manual_seed(seed)
+    noise = torch.randn(B_total, H // A, P, 2, generator=g)
+    return nodes, goal, samples, cond, noise
+
+
+def cpu_baseline(maze, nodes, goal, samples, cond, noise, state_dict, n_cand=64, batch=32):
+    """The oracle (numpy geometry + torch-CPU fp32 denoiser) on a bounded sample of the same workload."""
+    from oracle import denoiser as OD
+    from oracle import geometry as G
+    from oracle import rrt as ORRT
+    from oracle import sampler as OS
+    torch.set_num_threads(os.cpu_count() or 1)
+    net = OD.init_noise_pred_net().eval()
+    net.load_state_dict(state_dict)
+    noise_np = noise.numpy()
+
+    def sampler(cand_idx, chunk, state, prev_action, has_prev, cond_goal, local_map):
+        cv = OS.car_cond_vector(state, prev_action, has_prev, cond_goal)
+        x1 = OS.flow_sample(net, noise_np[cand_idx, chunk], OS.scale_local_map(local_map), cv, k_steps=1)
+        return OS.unnormalize_actions(x1)
+
+    pl = ORRT.OraclePlanner(maze, nodes[0], goal, sampler, edge_length=H, action_horizon=A, emulate_sticky_done=False)
+    t = pl.tree
+    for i in range(1, len(nodes)):
+        t.states.append(nodes[i].copy()); t.parents.append(0); t.last_action.append(np.zeros(2))
+        t.has_prev.append(True); t.num_visit.append(0); t.edge_states.append(None); t.edge_actions.append(None)
+    t0 = time.perf_counter()
+    done = 0
+    while done < n_cand:
+        pl.candidates = done                      # keep the candidate index == noise row
+        pl.goal_node = None
+        pl.expand_round(samples[done:done + batch], cond[done:done + batch])
+        done += batch
+        del t.states[N0:], t.parents[N0:], t.last_action[N0:], t.has_prev[N0:], t.num_visit[N0:]
+        del t.edge_states[N0:], t.edge_actions[N0:]
+    dt = time.perf_counter() - t0
+    return dict(value=n_cand / dt, unit="candidate expansions/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n_cand} candidates (rounds of {batch}) of the same synthetic workload, "
+                       f"oracle numpy geometry + torch-CPU fp32 denoiser, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="candidates per GPU per round")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch event timing")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from ditreeonlineplanner_amd import _lib
+    from ditreeonlineplanner_amd.engine import CNT_GOAL, CNT_LATCH, CNT_NODES, ExpansionEngine
+    from ditreeonlineplanner_amd.model import NoisePredNet
+    from ditreeonlineplanner_amd.ops import Context
+
+    Bper = args.batch
+    Btot = Bper * world
+    maze = load_maze("boxes")
+    nodes, goal, samples, cond, noise = synth_inputs(maze, Btot)
+    ctx = Context(local)
+    net = NoisePredNet(seed=0)
+    net.bind(ctx, precision=_lib.PREC_BF16, max_batch=Bper)
+    eng = ExpansionEngine(ctx, maze, nodes[0], goal, edge_length=H, action_horizon=A, pred_horizon=P, batch=Btot,
+                          capacity=N0 + Btot, rank=rank, world_size=world, emulate_sticky_done=False)
+    dev = ctx.device
+    t = eng.tree
+    nd = torch.as_tensor(nodes, device=dev)
+
+    def reset_tree():
+        t.counters[CNT_NODES] = N0
+        t.counters[CNT_GOAL] = -1
+        t.counters[CNT_LATCH] = 0
+        t.n_nodes_host = N0
+    t.state[:N0] = nd
+    t.xy[:N0] = nd[:, :2]
+    t.parent[:N0] = torch.arange(-1, N0 - 1, device=dev, dtype=torch.int32).clamp(min=0)
+    t.parent[0] = -1
+    t.has_prev[:N0] = 1
+    reset_tree()
+    s_dev = torch.as_tensor(samples, device=dev)
+    c_dev = torch.as_tensor(cond, device=dev)
+    n_dev = noise.to(dev)
+    torch.cuda.synchronize()
+
+    def step():
+        eng.expand_round(s_dev, c_dev, noise=n_dev)       # includes all-gather (N > 1) and accept
+        reset_tree()
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_profile:
+        ctx.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        et = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        elapsed = float(et.item())
+    gemm_ms, launches = (0.0, 0)
+    if not args.no_profile:
+        gemm_ms, launches = ctx.profile_read()
+        ctx.profile(False)
+
+    if rank == 0:
+        n_chunks = H // A
+        value = Btot * args.steps / elapsed
+        out = {
+            "metric": "candidate tree-expansions/sec (carmaze, H=32)", "value": value,
+            "unit": "candidate expansions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"cfgs/carmaze.yaml + fm_policy flow sampler (K=1), batch={Bper} candidates per GPU, "
+                                   f"H=32 (4 chunks x 8 steps), boxes.csv 20x20, {N0}-node tree snapshot, seeded random weights",
+                       "batch_per_gpu": Bper, "global_batch": Btot, "edge_length": H, "action_horizon": A,
+                       "pred_horizon": P, "flow_steps": 1, "tree_nodes": N0, "parallelism": f"candidates sharded x{world}"},
+        }
+        if launches > 0:
+            flop_total = 2.0 * MAC_PER_CALL * Bper * n_chunks * args.steps          # per rank, algorithmic
+            ach = flop_total / (gemm_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                               "kernel": "conv_gemm_kernel<bf16>", "launches": launches,
+                               "avg_launch_ms": gemm_ms / launches,
+                               "algorithmic_gflop_per_launch": flop_total / launches / 1e9,
+                               "kernel_time_share": gemm_ms * 1e-3 / elapsed}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(maze, nodes, goal, samples, cond, noise, net.state_dict())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -66,6 +66,34 @@ struct DenoiserState {
   int condK = 0, film_cols = 0;
   Act final_h;                   // input of the final 1x1 projection
   const float* lm_ptr = nullptr; // caller's scaled local map of the current call
+  // optional per-launch timing of the dominant kernel (hipEvents on the launch stream)
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;
+  size_t prof_used = 0;
+  double prof_ms_done = 0.0;
+  int64_t prof_launches_done = 0;
+  void run_gemm(const ConvGemmParams& p, hipStream_t s) {
+    if (!prof_on) { launch_conv_gemm(p, prec, s); return; }
+    if (prof_used + 2 > prof_ev.size()) {
+      const size_t old = prof_ev.size();
+      prof_ev.resize(old + 4096);
+      for (size_t i = old; i < prof_ev.size(); ++i) hipEventCreate(&prof_ev[i]);
+    }
+    hipEventRecord(prof_ev[prof_used], s);
+    launch_conv_gemm(p, prec, s);
+    hipEventRecord(prof_ev[prof_used + 1], s);
+    prof_used += 2;
+  }
+  void prof_collect() {
+    if (prof_used == 0) return;
+    hipEventSynchronize(prof_ev[prof_used - 1]);
+    for (size_t i = 0; i + 1 < prof_used; i += 2) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, prof_ev[i], prof_ev[i + 1]) == hipSuccess) prof_ms_done += ms;
+      ++prof_launches_done;
+    }
+    prof_used = 0;
+  }
   int es() const { return prec == 0 ? 2 : 4; }
 
   const HostParam& P_(const std::string& name) const {
@@ -174,9 +202,9 @@ struct DenoiserState {
       p.Res = aptr(*res); p.ldres = res->ld; p.res_Lp = res->Lp(); p.res_off = res->padded ? 1 : 0;
     }
     const int L = in.L, pr = prec;
-    ops.push_back([p, L, pr](int, int Bp, hipStream_t s) mutable {
+    ops.push_back([this, p, L](int, int Bp, hipStream_t s) mutable {
       p.M = Bp * L;
-      launch_conv_gemm(p, pr, s);
+      run_gemm(p, s);
     });
   }
   // Conv1d(k = 1) residual projection.
@@ -192,9 +220,9 @@ struct DenoiserState {
     p.Out = (void*)aptr(out); p.ldc = out.ld; p.out_Lp = out.Lp(); p.out_stride = 1; p.out_off = 1;
     p.L = in.L; p.N = Cout; p.bias = vec(wname + ".bias"); p.mode = MODE_BIAS;
     const int L = in.L, pr = prec;
-    ops.push_back([p, L, pr](int, int Bp, hipStream_t s) mutable {
+    ops.push_back([this, p, L](int, int Bp, hipStream_t s) mutable {
       p.M = Bp * L;
-      launch_conv_gemm(p, pr, s);
+      run_gemm(p, s);
     });
   }
   // Downsample1d: Conv1d(C, C, 3, stride 2, pad 1)  (conv1d_components.py:7-13)
@@ -210,9 +238,9 @@ struct DenoiserState {
     p.Out = (void*)aptr(out); p.ldc = out.ld; p.out_Lp = out.Lp(); p.out_stride = 1; p.out_off = 1;
     p.L = out.L; p.N = Cout; p.bias = vec(wname + ".bias"); p.mode = MODE_BIAS;
     const int L = out.L, pr = prec;
-    ops.push_back([p, L, pr](int, int Bp, hipStream_t s) mutable {
+    ops.push_back([this, p, L](int, int Bp, hipStream_t s) mutable {
       p.M = Bp * L;
-      launch_conv_gemm(p, pr, s);
+      run_gemm(p, s);
     });
   }
   // Upsample1d: ConvTranspose1d(C, C, 4, 2, 1) as two 2-tap GEMMs (even / odd outputs)
@@ -233,9 +261,9 @@ struct DenoiserState {
       p.Out = (void*)aptr(out); p.ldc = out.ld; p.out_Lp = out.Lp(); p.out_stride = 2; p.out_off = 1 + par;
       p.L = in.L; p.N = Cout; p.bias = vec(wname + ".bias"); p.mode = MODE_BIAS;
       const int L = in.L, pr = prec;
-      ops.push_back([p, L, pr](int, int Bp, hipStream_t s) mutable {
+      ops.push_back([this, p, L](int, int Bp, hipStream_t s) mutable {
         p.M = Bp * L;
-        launch_conv_gemm(p, pr, s);
+        run_gemm(p, s);
       });
     }
   }
@@ -306,9 +334,9 @@ void DenoiserState::build(int prec_, int Bmax_) {
     p.W = wp; p.Out = film; p.ldc = film_cols; p.out_Lp = 0; p.out_stride = 1; p.out_off = 0;
     p.N = film_cols; p.bias = bd; p.mode = MODE_BIAS; p.out_f32 = 1;
     const int pr = prec;
-    film_op = [p, pr](int, int Bp, hipStream_t s) mutable {
+    film_op = [this, p](int, int Bp, hipStream_t s) mutable {
       p.M = Bp; p.L = Bp; p.in_Lp = Bp; p.out_Lp = Bp;
-      launch_conv_gemm(p, pr, s);
+      run_gemm(p, s);
     };
   }
 
@@ -338,7 +366,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
     p.gamma = vec(pre + ".blocks.0.block.1.weight"); p.beta = vec(pre + ".blocks.0.block.1.bias"); p.group_ch = C0 / 8;
     p.film = film; p.film_ld = film_cols; p.film_off = film_offs[0];
     const int pr = prec, L = L0;
-    unet_ops.push_back([p, L, pr](int, int Bp, hipStream_t s) mutable { p.M = Bp * L; launch_conv_gemm(p, pr, s); });
+    unet_ops.push_back([this, p, L](int, int Bp, hipStream_t s) mutable { p.M = Bp * L; run_gemm(p, s); });
     // residual Conv1d(D, C0, 1): centre-tap columns of the same rows
     const HostParam& wr = P_(pre + ".residual_conv.weight");
     const float* wrd = wr.data;
@@ -350,7 +378,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
     q.A = a0.p; q.lda = 64; q.in_Lp = L0; q.in_stride = 1; q.in_off = 0; q.taps = 1; q.Cin = 64;
     q.W = wrp; q.Out = res.p; q.ldc = res.ld; q.out_Lp = res.Lp(); q.out_stride = 1; q.out_off = 1;
     q.L = L0; q.N = C0; q.bias = vec(pre + ".residual_conv.bias"); q.mode = MODE_BIAS;
-    unet_ops.push_back([q, L, pr](int, int Bp, hipStream_t s) mutable { q.M = Bp * L; launch_conv_gemm(q, pr, s); });
+    unet_ops.push_back([this, q, L](int, int Bp, hipStream_t s) mutable { q.M = Bp * L; run_gemm(q, s); });
     Act o = make_act("d0b1.out", L0, C0);
     add_conv3(unet_ops, pre + ".blocks.1.block.0", h, o, MODE_GN_MISH_RES, pre + ".blocks.1.block.1", 0, &res);
     fc = film_offs[1];
@@ -430,14 +458,14 @@ void DenoiserState::build(int prec_, int Bmax_) {
         for (int cc = 0; cc < Cw; ++cc) s += wd[(((size_t)n * Cw + cc) * k + kh) * k + kw];
         return s;
       });
-      enc_ops.push_back([=](int B, int, hipStream_t s) {
+      enc_ops.push_back([=, this](int B, int, hipStream_t s) {
         launch_im2col2d(in, in_f32, col, B, H, W, Cin, k, k, stride, pad, OH, OW, Kpad, pr, s);
         ConvGemmParams p{};
         const int M = B * OH * OW;
         p.A = col; p.lda = Kpad; p.in_Lp = M; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = Kpad;
         p.W = wp; p.Out = gout; p.ldc = Cout; p.out_Lp = M; p.out_stride = 1; p.out_off = 0;
         p.L = M; p.M = M; p.N = Cout; p.mode = MODE_BIAS; p.out_f32 = 1;
-        launch_conv_gemm(p, pr, s);
+        run_gemm(p, s);
       });
     };
     auto gn = [&](const std::string& gname, const Act& out, const Act* res, bool relu) {
@@ -467,14 +495,14 @@ void DenoiserState::build(int prec_, int Bmax_) {
       });
       const int HH = H0, OO = H1;
       const float** lm_slot = &lm_ptr;
-      enc_ops.push_back([=](int B, int, hipStream_t s) {
+      enc_ops.push_back([=, this](int B, int, hipStream_t s) {
         launch_im2col2d(*lm_slot, true, col, B, HH, HH, 1, 7, 7, 2, 3, OO, OO, 64, pr, s);
         ConvGemmParams p{};
         const int M = B * OO * OO;
         p.A = col; p.lda = 64; p.in_Lp = M; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = 64;
         p.W = wp; p.Out = gout; p.ldc = 64; p.out_Lp = M; p.out_stride = 1; p.out_off = 0;
         p.L = M; p.M = M; p.N = 64; p.mode = MODE_BIAS; p.out_f32 = 1;
-        launch_conv_gemm(p, pr, s);
+        run_gemm(p, s);
       });
     }
     gn(R + "bn1", c1, nullptr, true);
@@ -526,12 +554,12 @@ void DenoiserState::build(int prec_, int Bmax_) {
       float* bd = vec(R + "fc.bias");
       void* ip = pooled.p;
       float* op = map_emb;
-      enc_ops.push_back([=](int B, int, hipStream_t s) {
+      enc_ops.push_back([=, this](int B, int, hipStream_t s) {
         ConvGemmParams p{};
         p.A = ip; p.lda = Kf; p.in_Lp = B; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = Kf;
         p.W = wp; p.Out = op; p.ldc = Nf; p.out_Lp = B; p.out_stride = 1; p.out_off = 0;
         p.L = B; p.M = B; p.N = Nf; p.bias = bd; p.mode = MODE_BIAS; p.out_f32 = 1;
-        launch_conv_gemm(p, pr, s);
+        run_gemm(p, s);
       });
     }
   }
@@ -600,6 +628,8 @@ int denoise_run(ditree_ctx* ctx, const float* noise, const float* local_map, con
 
 void denoise_destroy(ditree_ctx* ctx) {
   if (ctx->dn) {
+    for (auto e : ctx->dn->prof_ev) hipEventDestroy(e);
+    ctx->dn->prof_ev.clear();
     ctx->dn->free_workspace();
     delete ctx->dn;
     ctx->dn = nullptr;
@@ -664,6 +694,26 @@ int32_t ditree_denoise(ditree_ctx* ctx, const float* noise, const float* local_m
                        float* x_out, void* stream) {
   if (!ctx) return DITREE_E_ARG;
   return denoise_run(ctx, noise, local_map, cond, B, K, t0, dt, act_norm, actions, x_out, (hipStream_t)stream);
+}
+
+int32_t ditree_profile(ditree_ctx* ctx, int32_t enable) {
+  if (!ctx) return DITREE_E_ARG;
+  DenoiserState* st = ctx->dn;
+  if (!st) return set_err(ctx, DITREE_E_STATE, "profile: weights not loaded");
+  st->prof_collect();
+  st->prof_on = enable != 0;
+  if (enable) { st->prof_ms_done = 0.0; st->prof_launches_done = 0; }
+  return DITREE_OK;
+}
+
+int32_t ditree_profile_read(ditree_ctx* ctx, double* gemm_ms, int64_t* gemm_launches) {
+  if (!ctx) return DITREE_E_ARG;
+  DenoiserState* st = ctx->dn;
+  if (!st || !gemm_ms || !gemm_launches) return set_err(ctx, DITREE_E_STATE, "profile_read: bad state");
+  st->prof_collect();
+  *gemm_ms = st->prof_ms_done;
+  *gemm_launches = st->prof_launches_done;
+  return DITREE_OK;
 }
 
 int32_t ditree_denoise_debug_read(ditree_ctx* ctx, const char* name, int32_t B, float* out, int64_t capacity,

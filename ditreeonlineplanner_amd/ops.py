@@ -219,3 +219,17 @@ Context.load_weights = _ctx_load_weights
 Context.denoise_reserve = _ctx_denoise_reserve
 Context.denoise = _ctx_denoise
 Context.debug_read = _ctx_debug_read
+
+
+def _ctx_profile(self, enable=True):
+    check(self._h, lib().ditree_profile(self._h, int(bool(enable))), "profile")
+
+
+def _ctx_profile_read(self):
+    ms, n = C.c_double(), C.c_int64()
+    check(self._h, lib().ditree_profile_read(self._h, C.byref(ms), C.byref(n)), "profile_read")
+    return ms.value, n.value
+
+
+Context.profile = _ctx_profile
+Context.profile_read = _ctx_profile_read
