@@ -65,7 +65,9 @@ def cpu_baseline(maze, nodes, goal, samples, cond, noise, state_dict, n_cand=64,
     from oracle import geometry as G
     from oracle import rrt as ORRT
     from oracle import sampler as OS
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives one GPU's job a 16-core CPU share; more threads than that only oversubscribe
+    ncpu = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    torch.set_num_threads(ncpu)
     net = OD.init_noise_pred_net().eval()
     net.load_state_dict(state_dict)
     noise_np = noise.numpy()

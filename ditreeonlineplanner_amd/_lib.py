@@ -81,6 +81,9 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch bundles its own libamdhip64.so.7; it must be the HIP runtime of the process (tensors and
+    # streams come from torch), so make sure it is mapped before our library resolves the same SONAME.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise DitreeLibraryError(
             f"{LIB_PATH} is missing: build it with `python -m ditreeonlineplanner_amd.build` "

@@ -593,8 +593,8 @@ static int parse_manifest(DenoiserState* st, const char* manifest, int64_t n_flo
   return 0;
 }
 
-int denoise_run(ditree_ctx* ctx, const float* noise, const float* local_map, const float* cond, int B, int K,
-                const float* t0, const float* dt, const double* act_norm, double* actions, float* x_out,
+int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const float* local_map, const float* cond,
+                int B, int K, const float* t0, const float* dt, const double* act_norm, double* actions, float* x_out,
                 hipStream_t s) {
   DenoiserState* st = ctx->dn;
   if (!st || !st->loaded) return set_err(ctx, DITREE_E_STATE, "denoise: weights not loaded");
@@ -604,7 +604,12 @@ int denoise_run(ditree_ctx* ctx, const float* noise, const float* local_map, con
     return set_err(ctx, DITREE_E_ARG, "denoise: bad argument");
   const int Bp = (B + 15) / 16 * 16;
   const int pr = st->prec;
-  HIP_TRY(ctx, hipMemcpyAsync(st->x_cur, noise, (size_t)B * st->P * st->D * 4, hipMemcpyDeviceToDevice, s));
+  {
+    const size_t row = (size_t)st->P * st->D * 4;         // one candidate's (P, D) f32 noise
+    if (noise_stride < (int64_t)st->P * st->D) return set_err(ctx, DITREE_E_ARG, "denoise: noise stride");
+    HIP_TRY(ctx, hipMemcpy2DAsync(st->x_cur, row, noise, (size_t)noise_stride * 4, row, (size_t)B,
+                                  hipMemcpyDeviceToDevice, s));
+  }
   st->lm_ptr = local_map;
   for (auto& op : st->enc_ops) op(B, Bp, s);
   for (int k = 0; k < K; ++k) {
@@ -693,7 +698,9 @@ int32_t ditree_denoise(ditree_ctx* ctx, const float* noise, const float* local_m
                        int32_t K, const float* t0, const float* dt, const double* act_norm, double* actions,
                        float* x_out, void* stream) {
   if (!ctx) return DITREE_E_ARG;
-  return denoise_run(ctx, noise, local_map, cond, B, K, t0, dt, act_norm, actions, x_out, (hipStream_t)stream);
+  if (!ctx->dn) return set_err(ctx, DITREE_E_STATE, "denoise: weights not loaded");
+  return denoise_run(ctx, noise, (int64_t)ctx->dn->P * ctx->dn->D, local_map, cond, B, K, t0, dt, act_norm, actions, x_out,
+                     (hipStream_t)stream);
 }
 
 int32_t ditree_profile(ditree_ctx* ctx, int32_t enable) {

@@ -10,8 +10,8 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
                            double* states_out, int64_t states_stride, double* actions_out, int64_t actout_stride,
                            int32_t* steps_out, int64_t steps_stride, int32_t* chunks_run, double* prev_action_io,
                            uint8_t* has_prev_io, hipStream_t s);
-int denoise_run(ditree_ctx* ctx, const float* noise, const float* local_map, const float* cond, int B, int K,
-                const float* t0, const float* dt, const double* act_norm, double* actions, float* x_out,
+int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const float* local_map, const float* cond,
+                int B, int K, const float* t0, const float* dt, const double* act_norm, double* actions, float* x_out,
                 hipStream_t s);
 void denoise_destroy(ditree_ctx* ctx);
 
@@ -260,8 +260,8 @@ int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditr
       launch_cond_vector(ctx->cur_state, ctx->prev_action, ctx->has_prev, p->cond_goal, B, nm, p->lm_size,
                          ctx->cond, s);
       double an[4] = {p->norm[12], p->norm[13], p->norm[14], p->norm[15]};
-      rc = denoise_run(ctx, p->noise + (size_t)j * P * 2, ctx->lmap, ctx->cond, B, p->K, p->t0, p->dt, an,
-                       ctx->act64, nullptr, s);
+      rc = denoise_run(ctx, p->noise + (size_t)j * P * 2, (int64_t)nC * P * 2, ctx->lmap, ctx->cond, B, p->K, p->t0,
+                       p->dt, an, ctx->act64, nullptr, s);
       if (rc) return rc;
       acts = ctx->act64;
       act_stride = (int64_t)P * 2;
