@@ -90,6 +90,30 @@ class RoundBuffers:
         return Round(n, *[t[lo:lo + n].data_ptr() if n > 0 else t.data_ptr() for t in self.fields()])
 
 
+def allgather_round_fields(fields, per, rank, world, group=None):
+    """One fixed-stride all-gather per candidate-record field.
+
+    Every field is a tensor whose leading axis is the round's candidate index; rank r produced
+    rows [r*per, (r+1)*per).  After the call all ranks hold all rows, so the replicated,
+    deterministic accept step builds the same tree everywhere.  With the nccl backend (RCCL) the
+    gather runs device-to-device over xGMI; with gloo (CPU tests, or several ranks sharing one
+    GPU in a test) CUDA tensors are staged through the host.
+    """
+    import torch.distributed as dist
+    backend = dist.get_backend(group)
+    for t in fields:
+        if t.shape[0] < per * world:
+            raise ValueError("round buffers must hold ceil(B / world) * world candidates")
+        flat = t[: per * world]
+        mine = flat[rank * per:(rank + 1) * per]
+        if backend == "gloo" and flat.is_cuda:
+            host = torch.empty(flat.shape, dtype=flat.dtype)
+            dist.all_gather_into_tensor(host, mine.cpu().contiguous(), group=group)
+            flat.copy_(host)
+        else:
+            dist.all_gather_into_tensor(flat, mine.clone(), group=group)
+
+
 class ExpansionEngine:
     """Batched RRT expansion on one GPU (optionally one shard of a multi-GPU round)."""
 
@@ -105,7 +129,7 @@ class ExpansionEngine:
         self.batch = batch
         self.k_steps = k_steps
         self.sticky = int(bool(emulate_sticky_done))
-        self.norm = np.ascontiguousarray(norm, dtype=np.float64)
+        self.norm = np.ascontiguousarray(CAR_NORM if norm is None else norm, dtype=np.float64)
         self.rank, self.world, self.pg = rank, world_size, process_group
         self.tree = DeviceTree(ctx, capacity, self.n_chunks, self.A)
         self.rb = RoundBuffers(ctx, batch, self.n_chunks, self.A)
@@ -168,17 +192,11 @@ class ExpansionEngine:
         if self.world > 1:
             self._allgather_round(B, per)
         if accept:
-            self.accept(B)
+            return self.accept(B)
+        return None
 
     def _allgather_round(self, B, per):
-        """One fixed-stride all-gather per record field (RCCL over xGMI when the backend is nccl)."""
-        import torch.distributed as dist
-        for t in self.rb.fields()[:-1]:
-            flat = t[: per * self.world]
-            if flat.shape[0] < per * self.world:
-                raise ValueError("engine batch must be >= ceil(B / world) * world")
-            lo = self.rank * per
-            dist.all_gather_into_tensor(flat, flat[lo:lo + per].clone(), group=self.pg)
+        allgather_round_fields(self.rb.fields()[:-1], per, self.rank, self.world, self.pg)
 
     def accept(self, B):
         rd = self.rb.desc(0, B)

@@ -233,3 +233,15 @@ def _ctx_profile_read(self):
 
 Context.profile = _ctx_profile
 Context.profile_read = _ctx_profile_read
+
+
+_DEFAULT = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    """Process-wide Context per device (the facades share it, like the reference shares one env)."""
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if device not in _DEFAULT:
+        _DEFAULT[device] = Context(device)
+    return _DEFAULT[device]

@@ -1,0 +1,137 @@
+"""RRT_Planner facade (reference: planners/RRT.py:18-257) -- the expand loop as wide rounds on the GPU.
+
+Constructor kwargs, ``plan() -> (path f32 (P,6)|None, actions f32 (A,2)|None)``, ``reset``,
+``update_maze``, ``results`` and ``node_list`` follow the reference.  Extra kwargs:
+  ``batch``            candidates per round (default 256; 1 = the reference's sequential order),
+  ``max_candidates``   deterministic budget instead of / in addition to the wall-clock budget,
+  ``edge_length``      = prop_duration[0] (the reference's per-visit schedule needs sequential
+                       visits; a schedule with more than one entry raises NotImplementedError).
+``run_type`` > 0 (reference-path tracking / sampling-bias maps) is the "next" scope row.
+"""
+from __future__ import annotations
+
+import random
+import time
+
+import numpy as np
+import torch
+
+from ..engine import CNT_ITERS, ExpansionEngine
+from .base_planner import BasePlanner, Node
+
+
+class RRT_Planner(BasePlanner):
+    def __init__(self, start_state, goal_state, environment, sampler, **kwargs):
+        super().__init__(start_state, goal_state, environment, sampler, **kwargs)
+        self.kd_tree_dim = 2
+        self.goal_sample_rate = 0.15
+        self.goal_conditioning_bias = kwargs.get("goal_conditioning_bias", 0.85)
+        self.prop_duration_schedule = kwargs.get("prop_duration", [64])
+        if len(self.prop_duration_schedule) != 1:
+            raise NotImplementedError("prop_duration schedules with more than one length need sequential visits")
+        self.offline_time_budget = kwargs.get("offline_time_budget", 60)
+        self.plan_count = 0
+        self.init_main_path = None
+        self.run_type = kwargs.get("run_type", 0)
+        if self.run_type != 0:
+            raise NotImplementedError("run_type > 0 is a later scope row (SURVEY 8(f))")
+        self.env.run_type = self.run_type
+        self.batch = int(kwargs.get("batch", 256))
+        self.max_candidates = kwargs.get("max_candidates", None)
+        self.capacity = int(kwargs.get("capacity", 65536))
+        lm = self.local_map_size if isinstance(self.local_map_size, (int, float)) else self.local_map_size[0]
+        self._engine = ExpansionEngine(
+            self.ctx, self.maze, self.start_node.state, self.goal_state, edge_length=self.prop_duration_schedule[0],
+            action_horizon=self.action_horizon, pred_horizon=getattr(sampler, "pred_horizon", 64),
+            local_map_size=int(lm), local_map_scale=self.local_map_scale, s_global=self.s_global, batch=self.batch,
+            capacity=self.capacity, k_steps=getattr(sampler, "num_diffusion_iters", 1),
+            norm=getattr(sampler, "norm", None) if getattr(sampler, "norm", None) is not None else None,
+            emulate_sticky_done=kwargs.get("emulate_sticky_done", True))
+        self._engine.env_goal = np.asarray(self.env.goal, dtype=np.float64)
+
+    # ------------------------------------------------------------------ reference surface
+    def reset(self, start_state=None, goal_state=None, reset_main_path=False):
+        if reset_main_path:
+            self.init_main_path = None
+        if start_state is not None:
+            self.start_node = Node(np.asarray(start_state, dtype=np.float64))
+            self.goal_state = np.asarray(goal_state, dtype=np.float64)
+            self.options["reset_cell"] = self.env.cell_xy_to_rowcol(start_state[:2])
+            self.options["reset_deg"] = np.rad2deg(start_state[2])
+            self.options["goal_cell"] = self.env.cell_xy_to_rowcol(goal_state[:2])
+        self.failed_node_list = []
+        self.results = {"iterations": 0, "time": 0, "path": None, "actions": None, "number_of_nodes": 0}
+        self.env.reset(options=self.options)
+        self._engine.reset(self.start_node.state, self.goal_state)
+        self._engine.env_goal = np.asarray(self.env.goal, dtype=np.float64)
+
+    def update_maze(self, new_maze):
+        self.maze = np.float32(new_maze)
+        self.env.maze_map = new_maze
+        self._engine.update_maze(self.maze)
+
+    @property
+    def node_list(self):
+        """Materialise ``Node`` objects from the device tree (RRT.py:42, base_planner.py:24-34)."""
+        t = self._engine.tree
+        n = t.n_nodes_host
+        states = t.state[:n].cpu().numpy()
+        parents = t.parent[:n].cpu().numpy()
+        es, ea = t.edge_states[:n].cpu().numpy(), t.edge_actions[:n].cpu().numpy()
+        ns, na = t.edge_nstates[:n].cpu().numpy(), t.edge_nactions[:n].cpu().numpy()
+        nv = t.num_visit[:n].cpu().numpy()
+        nodes = []
+        for i in range(n):
+            if i == 0:
+                nd = Node(states[0])
+            else:
+                nd = Node(states[i], ea[i, : na[i]], es[i, : ns[i]][None], parent=nodes[parents[i]])
+            nd.num_visit = int(nv[i])
+            nodes.append(nd)
+        return nodes
+
+    def nearest_node(self, sample):
+        t = self._engine.tree
+        q = torch.as_tensor(np.ascontiguousarray(np.asarray(sample, dtype=np.float64)[:, :2]), device=self.ctx.device)
+        idx = self.ctx.nn_argmin(q, t.xy, n_nodes=t.n_nodes_host)
+        return self.node_list[int(idx[0].item())]
+
+    def draw_round(self, B):
+        """B x [random_node_sample -> conditioning coin] in the reference's RNG call order
+        (base_planner.py:162-207, RRT.py:153-156)."""
+        s = np.zeros((B, 6))
+        c = np.zeros((B, 2))
+        for i in range(B):
+            smp = self.random_node_sample()
+            s[i] = smp[0]
+            c[i] = smp[0, :2] if random.random() > self.goal_conditioning_bias else self.goal_state[:2]
+        return s, c
+
+    # ------------------------------------------------------------------ plan
+    def plan(self):
+        eng = self._engine
+        dev = self.ctx.device
+        if hasattr(self.sampler, "ensure_bound"):
+            self.sampler.ensure_bound(self.batch)
+        start_time = time.time()
+        drawn = 0
+        goal = None
+        while (time.time() - start_time) < self.time_budget:
+            if self.max_candidates is not None and drawn >= self.max_candidates:
+                break
+            B = self.batch if self.max_candidates is None else min(self.batch, self.max_candidates - drawn)
+            s, c = self.draw_round(B)
+            noise = torch.randn((B, eng.n_chunks, eng.P, 2), device=dev)
+            cnt = eng.expand_round(torch.as_tensor(s, device=dev), torch.as_tensor(c, device=dev), noise=noise)
+            drawn += B
+            goal = eng.goal_node
+            if goal is not None:
+                break
+        iters = int(eng.tree.counters[CNT_ITERS].item())
+        if goal is not None:
+            self.env.done = True
+            return self.handle_goal_reached(goal, iters, start_time)
+        node = eng.fallback_node()                          # RRT.py:233-237
+        if node is None:
+            return self.handle_goal_not_reached(iters, start_time)
+        return self.handle_goal_reached(node, iters, start_time)

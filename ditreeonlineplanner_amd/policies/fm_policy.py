@@ -1,0 +1,119 @@
+"""DiffusionSampler facade (reference: policies/fm_policy.py:10-212) over the HIP engine.
+
+Same constructor and ``forward(obs_seq, prev_actions, goal, local_map) -> ndarray (B, pred_horizon,
+action_dim) float64``.  Conditioning vector, local-map scaling, K flow steps and the action
+un-normalisation all run on the GPU (ditree_cond_vector / ditree_denoise); only the tiny
+observation arrays cross PCIe.  Car configuration (``env_id`` containing "car",
+``policy='flow_matching'``, ``prediction_type='actions'``) -- the other branches of the reference
+class are outside this round's scope and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _lib
+from ..common.fm_utils import get_timesteps
+from ..ops import default_context
+
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+
+
+def load_metadata(env_id: str):
+    """``metadata/{env_id}.pt`` relative to the CWD (fm_policy.py:28-32) when it can be read with the
+    safe loader, else the packaged JSON copy of the same numbers; FileNotFoundError otherwise."""
+    path = f"metadata/{env_id}.pt"
+    if os.path.exists(path):
+        try:
+            import numpy.core.multiarray as _m
+            with torch.serialization.safe_globals([_m._reconstruct, np.ndarray, np.dtype, type(np.dtype("f8"))]):
+                md = torch.load(path, weights_only=True)
+            return {k: np.asarray(v, dtype=np.float64) for k, v in md.items()}
+        except Exception:
+            pass
+    js = os.path.join(_DATA, f"metadata_{env_id}.json")
+    if os.path.exists(js):
+        with open(js) as f:
+            return {k: np.asarray(v, dtype=np.float64) for k, v in json.load(f).items() if not k.startswith("_")}
+    raise FileNotFoundError(f"Metadata not found at {path}")
+
+
+class DiffusionSampler(nn.Module):
+    def __init__(self, noise_pred_net, noise_scheduler, env_id, policy, pred_horizon, action_dim,
+                 prediction_type="actions", obs_history=1, action_history=1, num_diffusion_iters=100,
+                 position_conditioned=False, goal_conditioned=True, local_map_conditioned=True, local_map_size=16,
+                 metadata=None, ctx=None, precision=_lib.PREC_BF16):
+        super().__init__()
+        if "car" not in env_id.lower() or policy != "flow_matching" or prediction_type != "actions":
+            raise NotImplementedError("this round covers carmaze + flow_matching + action prediction")
+        if obs_history != 1 or action_history != 1 or position_conditioned or not goal_conditioned:
+            raise NotImplementedError("car config: obs_history = action_history = 1, goal conditioned")
+        self.metadata = metadata if metadata is not None else load_metadata(env_id)
+        self.env_id, self.policy, self.prediction_type = env_id, policy, prediction_type
+        self.action_dim, self.pred_horizon = action_dim, pred_horizon
+        self.obs_history, self.action_history = obs_history, action_history
+        self.num_diffusion_iters = num_diffusion_iters
+        self.local_map_size = local_map_size
+        self.noise_pred_net = noise_pred_net
+        self.noise_scheduler = noise_scheduler
+        self._ctx = ctx
+        self.precision = precision
+        t0, dt = get_timesteps("exp", num_diffusion_iters, exp_scale=4.0)
+        self.t0, self.dt = t0.numpy().copy(), dt.numpy().copy()
+        self.norm = np.concatenate([self.metadata["Observations_mean"], self.metadata["Observations_std"],
+                                    self.metadata["Actions_mean"], self.metadata["Actions_std"]]).astype(np.float64)
+        self.device = "cuda"
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = default_context()
+        return self._ctx
+
+    def to(self, *a, **k):
+        return self
+
+    def ensure_bound(self, max_batch):
+        net = self.noise_pred_net
+        if getattr(net, "_ctx", None) is not self.ctx:
+            net.bind(self.ctx, precision=self.precision)
+        net.reserve(max_batch)
+
+    def forward(self, obs_seq, prev_actions, goal=None, local_map=None):
+        ctx = self.ctx
+        dev = ctx.device
+        obs_seq = np.asarray(obs_seq, dtype=np.float64)
+        if obs_seq.ndim == 1:
+            obs_seq = obs_seq[None]
+        if obs_seq.ndim == 2:
+            obs_seq = obs_seq[:, None]
+        B = obs_seq.shape[0]
+        state = torch.as_tensor(np.ascontiguousarray(obs_seq[:, -1, :]), device=dev)           # obs_history = 1
+        if prev_actions is not None:
+            pa = np.asarray(prev_actions, dtype=np.float64)
+            if pa.ndim == 2:
+                pa = pa[None]
+            if pa.shape[1] == 0:                                  # fm_policy.py:116-121 with an empty history
+                last = np.zeros((B, self.action_dim))
+            else:
+                last = np.broadcast_to(pa[:, -1, :], (B, self.action_dim))
+            has_prev = np.ones(B, dtype=np.uint8)
+        else:
+            last = np.zeros((B, self.action_dim))
+            has_prev = np.zeros(B, dtype=np.uint8)
+        g = np.broadcast_to(np.asarray(goal, dtype=np.float64).reshape(-1, 2), (B, 2))
+        cond = ctx.cond_vector(state, torch.as_tensor(np.ascontiguousarray(last), device=dev),
+                               torch.as_tensor(has_prev, device=dev),
+                               torch.as_tensor(np.ascontiguousarray(g), device=dev), self.local_map_size, self.norm)
+        lm = torch.as_tensor(local_map, dtype=torch.float32, device=dev)
+        if lm.dim() == 2:
+            lm = lm.unsqueeze(0)
+        lm = (lm * 2 - 1).contiguous()                             # fm_policy.py:152
+        noise = torch.randn((B, self.pred_horizon, self.action_dim), device=dev)     # :158-159
+        self.ensure_bound(B)
+        actions = ctx.denoise(noise, lm, cond, t0=self.t0, dt=self.dt, act_norm=self.norm[12:16], want_actions=True)
+        return actions.cpu().numpy()
