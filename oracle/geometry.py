@@ -103,7 +103,7 @@ def norm2(dx, dy):
     np.linalg.norm on 2e5 random vectors in the build container)."""
     dx = np.asarray(dx, dtype=np.float64)
     dy = np.asarray(dy, dtype=np.float64)
-    return np.sqrt(_fma(dy, dy, dx * dx).astype(np.float64))
+    return np.sqrt(np.asarray(_fma(dy, dy, dx * dx), dtype=np.float64))
 
 
 def goal_reached(state: np.ndarray, goal_xy: np.ndarray) -> np.ndarray:
