@@ -32,6 +32,7 @@ struct ConvGemmParams {
   const void* Res;    // residual, activation type
   int ldres, res_Lp, res_off;
   int out_f32;        // store f32 regardless of the activation type
+  int dbg;            // experiment switches (DITREE_GEMM_DBG): 1 = no staging in the loop, 2 = no MFMA
 };
 
 void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s);

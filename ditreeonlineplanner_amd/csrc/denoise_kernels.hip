@@ -19,6 +19,9 @@
 //  * epilogue fused in registers: bias, GroupNorm (two-pass statistics through LDS
 //    atomics; a tile always holds whole (sample, group) sets), Mish, FiLM scale/bias or
 //    residual add.
+#include <cstdlib>
+#include <type_traits>
+
 #include "denoise.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -56,118 +59,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return start + k;
 }
 
+// ---- shared epilogue: bias, GroupNorm + Mish (+ FiLM | + residual), store ------------------------
+// acc[mb][j][i] of lane (r5, h), wave (wm, wn) holds tile row wm*64 + mb*32 + (i&3) + 8*(i>>2) + 4*h,
+// tile channel wn*128 + 4*r5 + j.  `smem` must be free for reuse (callers barrier first).
 template <int PREC>
-__global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
-  constexpr int ES = (PREC == 0) ? 2 : 4;          // element bytes
-  constexpr int EK = 128 / ES;                     // elements of K per step
-  constexpr int EPS = 16 / ES;                     // elements per 16-B slot
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int r5 = lane & 31, h = lane >> 5;
-  const int wm = w >> 1, wn = w & 1;
-  const int ntn = (p.N + 255) >> 8;
-  const int ntm = (p.M + 255) >> 8;
-  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
-  const int tm = tile / ntn, tn = tile - tm * ntn;
-  const int K = p.taps * p.Cin;
-  const int nk = K / EK;
-  const int kpt = p.Cin / EK;                      // K-steps per tap
-
-  // ---- per-lane staging sources (byte offsets) ------------------------------------------
-  const char* Abase = (const char*)p.A;
-  const char* Wbase = (const char*)p.W;
-  long long aoff[4], boff[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int r = (w * 4 + q) * 8 + (lane >> 3);          // LDS row 0..255
-    const int sw = (r >> 1) & 7;
-    const int slot = (lane & 7) ^ sw;
-    int m = tm * 256 + r;
-    m = m < p.M ? m : p.M - 1;
-    const int b = m / p.L, l = m - b * p.L;
-    aoff[q] = (((long long)b * p.in_Lp + (long long)l * p.in_stride + p.in_off) * p.lda + slot * EPS) * ES;
-    // weight row permutation: LDS row rho = wn*128 + j*32 + rr  <->  channel wn*128 + 4*rr + j
-    const int c = (r & 128) + 4 * (r & 31) + ((r >> 5) & 3);
-    boff[q] = (((long long)(tn * 256 + c)) * K + slot * EPS) * ES;
-  }
-  auto stage = [&](int kt, int buf) {
-    const int tap = kt / kpt;
-    const long long akoff = ((long long)tap * p.lda + (long long)(kt - tap * kpt) * EK) * ES;
-    const long long bkoff = (long long)kt * EK * ES;
-    char* sbase = smem + buf * 65536;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(Abase + aoff[q] + akoff),
-                                       (LDS_AS void*)(sbase + (w * 4 + q) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(Wbase + boff[q] + bkoff),
-                                       (LDS_AS void*)(sbase + 32768 + (w * 4 + q) * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16_t acc[2][4];
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mb][j][i] = 0.0f;
-
-  const int swl = (r5 >> 1) & 7;
-  const int a_row_off = (wm * 64 + r5) * 128;               // + mb*32*128
-  const int b_row_off = 32768 + (wn * 128 + r5) * 128;      // + j*32*128
-
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-    const char* sb = smem + (kt & 1) * 65536;
-    if constexpr (PREC == 0) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int ps = (((ks << 1) | h) ^ swl) << 4;
-        bf16x8_t af[2], bfr[4];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-          af[mb] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(sb + a_row_off + mb * 4096 + ps));
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          bfr[j] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(sb + b_row_off + j * 4096 + ps));
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[j], acc[mb][j], 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int sl = 0; sl < 8; ++sl) {                       // 16-B slot = 4 floats = k 4*sl .. 4*sl+3
-        const int ps = (sl ^ swl) << 4;
-        f32x4_t af[2], bfr[4];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) af[mb] = *(const f32x4_t*)(sb + a_row_off + mb * 4096 + ps);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = *(const f32x4_t*)(sb + b_row_off + j * 4096 + ps);
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {                     // k pair (2*s2, 2*s2+1): lane half h takes k = 2*s2 + h
-#pragma unroll
-          for (int mb = 0; mb < 2; ++mb) {
-            const float a = h ? af[mb][2 * s2 + 1] : af[mb][2 * s2];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float bv = h ? bfr[j][2 * s2 + 1] : bfr[j][2 * s2];
-              acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[mb][j], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();                                            // all fragment reads done: LDS reusable
+__device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t (&acc)[2][4], char* smem, int tm, int tn,
+                                              int tid, int lane, int r5, int h, int wm, int wn) {
 
   // ---- epilogue ---------------------------------------------------------------------------
   const int c_l = wn * 128 + 4 * r5;                          // lane's 4 consecutive channels in the tile
@@ -318,18 +215,379 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
   }
 }
 
+template <int PREC, int DBG = 0>
+__global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
+  constexpr int ES = (PREC == 0) ? 2 : 4;          // element bytes
+  constexpr int EK = 128 / ES;                     // elements of K per step
+  constexpr int EPS = 16 / ES;                     // elements per 16-B slot
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r5 = lane & 31, h = lane >> 5;
+  const int wm = w >> 1, wn = w & 1;
+  const int ntn = (p.N + 255) >> 8;
+  const int ntm = (p.M + 255) >> 8;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int tm = tile / ntn, tn = tile - tm * ntn;
+  const int K = p.taps * p.Cin;
+  const int nk = K / EK;
+  const int kpt = p.Cin / EK;                      // K-steps per tap
+
+  // ---- per-lane staging sources (byte offsets) ------------------------------------------
+  const char* Abase = (const char*)p.A;
+  const char* Wbase = (const char*)p.W;
+  long long aoff[4], boff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = (w * 4 + q) * 8 + (lane >> 3);          // LDS row 0..255
+    const int sw = (r >> 1) & 7;
+    const int slot = (lane & 7) ^ sw;
+    int m = tm * 256 + r;
+    m = m < p.M ? m : p.M - 1;
+    const int b = m / p.L, l = m - b * p.L;
+    aoff[q] = (((long long)b * p.in_Lp + (long long)l * p.in_stride + p.in_off) * p.lda + slot * EPS) * ES;
+    // weight row permutation: LDS row rho = wn*128 + j*32 + rr  <->  channel wn*128 + 4*rr + j
+    const int c = (r & 128) + 4 * (r & 31) + ((r >> 5) & 3);
+    boff[q] = (((long long)(tn * 256 + c)) * K + slot * EPS) * ES;
+  }
+  // running per-lane source pointers of the K-step being staged; advanced by a wave-uniform
+  // increment per K-step (128 B inside a tap, a row jump at a tap boundary)
+  const char* pa[4];
+  const char* pb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    pa[q] = Abase + aoff[q];
+    pb[q] = Wbase + boff[q];
+  }
+  int kin = 0;                                       // K-step index inside the current tap
+  const long long a_tap_jump = ((long long)p.lda - (long long)p.Cin + EK) * ES;
+  auto advance = [&]() {
+    ++kin;
+    long long ainc = 128;
+    if (kin == kpt) { kin = 0; ainc = a_tap_jump; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      pa[q] += ainc;
+      pb[q] += 128;
+    }
+  };
+  // one 1-KiB piece (q = 0..3: activations, 4..7: weights) into the LDS stage at `sbase`
+  auto stage_piece = [&](int q, char* sbase) {
+    if (q < 4)
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)pa[q], (LDS_AS void*)(sbase + (w * 4 + q) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)pb[q - 4],
+                                       (LDS_AS void*)(sbase + 32768 + (w * 4 + q - 4) * 1024), 16, 0, 0);
+  };
+
+  f32x16_t acc[2][4];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][j][i] = 0.0f;
+
+  const int swl = (r5 >> 1) & 7;
+  const int a_row_off = (wm * 64 + r5) * 128;               // + mb*32*128
+  const int b_row_off = 32768 + (wn * 128 + r5) * 128;      // + j*32*128
+
+  // K-step body.  STAGE: also issue the 8 LDS-DMA pieces of K-step kt+1, two per 16-wide
+  // sub-step, interleaved with the MFMAs (an LDS-DMA issue costs the wave 60+ cycles; behind
+  // an MFMA it is hidden, in front of the first ds_read it is not).
+  auto kstep = [&](const char* sb, auto stage_tag, char* snext) {
+    constexpr bool STAGE = decltype(stage_tag)::value;
+    if constexpr (PREC == 0) {
+      bf16x8_t af[2][2], bfr[2][4];
+      auto rd = [&](int ks, int slot) {
+        const int ps = (((ks << 1) | h) ^ swl) << 4;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+          af[slot][mb] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(sb + a_row_off + mb * 4096 + ps));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          bfr[slot][j] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(sb + b_row_off + j * 4096 + ps));
+      };
+      rd(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) rd(ks + 1, (ks + 1) & 1);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][mb], bfr[ks & 1][j], acc[mb][j], 0, 0, 0);
+          if constexpr (STAGE) stage_piece(ks * 2 + mb, snext);
+        }
+      }
+      // pin the interleave: reads of the next sub-step first, then 4 MFMA : 1 LDS-DMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          if constexpr (STAGE) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) {                       // 16-B slot = 4 floats = k 4*sl .. 4*sl+3
+        const int ps = (sl ^ swl) << 4;
+        f32x4_t af[2], bfr[4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) af[mb] = *(const f32x4_t*)(sb + a_row_off + mb * 4096 + ps);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const f32x4_t*)(sb + b_row_off + j * 4096 + ps);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {                     // k pair (2*s2, 2*s2+1): lane half h takes k = 2*s2 + h
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) {
+            const float a = h ? af[mb][2 * s2 + 1] : af[mb][2 * s2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float bv = h ? bfr[j][2 * s2 + 1] : bfr[j][2 * s2];
+              acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[mb][j], 0, 0, 0);
+            }
+          }
+        }
+        if constexpr (STAGE) stage_piece(sl, snext);
+      }
+    }
+  };
+
+#pragma unroll
+  for (int q = 0; q < 8; ++q) stage_piece(q, smem);
+  advance();
+  for (int kt = 0; kt < nk - 1; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (DBG == 1) kstep(smem + (kt & 1) * 65536, std::false_type{}, nullptr);
+    else if constexpr (DBG == 2) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) stage_piece(q, smem + ((kt + 1) & 1) * 65536);
+    } else kstep(smem + (kt & 1) * 65536, std::true_type{}, smem + ((kt + 1) & 1) * 65536);
+    advance();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  kstep(smem + ((nk - 1) & 1) * 65536, std::false_type{}, nullptr);
+  __syncthreads();                                            // all fragment reads done: LDS reusable
+  gemm_epilogue<PREC>(p, acc, smem, tm, tn, tid, lane, r5, h, wm, wn);
+}
+
+// =================================================================================================
+// conv3_halo_kernel: Conv1d(k = 3, stride 1, pad 1) on padded channels-last bf16 activations.
+//
+// Same tile / wave / epilogue geometry as conv_gemm_kernel, different K loop: K is walked
+// channel-chunk major, tap minor.  For one 64-channel chunk the activation block of the tile --
+// (256/L) samples x (L+2) padded rows, i.e. the 256 output rows plus their halos -- is staged
+// into LDS ONCE and serves all three taps (the tap only shifts the fragment row), so every
+// activation byte crosses L2->LDS once per tile instead of three times; only the weights are
+// re-staged per tap.  Per chunk: 36 KB (A) + 96 KB (W) instead of 192 KB.
+//   LDS: A[2] x 40 KB (40 one-KiB pieces, 5 per wave, rows beyond the block clamp) + W[2] x 32 KB.
+//   Pipeline: fragments are read one 16-wide sub-step ahead, also across K-steps; the single
+//   barrier of a K-step sits between its third and fourth MFMA group, where 8 MFMAs are queued;
+//   W(s+2) is issued right after the barrier of step s, A(c+2) after the last barrier of chunk c,
+//   waited with a counted vmcnt (activations stay in flight for three K-steps).
+// =================================================================================================
+__global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int A_BUF = 40960, W_BUF = 32768, W_BASE = 2 * A_BUF;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r5 = lane & 31, h = lane >> 5;
+  const int wm = w >> 1, wn = w & 1;
+  const int ntn = (p.N + 255) >> 8;
+  const int ntm = (p.M + 255) >> 8;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int tm = tile / ntn, tn = tile - tm * ntn;
+  const int L = p.L, Lp = p.in_Lp, S = 256 / L;
+  const int a_rows = S * Lp;
+  const int nc = p.Cin >> 6;
+  const long long K = 3LL * p.Cin;
+
+  // ---- staging sources: wave-uniform base + 32-bit per-lane byte offsets ---------------------------
+  unsigned pa[5], pb[4];
+  const char* const a_base = (const char*)p.A + ((long long)tm * S * Lp + p.in_off) * p.lda * 2;
+  const char* const w_base = (const char*)p.W + ((long long)tn * 256) * K * 2;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int r = (w + 8 * i) * 8 + (lane >> 3);                     // LDS row of the A block
+    const int rs = r < a_rows ? r : a_rows - 1;
+    const int slot = (lane & 7) ^ ((r >> 1) & 7);
+    pa[i] = (unsigned)((rs * p.lda + slot * 8) * 2);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = (w * 4 + q) * 8 + (lane >> 3);
+    const int slot = (lane & 7) ^ ((r >> 1) & 7);
+    const int c = (r & 128) + 4 * (r & 31) + ((r >> 5) & 3);
+    pb[q] = (unsigned)(((long long)c * K + slot * 8) * 2);
+  }
+  const long long w_tap = (long long)p.Cin * 2;                      // bytes between taps in a weight row
+  auto issue_a = [&](int c, int i) {                                 // piece i of chunk c
+    const char* sbase = a_base + (long long)c * 128;
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(sbase + pa[i]),
+                                     (LDS_AS void*)(smem + (c & 1) * A_BUF + (w + 8 * i) * 1024), 16, 0, 0);
+  };
+  auto issue_w = [&](int c, int t, int q) {                          // piece q of step (c, t)
+    const char* sbase = w_base + (long long)c * 128 + t * w_tap;
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(sbase + pb[q]),
+                                     (LDS_AS void*)(smem + W_BASE + ((c + t) & 1) * W_BUF + (w * 4 + q) * 1024), 16, 0, 0);
+  };
+
+  // ---- fragment addressing ---------------------------------------------------------------------
+  int lrow[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int ml = wm * 64 + mb * 32 + r5;
+    const int sb = ml / L;
+    lrow[mb] = sb * Lp + (ml - sb * L);                              // + tap
+  }
+  const int swl = (r5 >> 1) & 7;
+  const int b_row_off = (wn * 128 + r5) * 128;
+
+  f32x16_t acc[2][4];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][j][i] = 0.0f;
+
+  bf16x8_t af[2][2], bfr[2][4];
+  auto rd = [&](int set, int c, int t, int ks) {
+    const char* ab = smem + (c & 1) * A_BUF;
+    const char* wb = smem + W_BASE + ((c + t) & 1) * W_BUF;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int row = lrow[mb] + t;
+      const int ps = (((ks << 1) | h) ^ ((row >> 1) & 7)) << 4;
+      af[set][mb] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(ab + row * 128 + ps));
+    }
+    const int psb = (((ks << 1) | h) ^ swl) << 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bfr[set][j] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(wb + b_row_off + j * 4096 + psb));
+  };
+  auto mm = [&](int set, int mb, int j) {
+    acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][mb], bfr[set][j], acc[mb][j], 0, 0, 0);
+  };
+  auto mm8 = [&](int set) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mm(set, mb, j);
+  };
+
+  // One K-step (chunk c, tap T).  HAS_NEXT: another step follows (barrier + read-ahead);
+  // ISSUE_W: stage W of step s+2; ISSUE_A: stage A of chunk c+2; VM: LDS-DMA pieces that may
+  // stay in flight across this step's barrier (the A pieces issued after the W pieces it waits for).
+  auto step = [&](auto tT, auto tNext, auto tIW, auto tIA, auto tVM, int c) {
+    constexpr int T = decltype(tT)::value;
+    constexpr bool HAS_NEXT = decltype(tNext)::value, ISSUE_W = decltype(tIW)::value, ISSUE_A = decltype(tIA)::value;
+    constexpr int VM = decltype(tVM)::value;
+    // keep the fragment-address arithmetic inside the step (hoisted out of the chunk loop it
+    // costs ~30 VGPRs of precomputed addresses and spills)
+    asm volatile("" : "+v"(lrow[0]), "+v"(lrow[1]));
+    rd(1, c, T, 1);
+    mm8(0);
+    rd(0, c, T, 2);
+    mm8(1);
+    rd(1, c, T, 3);
+    mm8(0);
+    if constexpr (HAS_NEXT) {
+      // this wave's reads of W(s) / A(c) are complete, the DMA of step s+1 has landed
+      if constexpr (VM == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      constexpr int T1 = (T + 1) % 3;
+      rd(0, c + (T + 1) / 3, T1, 0);
+    }
+    constexpr int T2 = (T + 2) % 3;
+    const int c2 = c + (T + 2) / 3;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        mm(1, mb, j);
+        const int i = mb * 4 + j;
+        if constexpr (ISSUE_W) { if (i < 4) issue_w(c2, T2, i); }
+        if constexpr (ISSUE_A) { if (i >= 3) issue_a(c + 2, i - 3); }
+      }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I5 = std::integral_constant<int, 5>;
+  using Tt = std::true_type;
+  using Ff = std::false_type;
+
+  // ---- prologue: A(0), W(0,0) -> visible; then W(0,1) and A(1) in flight ----------------------------
+#pragma unroll
+  for (int i = 0; i < 5; ++i) issue_a(0, i);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue_w(0, 0, q);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue_w(0, 1, q);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) issue_a(1, i);
+  rd(0, 0, 0, 0);
+
+  for (int c = 0; c < nc - 2; ++c) {
+    step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, c);          // waits W(c,1); A(c+1) may stay in flight
+    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, c);
+    step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, c);          // stages W(c+1,1) then A(c+2)
+  }
+  {
+    const int c = nc - 2;                           // last chunk but one: no A left to stage
+    step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, c);
+    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, c);
+    step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, c);
+  }
+  {
+    const int c = nc - 1;                           // last chunk
+    step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, c);
+    step(I1{}, Tt{}, Ff{}, Ff{}, I0{}, c);
+    step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, c);
+  }
+  __syncthreads();
+  gemm_epilogue<0>(p, acc, smem, tm, tn, tid, lane, r5, h, wm, wn);
+}
+
 void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s) {
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("DITREE_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
   const int ntn = (p.N + 255) >> 8, ntm = (p.M + 255) >> 8;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)conv_gemm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    hipFuncSetAttribute((const void*)conv_gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipFuncSetAttribute((const void*)conv_gemm_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipFuncSetAttribute((const void*)conv_gemm_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipFuncSetAttribute((const void*)conv_gemm_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipFuncSetAttribute((const void*)conv_gemm_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     attr_set = true;
   }
-  if (prec == 0)
-    hipLaunchKernelGGL(conv_gemm_kernel<0>, dim3(ntm * ntn), dim3(512), 131072, s, p);
-  else
-    hipLaunchKernelGGL(conv_gemm_kernel<1>, dim3(ntm * ntn), dim3(512), 131072, s, p);
+  const dim3 grid(ntm * ntn), block(512);
+  static int halo = -1;
+  if (halo < 0) { const char* e = getenv("DITREE_NO_HALO"); halo = (e && atoi(e)) ? 0 : 1; }
+  const bool halo_ok = prec == 0 && halo && dbg == 0 && p.taps == 3 && p.in_stride == 1 && p.in_Lp == p.L + 2 &&
+                       (256 % p.L) == 0 && p.L >= 16 && (p.M & 255) == 0 && (p.Cin & 63) == 0 && p.Cin >= 192;
+  if (halo_ok) {
+    static bool attr2 = false;
+    if (!attr2) {
+      hipFuncSetAttribute((const void*)conv3_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+      attr2 = true;
+    }
+    hipLaunchKernelGGL(conv3_halo_kernel, grid, block, 147456, s, p);
+    return;
+  }
+  if (prec == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 0>), grid, block, 131072, s, p);
+  else if (dbg == 1) hipLaunchKernelGGL((conv_gemm_kernel<0, 1>), grid, block, 131072, s, p);
+  else if (dbg == 2) hipLaunchKernelGGL((conv_gemm_kernel<0, 2>), grid, block, 131072, s, p);
+  else hipLaunchKernelGGL((conv_gemm_kernel<0, 0>), grid, block, 131072, s, p);
 }
 
 // ============================================================================= small kernels
