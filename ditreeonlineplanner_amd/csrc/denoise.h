@@ -43,7 +43,11 @@ void launch_prep_cond(const float* temb, const float* map_emb, int E, const floa
                       int Kpad, int prec, hipStream_t s);
 void launch_final_proj_flow(const void* Y, int C, int Lp, const float* W, const float* bias, int D, float* x, float dt,
                             const double* act_norm, double* actions, int B, int P, int prec, hipStream_t s);
-void launch_im2col2d(const void* in, bool src_f32, void* out, int B, int H, int W, int C, int KH, int KW, int stride,
+struct TapList {          // live (kh, kw) taps of a Conv2d on a small map
+  int n;
+  signed char kh[49], kw[49];
+};
+void launch_im2col2d(const void* in, bool src_f32, void* out, int B, int H, int W, int C, const TapList& taps, int stride,
                      int pad, int OH, int OW, int Kpad, int prec, hipStream_t s);
 void launch_gn2d(const float* in, const float* gamma, const float* beta, const void* res, int relu, void* out, int B,
                  int HW, int C, float eps, int prec, hipStream_t s);

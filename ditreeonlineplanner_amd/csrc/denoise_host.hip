@@ -60,6 +60,7 @@ struct DenoiserState {
   std::function<void(int, int, hipStream_t)> film_op;
   float* x_cur = nullptr;        // (Bmax, P, D) f32
   float* temb = nullptr;         // (256,) f32
+  float temb_t = -1.0f;          // timestep the cached embedding was computed for (< 0: none)
   float* map_emb = nullptr;      // (Bmax, E) f32
   float* film = nullptr;         // (Bp, film_cols) f32
   void* condA = nullptr;         // (Bp, condK)
@@ -121,6 +122,7 @@ struct DenoiserState {
     film_op = nullptr;
     prec = -1;
     Bmax = 0;
+    temb_t = -1.0f;
   }
 
   float* upload_f32(const std::string& key, const float* src, int64_t n) {
@@ -444,22 +446,37 @@ void DenoiserState::build(int prec_, int Bmax_) {
       return a;
     };
     // conv -> f32 GEMM output in `gout`
+    auto live_taps = [](int k, int stride, int pad, int H, int OH) {
+      TapList tl{};
+      for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw) {
+          bool lh = false, lw = false;
+          for (int o = 0; o < OH; ++o) {
+            const int ih = o * stride + kh - pad, iw = o * stride + kw - pad;
+            lh |= (ih >= 0 && ih < H);
+            lw |= (iw >= 0 && iw < H);
+          }
+          if (lh && lw) { tl.kh[tl.n] = (signed char)kh; tl.kw[tl.n] = (signed char)kw; ++tl.n; }
+        }
+      return tl;
+    };
     auto conv2d = [&](const std::string& wname, const void* in, bool in_f32, int H, int W, int Cin, int Cout, int k,
                       int stride, int pad, int OH, int OW, bool fold_in) {
       const HostParam& w = P_(wname + ".weight");
       const float* wd = w.data;
       const int Cw = (int)w.dims[1];
-      const int K = k * k * Cin, Kpad = (K + 63) / 64 * 64;
+      const TapList tl = live_taps(k, stride, pad, H, OH);
+      const int K = tl.n * Cin, Kpad = (K + 63) / 64 * 64;
       void* wp = pack(wname, Cout, 1, Kpad, [=](int n, int, int kk) {
         if (kk >= K) return 0.0f;
-        const int c = kk % Cin, t = kk / Cin, kw = t % k, kh = t / k;
+        const int c = kk % Cin, t = kk / Cin, kw = tl.kw[t], kh = tl.kh[t];
         if (!fold_in) return wd[(((size_t)n * Cw + c) * k + kh) * k + kw];
         float s = 0.f;                                       // x.repeat(1,3,1,1): identical channels fold into one
         for (int cc = 0; cc < Cw; ++cc) s += wd[(((size_t)n * Cw + cc) * k + kh) * k + kw];
         return s;
       });
       enc_ops.push_back([=, this](int B, int, hipStream_t s) {
-        launch_im2col2d(in, in_f32, col, B, H, W, Cin, k, k, stride, pad, OH, OW, Kpad, pr, s);
+        launch_im2col2d(in, in_f32, col, B, H, W, Cin, tl, stride, pad, OH, OW, Kpad, pr, s);
         ConvGemmParams p{};
         const int M = B * OH * OW;
         p.A = col; p.lda = Kpad; p.in_Lp = M; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = Kpad;
@@ -494,9 +511,11 @@ void DenoiserState::build(int prec_, int Bmax_) {
         return s;
       });
       const int HH = H0, OO = H1;
+      const TapList stem_taps = live_taps(7, 2, 3, H0, H1);
+      if (stem_taps.n != 49) throw std::runtime_error("stem conv expects all 49 taps live");
       const float** lm_slot = &lm_ptr;
       enc_ops.push_back([=, this](int B, int, hipStream_t s) {
-        launch_im2col2d(*lm_slot, true, col, B, HH, HH, 1, 7, 7, 2, 3, OO, OO, 64, pr, s);
+        launch_im2col2d(*lm_slot, true, col, B, HH, HH, 1, stem_taps, 2, 3, OO, OO, 64, pr, s);
         ConvGemmParams p{};
         const int M = B * OO * OO;
         p.A = col; p.lda = 64; p.in_Lp = M; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = 64;
@@ -614,9 +633,12 @@ int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const
   for (auto& op : st->enc_ops) op(B, Bp, s);
   for (int k = 0; k < K; ++k) {
     const float t = t0[k] * 20.0f;                                      // pos_emb_scale, fm_policy.py:187
-    launch_time_embed(t, st->dev_f["unet.diffusion_step_encoder.1.weight"], st->dev_f["unet.diffusion_step_encoder.1.bias"],
-                      st->dev_f["unet.diffusion_step_encoder.3.weight"], st->dev_f["unet.diffusion_step_encoder.3.bias"],
-                      st->temb, s);
+    if (t != st->temb_t) {                                              // batch-invariant: K = 1 computes it once
+      launch_time_embed(t, st->dev_f["unet.diffusion_step_encoder.1.weight"], st->dev_f["unet.diffusion_step_encoder.1.bias"],
+                        st->dev_f["unet.diffusion_step_encoder.3.weight"], st->dev_f["unet.diffusion_step_encoder.3.bias"],
+                        st->temb, s);
+      st->temb_t = K == 1 ? t : -1.0f;                                  // several steps share one buffer: recompute
+    }
     launch_prep_cond(st->temb, st->map_emb, st->E, cond, st->G, st->condA, B, st->condK, pr, s);
     st->film_op(B, Bp, s);
     launch_prep_sample(st->x_cur, st->named["a0"].p, Bp, st->P, st->D, pr, s);

@@ -308,28 +308,19 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
         for (int j = 0; j < 4; ++j)
           bfr[slot][j] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(sb + b_row_off + j * 4096 + ps));
       };
+      if constexpr (STAGE) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) stage_piece(q, snext);
+      }
       rd(0, 0);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (ks < 3) rd(ks + 1, (ks + 1) & 1);
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][mb], bfr[ks & 1][j], acc[mb][j], 0, 0, 0);
-          if constexpr (STAGE) stage_piece(ks * 2 + mb, snext);
-        }
-      }
-      // pin the interleave: reads of the next sub-step first, then 4 MFMA : 1 LDS-DMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-          if constexpr (STAGE) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
       }
     } else {
 #pragma unroll
@@ -731,19 +722,21 @@ void launch_final_proj_flow(const void* Y, int C, int Lp, const float* W, const 
 }
 
 // ------------------------------------------------------------------------------- encoder helpers
-// im2col for Conv2d on NHWC activations: out row (b, oh, ow), column (kh*KW + kw)*C + c, zero
-// padded to Kpad.  SRC_F32: the source is the f32 local map (B, H, W) with C = 1.
+// im2col for Conv2d on NHWC activations: out row (b, oh, ow), column tap*C + c over the LIVE taps only
+// (a tap that falls into the zero padding for every output position is dropped from both the
+// columns and the packed weights -- exact, e.g. 3x3 convs on 1x1 maps keep the centre tap only),
+// zero padded to Kpad.  SRC_F32: the source is the f32 local map (B, H, W) with C = 1.
 template <int PREC, bool SRC_F32>
 __global__ void im2col2d_kernel(const void* __restrict__ in, void* __restrict__ out, int B, int H, int W, int C,
-                                int KH, int KW, int stride, int pad, int OH, int OW, int Kpad) {
+                                TapList taps, int stride, int pad, int OH, int OW, int Kpad) {
   const long long row = blockIdx.x;
   const int ow = (int)(row % OW), oh = (int)((row / OW) % OH), b = (int)(row / ((long long)OW * OH));
-  const int K = KH * KW * C;
+  const int K = taps.n * C;
   for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
     float v = 0.f;
     if (k < K) {
-      const int c = k % C, kk = k / C, kw = kk % KW, kh = kk / KW;
-      const int ih = oh * stride + kh - pad, iw = ow * stride + kw - pad;
+      const int c = k % C, kk = k / C;
+      const int ih = oh * stride + taps.kh[kk] - pad, iw = ow * stride + taps.kw[kk] - pad;
       if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
         const long long idx = (((long long)b * H + ih) * W + iw) * C + c;
         v = SRC_F32 ? ((const float*)in)[idx] : load_elem<PREC>(in, idx);
@@ -752,15 +745,15 @@ __global__ void im2col2d_kernel(const void* __restrict__ in, void* __restrict__ 
     store_elem<PREC>(out, row * Kpad + k, v);
   }
 }
-void launch_im2col2d(const void* in, bool src_f32, void* out, int B, int H, int W, int C, int KH, int KW, int stride,
+void launch_im2col2d(const void* in, bool src_f32, void* out, int B, int H, int W, int C, const TapList& taps, int stride,
                      int pad, int OH, int OW, int Kpad, int prec, hipStream_t s) {
   dim3 grid((unsigned)((long long)B * OH * OW)), block(Kpad >= 256 ? 256 : 64);
   if (prec == 0) {
-    if (src_f32) hipLaunchKernelGGL((im2col2d_kernel<0, true>), grid, block, 0, s, in, out, B, H, W, C, KH, KW, stride, pad, OH, OW, Kpad);
-    else hipLaunchKernelGGL((im2col2d_kernel<0, false>), grid, block, 0, s, in, out, B, H, W, C, KH, KW, stride, pad, OH, OW, Kpad);
+    if (src_f32) hipLaunchKernelGGL((im2col2d_kernel<0, true>), grid, block, 0, s, in, out, B, H, W, C, taps, stride, pad, OH, OW, Kpad);
+    else hipLaunchKernelGGL((im2col2d_kernel<0, false>), grid, block, 0, s, in, out, B, H, W, C, taps, stride, pad, OH, OW, Kpad);
   } else {
-    if (src_f32) hipLaunchKernelGGL((im2col2d_kernel<1, true>), grid, block, 0, s, in, out, B, H, W, C, KH, KW, stride, pad, OH, OW, Kpad);
-    else hipLaunchKernelGGL((im2col2d_kernel<1, false>), grid, block, 0, s, in, out, B, H, W, C, KH, KW, stride, pad, OH, OW, Kpad);
+    if (src_f32) hipLaunchKernelGGL((im2col2d_kernel<1, true>), grid, block, 0, s, in, out, B, H, W, C, taps, stride, pad, OH, OW, Kpad);
+    else hipLaunchKernelGGL((im2col2d_kernel<1, false>), grid, block, 0, s, in, out, B, H, W, C, taps, stride, pad, OH, OW, Kpad);
   }
 }
 
