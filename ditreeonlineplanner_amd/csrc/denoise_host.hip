@@ -56,7 +56,13 @@ struct DenoiserState {
   std::map<std::string, Act> named;
   std::map<std::string, void*> dev_w;       // packed GEMM weights by name
   std::map<std::string, float*> dev_f;      // f32 vectors (bias, gamma, beta, small matrices)
-  std::vector<std::function<void(int, int, hipStream_t)>> enc_ops, unet_ops;   // (B, Bp, stream)
+  std::vector<std::function<void(int, int, hipStream_t)>> unet_ops;            // (B, Bp, stream)
+  std::vector<std::function<void(int, int, int, hipStream_t)>> enc_ops;        // (b0, Bn, scratch region, stream)
+  static constexpr int ENC_SUBS = 4;     // encoder sub-batches that may run concurrently
+  int sub_cap = 0;
+  size_t col_region = 0, gout_region = 0;
+  hipStream_t aux[ENC_SUBS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[ENC_SUBS] = {nullptr, nullptr, nullptr, nullptr};
   std::function<void(int, int, hipStream_t)> film_op;
   float* x_cur = nullptr;        // (Bmax, P, D) f32
   float* temb = nullptr;         // (256,) f32
@@ -73,6 +79,13 @@ struct DenoiserState {
   size_t prof_used = 0;
   double prof_ms_done = 0.0;
   int64_t prof_launches_done = 0;
+  // Profiling brackets every GEMM launch with events on its stream.  Back-to-back GEMM launches on
+  // one stream share an event (the end of one is the start of the next), which halves the marker
+  // packets; `prof_chain` is broken by note_other() whenever another kernel is enqueued in between.
+  hipStream_t prof_last_stream = nullptr;
+  bool prof_chain = false;
+  std::vector<std::pair<size_t, size_t>> prof_pairs;          // (start event, end event) per launch
+  void note_other() { prof_chain = false; }
   void run_gemm(const ConvGemmParams& p, hipStream_t s) {
     if (!prof_on) { launch_conv_gemm(p, prec, s); return; }
     if (prof_used + 2 > prof_ev.size()) {
@@ -80,20 +93,31 @@ struct DenoiserState {
       prof_ev.resize(old + 4096);
       for (size_t i = old; i < prof_ev.size(); ++i) hipEventCreate(&prof_ev[i]);
     }
-    hipEventRecord(prof_ev[prof_used], s);
+    size_t start;
+    if (prof_chain && prof_last_stream == s && prof_used > 0) {
+      start = prof_used - 1;
+    } else {
+      start = prof_used++;
+      hipEventRecord(prof_ev[start], s);
+    }
     launch_conv_gemm(p, prec, s);
-    hipEventRecord(prof_ev[prof_used + 1], s);
-    prof_used += 2;
+    const size_t end = prof_used++;
+    hipEventRecord(prof_ev[end], s);
+    prof_pairs.emplace_back(start, end);
+    prof_chain = true;
+    prof_last_stream = s;
   }
   void prof_collect() {
     if (prof_used == 0) return;
-    hipEventSynchronize(prof_ev[prof_used - 1]);
-    for (size_t i = 0; i + 1 < prof_used; i += 2) {
+    hipDeviceSynchronize();                                  // events live on several streams
+    for (auto& pr : prof_pairs) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, prof_ev[i], prof_ev[i + 1]) == hipSuccess) prof_ms_done += ms;
+      if (hipEventElapsedTime(&ms, prof_ev[pr.first], prof_ev[pr.second]) == hipSuccess) prof_ms_done += ms;
       ++prof_launches_done;
     }
+    prof_pairs.clear();
     prof_used = 0;
+    prof_chain = false;
   }
   int es() const { return prec == 0 ? 2 : 4; }
 
@@ -432,12 +456,22 @@ void DenoiserState::build(int prec_, int Bmax_) {
   vec("unet.diffusion_step_encoder.3.bias");
 
   // ---------------- encoder: ResNet-18 with GroupNorm(C/16), NHWC, im2col + GEMM + GN kernels ------------
+  // Every op works on a sub-batch [b0, b0 + Bn) with its own im2col / GEMM-output scratch region, so that
+  // several sub-batches can run concurrently on different streams (the layers are small: 8..100 tiles
+  // each, far fewer than the 256 CUs).
   {
     const std::string R = "encoder.resnet18.";
     const int pr = prec;
-    const size_t col_elems = (size_t)Bmax * 25 * 576 > (size_t)Bmax * 100 * 64 ? (size_t)Bmax * 25 * 576 : (size_t)Bmax * 100 * 64;
-    void* col = dalloc(std::max(col_elems, (size_t)Bmax * 4608) * es());
-    float* gout = (float*)dalloc((size_t)Bmax * 100 * 64 * 4 > (size_t)Bmax * 512 * 4 ? (size_t)Bmax * 100 * 64 * 4 : (size_t)Bmax * 512 * 4);
+    const size_t E_ = es();
+    sub_cap = (Bmax + ENC_SUBS - 1) / ENC_SUBS;
+    sub_cap = (sub_cap + 15) / 16 * 16;
+    const size_t col_per_sample = 25 * 576;                         // largest im2col footprint per sample (layer1)
+    const size_t gout_per_sample = 100 * 64;                        // largest f32 GEMM output per sample (stem)
+    col_region = (size_t)sub_cap * col_per_sample;
+    gout_region = (size_t)sub_cap * gout_per_sample;
+    char* col = (char*)dalloc(col_region * ENC_SUBS * E_);
+    float* gout = (float*)dalloc(gout_region * ENC_SUBS * 4);
+    const size_t colreg = col_region, goutreg = gout_region;
     auto ebuf = [&](const std::string& name, int HW, int C) {
       Act a;
       a.L = HW; a.C = C; a.ld = C; a.coff = 0; a.padded = false;
@@ -445,7 +479,6 @@ void DenoiserState::build(int prec_, int Bmax_) {
       named[name] = a;
       return a;
     };
-    // conv -> f32 GEMM output in `gout`
     auto live_taps = [](int k, int stride, int pad, int H, int OH) {
       TapList tl{};
       for (int kh = 0; kh < k; ++kh)
@@ -460,13 +493,17 @@ void DenoiserState::build(int prec_, int Bmax_) {
         }
       return tl;
     };
-    auto conv2d = [&](const std::string& wname, const void* in, bool in_f32, int H, int W, int Cin, int Cout, int k,
-                      int stride, int pad, int OH, int OW, bool fold_in) {
+    // conv (+ optional folding of the 3 identical input channels) -> f32 GEMM output in the region's `gout`.
+    // in == nullptr: the source is the caller's f32 local map (lm_ptr), C = 1.
+    auto conv2d = [&](const std::string& wname, const void* in, int H, int Cin, int Cout, int k, int stride, int pad,
+                      int OH, bool fold_in) {
       const HostParam& w = P_(wname + ".weight");
       const float* wd = w.data;
       const int Cw = (int)w.dims[1];
       const TapList tl = live_taps(k, stride, pad, H, OH);
       const int K = tl.n * Cin, Kpad = (K + 63) / 64 * 64;
+      if ((size_t)OH * OH * Kpad > col_per_sample || (size_t)OH * OH * Cout > gout_per_sample)
+        throw std::runtime_error("encoder scratch region too small for " + wname);
       void* wp = pack(wname, Cout, 1, Kpad, [=](int n, int, int kk) {
         if (kk >= K) return 0.0f;
         const int c = kk % Cin, t = kk / Cin, kw = tl.kw[t], kh = tl.kh[t];
@@ -475,12 +512,19 @@ void DenoiserState::build(int prec_, int Bmax_) {
         for (int cc = 0; cc < Cw; ++cc) s += wd[(((size_t)n * Cw + cc) * k + kh) * k + kw];
         return s;
       });
-      enc_ops.push_back([=, this](int B, int, hipStream_t s) {
-        launch_im2col2d(in, in_f32, col, B, H, W, Cin, tl, stride, pad, OH, OW, Kpad, pr, s);
+      const float** lm_slot = &lm_ptr;
+      enc_ops.push_back([=, this](int b0, int Bn, int reg, hipStream_t s) {
+        char* colr = col + (size_t)reg * colreg * E_;
+        float* goutr = gout + (size_t)reg * goutreg;
+        if (in == nullptr)
+          launch_im2col2d(*lm_slot + (size_t)b0 * H * H, true, colr, Bn, H, H, 1, tl, stride, pad, OH, OH, Kpad, pr, s);
+        else
+          launch_im2col2d((const char*)in + (size_t)b0 * H * H * Cin * E_, false, colr, Bn, H, H, Cin, tl, stride, pad,
+                          OH, OH, Kpad, pr, s);
         ConvGemmParams p{};
-        const int M = B * OH * OW;
-        p.A = col; p.lda = Kpad; p.in_Lp = M; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = Kpad;
-        p.W = wp; p.Out = gout; p.ldc = Cout; p.out_Lp = M; p.out_stride = 1; p.out_off = 0;
+        const int M = Bn * OH * OH;
+        p.A = colr; p.lda = Kpad; p.in_Lp = M; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = Kpad;
+        p.W = wp; p.Out = goutr; p.ldc = Cout; p.out_Lp = M; p.out_stride = 1; p.out_off = 0;
         p.L = M; p.M = M; p.N = Cout; p.mode = MODE_BIAS; p.out_f32 = 1;
         run_gemm(p, s);
       });
@@ -488,48 +532,29 @@ void DenoiserState::build(int prec_, int Bmax_) {
     auto gn = [&](const std::string& gname, const Act& out, const Act* res, bool relu) {
       float* ga = vec(gname + ".weight");
       float* be = vec(gname + ".bias");
-      const void* rp = res ? res->p : nullptr;
-      void* op = out.p;
+      const char* rp = res ? (const char*)res->p : nullptr;
+      char* op = (char*)out.p;
       const int HW = out.L, C = out.C;
-      enc_ops.push_back([=](int B, int, hipStream_t s) { launch_gn2d(gout, ga, be, rp, relu ? 1 : 0, op, B, HW, C, 1e-5f, pr, s); });
+      enc_ops.push_back([=](int b0, int Bn, int reg, hipStream_t s) {
+        const size_t off = (size_t)b0 * HW * C * E_;
+        launch_gn2d(gout + (size_t)reg * goutreg, ga, be, rp ? rp + off : nullptr, relu ? 1 : 0, op + off, Bn, HW, C, 1e-5f,
+                    pr, s);
+      });
     };
     const int H0 = lm;
     auto osz = [](int h, int k, int s, int p) { return (h + 2 * p - k) / s + 1; };
     const int H1 = osz(H0, 7, 2, 3);                  // 10
     const int H2 = osz(H1, 3, 2, 1);                  // 5
     Act c1 = ebuf("enc.c1", H1 * H1, 64);
-    // stem: the f32 local map is read directly by im2col (C = 1 after folding the 3-channel repeat)
-    {
-      const HostParam& w = P_(R + "conv1.weight");
-      const float* wd = w.data;
-      const int Cw = (int)w.dims[1];
-      void* wp = pack(R + "conv1", 64, 1, 64, [=](int n, int, int kk) {
-        if (kk >= 49) return 0.0f;
-        const int kw = kk % 7, kh = kk / 7;
-        float s = 0.f;
-        for (int cc = 0; cc < Cw; ++cc) s += wd[(((size_t)n * Cw + cc) * 7 + kh) * 7 + kw];
-        return s;
-      });
-      const int HH = H0, OO = H1;
-      const TapList stem_taps = live_taps(7, 2, 3, H0, H1);
-      if (stem_taps.n != 49) throw std::runtime_error("stem conv expects all 49 taps live");
-      const float** lm_slot = &lm_ptr;
-      enc_ops.push_back([=, this](int B, int, hipStream_t s) {
-        launch_im2col2d(*lm_slot, true, col, B, HH, HH, 1, stem_taps, 2, 3, OO, OO, 64, pr, s);
-        ConvGemmParams p{};
-        const int M = B * OO * OO;
-        p.A = col; p.lda = 64; p.in_Lp = M; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = 64;
-        p.W = wp; p.Out = gout; p.ldc = 64; p.out_Lp = M; p.out_stride = 1; p.out_off = 0;
-        p.L = M; p.M = M; p.N = 64; p.mode = MODE_BIAS; p.out_f32 = 1;
-        run_gemm(p, s);
-      });
-    }
+    conv2d(R + "conv1", nullptr, H0, 1, 64, 7, 2, 3, H1, true);
     gn(R + "bn1", c1, nullptr, true);
     Act pool = ebuf("enc.pool", H2 * H2, 64);
     {
-      void* ip = c1.p; void* op = pool.p;
+      const char* ip = (const char*)c1.p; char* op = (char*)pool.p;
       const int a = H1, b2 = H2;
-      enc_ops.push_back([=](int B, int, hipStream_t s) { launch_maxpool2d(ip, op, B, a, a, 64, b2, b2, pr, s); });
+      enc_ops.push_back([=](int b0, int Bn, int, hipStream_t s) {
+        launch_maxpool2d(ip + (size_t)b0 * a * a * 64 * E_, op + (size_t)b0 * b2 * b2 * 64 * E_, Bn, a, a, 64, b2, b2, pr, s);
+      });
     }
     Act cur = pool;
     int Hc = H2, Cc = 64;
@@ -542,17 +567,17 @@ void DenoiserState::build(int prec_, int Bmax_) {
         const int Ho = osz(Hc, 3, stride, 1);
         const std::string tag = "enc.l" + std::to_string(li + 1) + "." + std::to_string(bi);
         Act t1 = ebuf(tag + ".t", Ho * Ho, Cout);
-        conv2d(pre + ".conv1", cur.p, false, Hc, Hc, Cc, Cout, 3, stride, 1, Ho, Ho, false);
+        conv2d(pre + ".conv1", cur.p, Hc, Cc, Cout, 3, stride, 1, Ho, false);
         gn(pre + ".bn1", t1, nullptr, true);
         Act idt = cur;
         if (has(pre + ".downsample.0.weight")) {
           Act ds = ebuf(tag + ".ds", Ho * Ho, Cout);
-          conv2d(pre + ".downsample.0", cur.p, false, Hc, Hc, Cc, Cout, 1, stride, 0, Ho, Ho, false);
+          conv2d(pre + ".downsample.0", cur.p, Hc, Cc, Cout, 1, stride, 0, Ho, false);
           gn(pre + ".downsample.1", ds, nullptr, false);
           idt = ds;
         }
         Act o = ebuf(tag + ".out", Ho * Ho, Cout);
-        conv2d(pre + ".conv2", t1.p, false, Ho, Ho, Cout, Cout, 3, 1, 1, Ho, Ho, false);
+        conv2d(pre + ".conv2", t1.p, Ho, Cout, Cout, 3, 1, 1, Ho, false);
         gn(pre + ".bn2", o, &idt, true);
         cur = o;
         Hc = Ho;
@@ -561,9 +586,11 @@ void DenoiserState::build(int prec_, int Bmax_) {
     }
     Act pooled = ebuf("enc.avg", 1, Cc);
     {
-      void* ip = cur.p; void* op = pooled.p;
+      const char* ip = (const char*)cur.p; char* op = (char*)pooled.p;
       const int HW = Hc * Hc, C = Cc;
-      enc_ops.push_back([=](int B, int, hipStream_t s) { launch_avgpool2d(ip, op, B, HW, C, pr, s); });
+      enc_ops.push_back([=](int b0, int Bn, int, hipStream_t s) {
+        launch_avgpool2d(ip + (size_t)b0 * HW * C * E_, op + (size_t)b0 * C * E_, Bn, HW, C, pr, s);
+      });
     }
     {
       const HostParam& w = P_(R + "fc.weight");
@@ -571,13 +598,13 @@ void DenoiserState::build(int prec_, int Bmax_) {
       const int Kf = (int)w.dims[1], Nf = (int)w.dims[0];
       void* wp = pack(R + "fc", Nf, 1, Kf, [=](int n, int, int ci) { return wd[(size_t)n * Kf + ci]; });
       float* bd = vec(R + "fc.bias");
-      void* ip = pooled.p;
+      const char* ip = (const char*)pooled.p;
       float* op = map_emb;
-      enc_ops.push_back([=, this](int B, int, hipStream_t s) {
+      enc_ops.push_back([=, this](int b0, int Bn, int, hipStream_t s) {
         ConvGemmParams p{};
-        p.A = ip; p.lda = Kf; p.in_Lp = B; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = Kf;
-        p.W = wp; p.Out = op; p.ldc = Nf; p.out_Lp = B; p.out_stride = 1; p.out_off = 0;
-        p.L = B; p.M = B; p.N = Nf; p.bias = bd; p.mode = MODE_BIAS; p.out_f32 = 1;
+        p.A = ip + (size_t)b0 * Kf * E_; p.lda = Kf; p.in_Lp = Bn; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = Kf;
+        p.W = wp; p.Out = op + (size_t)b0 * Nf; p.ldc = Nf; p.out_Lp = Bn; p.out_stride = 1; p.out_off = 0;
+        p.L = Bn; p.M = Bn; p.N = Nf; p.bias = bd; p.mode = MODE_BIAS; p.out_f32 = 1;
         run_gemm(p, s);
       });
     }
@@ -630,7 +657,34 @@ int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const
                                   hipMemcpyDeviceToDevice, s));
   }
   st->lm_ptr = local_map;
-  for (auto& op : st->enc_ops) op(B, Bp, s);
+  {
+    // encoder: up to ENC_SUBS sub-batches on separate streams (fork/join with events on `s`)
+    // measured on MI355X (B = 1024): 4 concurrent sub-batches cost more in extra launches than the
+    // concurrency returns (34.9 vs 31.6 ms per round); default is one sub-batch, DITREE_ENC_SUBS overrides
+    static int subs_env = -1;
+    if (subs_env < 0) { const char* e = getenv("DITREE_ENC_SUBS"); subs_env = e ? std::max(1, std::min(atoi(e), (int)DenoiserState::ENC_SUBS)) : 1; }
+    const int nsub = (B >= 64) ? subs_env : 1;
+    const int per = nsub == 1 ? B : std::min(st->sub_cap, (((B + nsub - 1) / nsub) + 15) / 16 * 16);
+    if (nsub > 1 && !st->aux[1]) {
+      for (int i = 1; i < DenoiserState::ENC_SUBS; ++i) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&st->aux[i], hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&st->ev_join[i], hipEventDisableTiming));
+      }
+      HIP_TRY(ctx, hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming));
+    }
+    if (nsub > 1) HIP_TRY(ctx, hipEventRecord(st->ev_fork, s));
+    for (int i = 0; i < nsub; ++i) {
+      const int b0 = i * per, bn = std::min(per, B - b0);
+      if (bn <= 0) break;
+      hipStream_t si = (i == 0) ? s : st->aux[i];
+      if (i > 0) HIP_TRY(ctx, hipStreamWaitEvent(si, st->ev_fork, 0));
+      for (auto& op : st->enc_ops) { st->note_other(); op(b0, bn, i, si); }   // every encoder op starts with a non-GEMM kernel
+      if (i > 0) {
+        HIP_TRY(ctx, hipEventRecord(st->ev_join[i], si));
+        HIP_TRY(ctx, hipStreamWaitEvent(s, st->ev_join[i], 0));
+      }
+    }
+  }
   for (int k = 0; k < K; ++k) {
     const float t = t0[k] * 20.0f;                                      // pos_emb_scale, fm_policy.py:187
     if (t != st->temb_t) {                                              // batch-invariant: K = 1 computes it once
@@ -639,11 +693,14 @@ int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const
                         st->temb, s);
       st->temb_t = K == 1 ? t : -1.0f;                                  // several steps share one buffer: recompute
     }
+    st->note_other();
     launch_prep_cond(st->temb, st->map_emb, st->E, cond, st->G, st->condA, B, st->condK, pr, s);
     st->film_op(B, Bp, s);
+    st->note_other();
     launch_prep_sample(st->x_cur, st->named["a0"].p, Bp, st->P, st->D, pr, s);
     for (auto& op : st->unet_ops) op(B, Bp, s);
     const bool last = (k == K - 1);
+    st->note_other();
     launch_final_proj_flow(st->final_h.p, st->final_h.C, st->final_h.Lp(), st->dev_f["unet.final_conv.1.weight"],
                            st->dev_f["unet.final_conv.1.bias"], st->D, st->x_cur, dt[k], act_norm,
                            (last && actions) ? actions : nullptr, B, st->P, pr, s);
@@ -657,6 +714,11 @@ void denoise_destroy(ditree_ctx* ctx) {
   if (ctx->dn) {
     for (auto e : ctx->dn->prof_ev) hipEventDestroy(e);
     ctx->dn->prof_ev.clear();
+    for (int i = 1; i < DenoiserState::ENC_SUBS; ++i) {
+      if (ctx->dn->aux[i]) hipStreamDestroy(ctx->dn->aux[i]);
+      if (ctx->dn->ev_join[i]) hipEventDestroy(ctx->dn->ev_join[i]);
+    }
+    if (ctx->dn->ev_fork) hipEventDestroy(ctx->dn->ev_fork);
     ctx->dn->free_workspace();
     delete ctx->dn;
     ctx->dn = nullptr;

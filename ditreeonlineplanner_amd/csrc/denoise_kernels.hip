@@ -44,11 +44,19 @@ __device__ __forceinline__ float bf2f(unsigned short u) {
 
 template <int PREC>
 __device__ __forceinline__ float mish_f(float x) {
-  // x * tanh(softplus(x)) = x * w / (w + 2), w = e^x (e^x + 2); softplus threshold 20 as torch
-  if (x > 20.0f) return x;
-  float n = (PREC == 0) ? __expf(x) : expf(x);
-  float w = n * (n + 2.0f);
-  return x * (w / (w + 2.0f));
+  // x * tanh(softplus(x)) = x * w / (w + 2), w = e^x (e^x + 2)
+  if constexpr (PREC == 0) {
+    // throughput path: x - 2x / (n (n + 2) + 2); n = inf (x > 88) gives rcp = 0 -> x, n = 0 gives 0,
+    // so torch's softplus threshold needs no branch.  5 VALU + exp + rcp.
+    const float n = __expf(x);
+    const float d = fmaf(n, n + 2.0f, 2.0f);
+    return fmaf(-2.0f * x, __builtin_amdgcn_rcpf(d), x);
+  } else {
+    if (x > 20.0f) return x;                       // softplus threshold as torch
+    const float n = expf(x);
+    const float w = n * (n + 2.0f);
+    return x * (w / (w + 2.0f));
+  }
 }
 
 // bijective XCD-aware tile remap (blocks b and b+8 share an XCD): each XCD gets a
@@ -106,6 +114,38 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
     for (int blk = 0; blk < 4; ++blk) slot[blk] = blk_b[blk] - tm * spt;
     const float inv_cnt = 1.0f / (float)(p.group_ch * p.L);
     float mean[4], rstd[4];
+    if constexpr (PREC == 0) {
+      // one pass: sum and sum of squares (f32), var = E[x^2] - mean^2
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float v = acc[blk >> 1][j][(blk & 1) * 8 + i];
+            s += v;
+            q = fmaf(v, v, q);
+          }
+        s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
+        s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
+        s += __shfl_xor(s, 4); q += __shfl_xor(q, 4);
+        s += __shfl_xor(s, 8); q += __shfl_xor(q, 8);
+        s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+        if (wide) { s += __shfl_xor(s, 16); q += __shfl_xor(q, 16); }
+        if (lane == 0 || (!wide && lane == 16)) {
+          atomicAdd(&s_sum[slot[blk] * 4 + gi], s);
+          atomicAdd(&s_sq[slot[blk] * 4 + gi], q);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        mean[blk] = s_sum[slot[blk] * 4 + gi] * inv_cnt;
+        const float var = fmaxf(s_sq[slot[blk] * 4 + gi] * inv_cnt - mean[blk] * mean[blk], 0.0f);
+        rstd[blk] = rsqrtf(var + p.eps);
+      }
+    } else {
     // pass 1: sums
     {
       float ps[4];
@@ -151,6 +191,8 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
     __syncthreads();
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) rstd[blk] = rsqrtf(s_sq[slot[blk] * 4 + gi] * inv_cnt + p.eps);
+
+    }
 
     f32x4_t gam = *(const f32x4_t*)(p.gamma + n0);
     f32x4_t bet = *(const f32x4_t*)(p.beta + n0);
@@ -383,6 +425,7 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
 //   W(s+2) is issued right after the barrier of step s, A(c+2) after the last barrier of chunk c,
 //   waited with a counted vmcnt (activations stay in flight for three K-steps).
 // =================================================================================================
+template <int DBG>
 __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int A_BUF = 40960, W_BUF = 32768, W_BASE = 2 * A_BUF;
@@ -482,19 +525,21 @@ __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
     // keep the fragment-address arithmetic inside the step (hoisted out of the chunk loop it
     // costs ~30 VGPRs of precomputed addresses and spills)
     asm volatile("" : "+v"(lrow[0]), "+v"(lrow[1]));
-    rd(1, c, T, 1);
-    mm8(0);
-    rd(0, c, T, 2);
-    mm8(1);
-    rd(1, c, T, 3);
-    mm8(0);
+    if constexpr (DBG != 2) {
+      rd(1, c, T, 1);
+      mm8(0);
+      rd(0, c, T, 2);
+      mm8(1);
+      rd(1, c, T, 3);
+      mm8(0);
+    }
     if constexpr (HAS_NEXT) {
       // this wave's reads of W(s) / A(c) are complete, the DMA of step s+1 has landed
       if constexpr (VM == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       constexpr int T1 = (T + 1) % 3;
-      rd(0, c + (T + 1) / 3, T1, 0);
+      if constexpr (DBG != 2) rd(0, c + (T + 1) / 3, T1, 0);
     }
     constexpr int T2 = (T + 2) % 3;
     const int c2 = c + (T + 2) / 3;
@@ -502,10 +547,10 @@ __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        mm(1, mb, j);
+        if constexpr (DBG != 2) mm(1, mb, j);
         const int i = mb * 4 + j;
-        if constexpr (ISSUE_W) { if (i < 4) issue_w(c2, T2, i); }
-        if constexpr (ISSUE_A) { if (i >= 3) issue_a(c + 2, i - 3); }
+        if constexpr (ISSUE_W && DBG != 1 ) { if (i < 4) issue_w(c2, T2, i); }
+        if constexpr (ISSUE_A && DBG != 1 ) { if (i >= 3) issue_a(c + 2, i - 3); }
       }
   };
   using I0 = std::integral_constant<int, 0>;
@@ -546,7 +591,13 @@ __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
     step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, c);
   }
   __syncthreads();
-  gemm_epilogue<0>(p, acc, smem, tm, tn, tid, lane, r5, h, wm, wn);
+  if constexpr (DBG == 3) {
+    ConvGemmParams q = p;
+    q.mode = MODE_BIAS;                               // ablation: plain store, no GroupNorm / Mish / FiLM / residual
+    gemm_epilogue<0>(q, acc, smem, tm, tn, tid, lane, r5, h, wm, wn);
+  } else {
+    gemm_epilogue<0>(p, acc, smem, tm, tn, tid, lane, r5, h, wm, wn);
+  }
 }
 
 void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s) {
@@ -564,15 +615,21 @@ void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s) {
   const dim3 grid(ntm * ntn), block(512);
   static int halo = -1;
   if (halo < 0) { const char* e = getenv("DITREE_NO_HALO"); halo = (e && atoi(e)) ? 0 : 1; }
-  const bool halo_ok = prec == 0 && halo && dbg == 0 && p.taps == 3 && p.in_stride == 1 && p.in_Lp == p.L + 2 &&
+  const bool halo_ok = prec == 0 && halo && p.taps == 3 && p.in_stride == 1 && p.in_Lp == p.L + 2 &&
                        (256 % p.L) == 0 && p.L >= 16 && (p.M & 255) == 0 && (p.Cin & 63) == 0 && p.Cin >= 192;
   if (halo_ok) {
     static bool attr2 = false;
     if (!attr2) {
-      hipFuncSetAttribute((const void*)conv3_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+      hipFuncSetAttribute((const void*)conv3_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+      hipFuncSetAttribute((const void*)conv3_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+      hipFuncSetAttribute((const void*)conv3_halo_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+      hipFuncSetAttribute((const void*)conv3_halo_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
       attr2 = true;
     }
-    hipLaunchKernelGGL(conv3_halo_kernel, grid, block, 147456, s, p);
+    if (dbg == 1) hipLaunchKernelGGL(conv3_halo_kernel<1>, grid, block, 147456, s, p);
+    else if (dbg == 2) hipLaunchKernelGGL(conv3_halo_kernel<2>, grid, block, 147456, s, p);
+    else if (dbg == 3) hipLaunchKernelGGL(conv3_halo_kernel<3>, grid, block, 147456, s, p);
+    else hipLaunchKernelGGL(conv3_halo_kernel<0>, grid, block, 147456, s, p);
     return;
   }
   if (prec == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 0>), grid, block, 131072, s, p);
