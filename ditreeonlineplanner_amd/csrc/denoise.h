@@ -32,10 +32,17 @@ struct ConvGemmParams {
   const void* Res;    // residual, activation type
   int ldres, res_Lp, res_off;
   int out_f32;        // store f32 regardless of the activation type
-  int dbg;            // experiment switches (DITREE_GEMM_DBG): 1 = no staging in the loop, 2 = no MFMA
+  int dbg;            // unused by the kernels (ablation variants are compile-time, DITREE_GEMM_DBG)
+  // implicit Conv2d on NHWC activations (c2d != 0): GEMM row m = (b, oh, ow); K = live taps x Cin
+  // (Cin a multiple of 64: one tap spans Cin/64 K-steps); A is the input activation (B, H, W, Cin);
+  // taps that fall outside the map read `zero` (>= 128 zero bytes).
+  int c2d, c2_H, c2_W, c2_OW, c2_OHW, c2_stride, c2_pad;
+  signed char c2_kh[12], c2_kw[12];
+  const void* zero;
 };
 
 void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s);
+int conv_gemm_kind(const ConvGemmParams& p, int prec);   // 0 halo kernel, 1 generic, 2 implicit Conv2d
 void launch_prep_sample(const float* x, void* A0, int B, int P, int D, int prec, hipStream_t s);
 void launch_time_embed(float t, const float* W1, const float* b1, const float* W2, const float* b2, float* out,
                        hipStream_t s);

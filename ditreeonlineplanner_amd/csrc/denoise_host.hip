@@ -73,18 +73,22 @@ struct DenoiserState {
   int condK = 0, film_cols = 0;
   Act final_h;                   // input of the final 1x1 projection
   const float* lm_ptr = nullptr; // caller's scaled local map of the current call
+  void* zero_row = nullptr;      // 256 zero bytes: source of out-of-map taps in implicit Conv2d
   // optional per-launch timing of the dominant kernel (hipEvents on the launch stream)
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;
   size_t prof_used = 0;
-  double prof_ms_done = 0.0;
-  int64_t prof_launches_done = 0;
+  // per kernel kind: 0 = conv3_halo_kernel, 1 = conv_gemm_kernel, 2 = conv_gemm_kernel (implicit Conv2d)
+  double prof_ms_done[3] = {0, 0, 0};
+  int64_t prof_launches_done[3] = {0, 0, 0};
+  double prof_flops_done[3] = {0, 0, 0};
+  struct ProfRec { size_t a, b; int kind; double flops; };
   // Profiling brackets every GEMM launch with events on its stream.  Back-to-back GEMM launches on
   // one stream share an event (the end of one is the start of the next), which halves the marker
   // packets; `prof_chain` is broken by note_other() whenever another kernel is enqueued in between.
   hipStream_t prof_last_stream = nullptr;
   bool prof_chain = false;
-  std::vector<std::pair<size_t, size_t>> prof_pairs;          // (start event, end event) per launch
+  std::vector<ProfRec> prof_pairs;                           // (start event, end event, kind, flops) per launch
   void note_other() { prof_chain = false; }
   void run_gemm(const ConvGemmParams& p, hipStream_t s) {
     if (!prof_on) { launch_conv_gemm(p, prec, s); return; }
@@ -103,7 +107,7 @@ struct DenoiserState {
     launch_conv_gemm(p, prec, s);
     const size_t end = prof_used++;
     hipEventRecord(prof_ev[end], s);
-    prof_pairs.emplace_back(start, end);
+    prof_pairs.push_back(ProfRec{start, end, conv_gemm_kind(p, prec), 2.0 * (double)p.M * (double)p.N * (double)p.taps * (double)p.Cin});
     prof_chain = true;
     prof_last_stream = s;
   }
@@ -112,8 +116,9 @@ struct DenoiserState {
     hipDeviceSynchronize();                                  // events live on several streams
     for (auto& pr : prof_pairs) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, prof_ev[pr.first], prof_ev[pr.second]) == hipSuccess) prof_ms_done += ms;
-      ++prof_launches_done;
+      if (hipEventElapsedTime(&ms, prof_ev[pr.a], prof_ev[pr.b]) == hipSuccess) prof_ms_done[pr.kind] += ms;
+      ++prof_launches_done[pr.kind];
+      prof_flops_done[pr.kind] += pr.flops;
     }
     prof_pairs.clear();
     prof_used = 0;
@@ -463,6 +468,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
     const std::string R = "encoder.resnet18.";
     const int pr = prec;
     const size_t E_ = es();
+    zero_row = dalloc(256);
     sub_cap = (Bmax + ENC_SUBS - 1) / ENC_SUBS;
     sub_cap = (sub_cap + 15) / 16 * 16;
     const size_t col_per_sample = 25 * 576;                         // largest im2col footprint per sample (layer1)
@@ -513,17 +519,29 @@ void DenoiserState::build(int prec_, int Bmax_) {
         return s;
       });
       const float** lm_slot = &lm_ptr;
+      const bool implicit = (in != nullptr) && (Cin % 64 == 0) && tl.n <= 12;
+      const void* zr = zero_row;
       enc_ops.push_back([=, this](int b0, int Bn, int reg, hipStream_t s) {
         char* colr = col + (size_t)reg * colreg * E_;
         float* goutr = gout + (size_t)reg * goutreg;
-        if (in == nullptr)
-          launch_im2col2d(*lm_slot + (size_t)b0 * H * H, true, colr, Bn, H, H, 1, tl, stride, pad, OH, OH, Kpad, pr, s);
-        else
-          launch_im2col2d((const char*)in + (size_t)b0 * H * H * Cin * E_, false, colr, Bn, H, H, Cin, tl, stride, pad,
-                          OH, OH, Kpad, pr, s);
         ConvGemmParams p{};
         const int M = Bn * OH * OH;
-        p.A = colr; p.lda = Kpad; p.in_Lp = M; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = Kpad;
+        if (implicit) {
+          // implicit GEMM: the kernel gathers the (tap, channel-chunk) rows itself, no im2col pass
+          p.A = (const char*)in + (size_t)b0 * H * H * Cin * E_; p.lda = Cin; p.taps = tl.n; p.Cin = Cin;
+          p.c2d = 1; p.c2_H = H; p.c2_W = H; p.c2_OW = OH; p.c2_OHW = OH * OH; p.c2_stride = stride; p.c2_pad = pad;
+          for (int t = 0; t < tl.n; ++t) { p.c2_kh[t] = tl.kh[t]; p.c2_kw[t] = tl.kw[t]; }
+          p.zero = zr;
+        } else {
+          note_other();
+          if (in == nullptr)
+            launch_im2col2d(*lm_slot + (size_t)b0 * H * H, true, colr, Bn, H, H, 1, tl, stride, pad, OH, OH, Kpad, pr, s);
+          else
+            launch_im2col2d((const char*)in + (size_t)b0 * H * H * Cin * E_, false, colr, Bn, H, H, Cin, tl, stride, pad,
+                            OH, OH, Kpad, pr, s);
+          p.A = colr; p.lda = Kpad; p.taps = 1; p.Cin = Kpad;
+        }
+        p.in_Lp = M; p.in_stride = 1; p.in_off = 0;
         p.W = wp; p.Out = goutr; p.ldc = Cout; p.out_Lp = M; p.out_stride = 1; p.out_off = 0;
         p.L = M; p.M = M; p.N = Cout; p.mode = MODE_BIAS; p.out_f32 = 1;
         run_gemm(p, s);
@@ -535,7 +553,8 @@ void DenoiserState::build(int prec_, int Bmax_) {
       const char* rp = res ? (const char*)res->p : nullptr;
       char* op = (char*)out.p;
       const int HW = out.L, C = out.C;
-      enc_ops.push_back([=](int b0, int Bn, int reg, hipStream_t s) {
+      enc_ops.push_back([=, this](int b0, int Bn, int reg, hipStream_t s) {
+        note_other();
         const size_t off = (size_t)b0 * HW * C * E_;
         launch_gn2d(gout + (size_t)reg * goutreg, ga, be, rp ? rp + off : nullptr, relu ? 1 : 0, op + off, Bn, HW, C, 1e-5f,
                     pr, s);
@@ -552,7 +571,8 @@ void DenoiserState::build(int prec_, int Bmax_) {
     {
       const char* ip = (const char*)c1.p; char* op = (char*)pool.p;
       const int a = H1, b2 = H2;
-      enc_ops.push_back([=](int b0, int Bn, int, hipStream_t s) {
+      enc_ops.push_back([=, this](int b0, int Bn, int, hipStream_t s) {
+        note_other();
         launch_maxpool2d(ip + (size_t)b0 * a * a * 64 * E_, op + (size_t)b0 * b2 * b2 * 64 * E_, Bn, a, a, 64, b2, b2, pr, s);
       });
     }
@@ -588,7 +608,8 @@ void DenoiserState::build(int prec_, int Bmax_) {
     {
       const char* ip = (const char*)cur.p; char* op = (char*)pooled.p;
       const int HW = Hc * Hc, C = Cc;
-      enc_ops.push_back([=](int b0, int Bn, int, hipStream_t s) {
+      enc_ops.push_back([=, this](int b0, int Bn, int, hipStream_t s) {
+        note_other();
         launch_avgpool2d(ip + (size_t)b0 * HW * C * E_, op + (size_t)b0 * C * E_, Bn, HW, C, pr, s);
       });
     }
@@ -678,7 +699,7 @@ int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const
       if (bn <= 0) break;
       hipStream_t si = (i == 0) ? s : st->aux[i];
       if (i > 0) HIP_TRY(ctx, hipStreamWaitEvent(si, st->ev_fork, 0));
-      for (auto& op : st->enc_ops) { st->note_other(); op(b0, bn, i, si); }   // every encoder op starts with a non-GEMM kernel
+      for (auto& op : st->enc_ops) op(b0, bn, i, si);
       if (i > 0) {
         HIP_TRY(ctx, hipEventRecord(st->ev_join[i], si));
         HIP_TRY(ctx, hipStreamWaitEvent(s, st->ev_join[i], 0));
@@ -793,17 +814,20 @@ int32_t ditree_profile(ditree_ctx* ctx, int32_t enable) {
   if (!st) return set_err(ctx, DITREE_E_STATE, "profile: weights not loaded");
   st->prof_collect();
   st->prof_on = enable != 0;
-  if (enable) { st->prof_ms_done = 0.0; st->prof_launches_done = 0; }
+  if (enable) for (int k = 0; k < 3; ++k) { st->prof_ms_done[k] = 0.0; st->prof_launches_done[k] = 0; st->prof_flops_done[k] = 0.0; }
   return DITREE_OK;
 }
 
-int32_t ditree_profile_read(ditree_ctx* ctx, double* gemm_ms, int64_t* gemm_launches) {
+int32_t ditree_profile_read(ditree_ctx* ctx, double* ms3, int64_t* launches3, double* flops3) {
   if (!ctx) return DITREE_E_ARG;
   DenoiserState* st = ctx->dn;
-  if (!st || !gemm_ms || !gemm_launches) return set_err(ctx, DITREE_E_STATE, "profile_read: bad state");
+  if (!st || !ms3 || !launches3 || !flops3) return set_err(ctx, DITREE_E_STATE, "profile_read: bad state");
   st->prof_collect();
-  *gemm_ms = st->prof_ms_done;
-  *gemm_launches = st->prof_launches_done;
+  for (int k = 0; k < 3; ++k) {
+    ms3[k] = st->prof_ms_done[k];
+    launches3[k] = st->prof_launches_done[k];
+    flops3[k] = st->prof_flops_done[k];
+  }
   return DITREE_OK;
 }
 

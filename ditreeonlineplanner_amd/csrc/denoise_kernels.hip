@@ -257,7 +257,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
   }
 }
 
-template <int PREC, int DBG = 0>
+template <int PREC, int DBG = 0, bool C2D = false>
 __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
   constexpr int ES = (PREC == 0) ? 2 : 4;          // element bytes
   constexpr int EK = 128 / ES;                     // elements of K per step
@@ -303,14 +303,51 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
   }
   int kin = 0;                                       // K-step index inside the current tap
   const long long a_tap_jump = ((long long)p.lda - (long long)p.Cin + EK) * ES;
-  auto advance = [&]() {
-    ++kin;
-    long long ainc = 128;
-    if (kin == kpt) { kin = 0; ainc = a_tap_jump; }
+  // implicit Conv2d: per staged row the sample base, the top-left input pixel of its window and
+  // the swizzled slot; the source pointer is rebuilt for every K-step (tap, channel chunk)
+  const char* c2_base[4];
+  int c2_ih0[4], c2_iw0[4], c2_slot[4];
+  int c2_tap = 0;
+  if constexpr (C2D) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      pa[q] += ainc;
-      pb[q] += 128;
+      const int r = (w * 4 + q) * 8 + (lane >> 3);
+      int m = tm * 256 + r;
+      m = m < p.M ? m : p.M - 1;
+      const int b = m / p.c2_OHW, rem = m - b * p.c2_OHW;
+      const int oh = rem / p.c2_OW, ow = rem - oh * p.c2_OW;
+      c2_base[q] = Abase + (long long)b * p.c2_H * p.c2_W * p.Cin * ES;
+      c2_ih0[q] = oh * p.c2_stride - p.c2_pad;
+      c2_iw0[q] = ow * p.c2_stride - p.c2_pad;
+      c2_slot[q] = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+    }
+  }
+  auto c2_point = [&]() {                              // pa[] for K-step (c2_tap, kin)
+    const int kh = p.c2_kh[c2_tap], kw = p.c2_kw[c2_tap];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ih = c2_ih0[q] + kh, iw = c2_iw0[q] + kw;
+      const bool ok = ih >= 0 && ih < p.c2_H && iw >= 0 && iw < p.c2_W;
+      const char* src = c2_base[q] + ((long long)(ih * p.c2_W + iw) * p.Cin + kin * EK) * ES;
+      pa[q] = (ok ? src : (const char*)p.zero) + c2_slot[q];
+    }
+  };
+  if constexpr (C2D) c2_point();
+  auto advance = [&]() {
+    ++kin;
+    if constexpr (C2D) {
+      if (kin == kpt) { kin = 0; ++c2_tap; }
+      if (c2_tap < p.taps) c2_point();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pb[q] += 128;
+    } else {
+      long long ainc = 128;
+      if (kin == kpt) { kin = 0; ainc = a_tap_jump; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        pa[q] += ainc;
+        pb[q] += 128;
+      }
     }
   };
   // one 1-KiB piece (q = 0..3: activations, 4..7: weights) into the LDS stage at `sbase`
@@ -600,6 +637,14 @@ __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
   }
 }
 
+static bool halo_eligible(const ConvGemmParams& p, int prec) {
+  static int halo = -1;
+  if (halo < 0) { const char* e = getenv("DITREE_NO_HALO"); halo = (e && atoi(e)) ? 0 : 1; }
+  return prec == 0 && halo && !p.c2d && p.taps == 3 && p.in_stride == 1 && p.in_Lp == p.L + 2 && (256 % p.L) == 0 &&
+         p.L >= 16 && (p.M & 255) == 0 && (p.Cin & 63) == 0 && p.Cin >= 192;
+}
+int conv_gemm_kind(const ConvGemmParams& p, int prec) { return halo_eligible(p, prec) ? 0 : (p.c2d ? 2 : 1); }
+
 void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s) {
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("DITREE_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
@@ -613,10 +658,7 @@ void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s) {
     attr_set = true;
   }
   const dim3 grid(ntm * ntn), block(512);
-  static int halo = -1;
-  if (halo < 0) { const char* e = getenv("DITREE_NO_HALO"); halo = (e && atoi(e)) ? 0 : 1; }
-  const bool halo_ok = prec == 0 && halo && p.taps == 3 && p.in_stride == 1 && p.in_Lp == p.L + 2 &&
-                       (256 % p.L) == 0 && p.L >= 16 && (p.M & 255) == 0 && (p.Cin & 63) == 0 && p.Cin >= 192;
+  const bool halo_ok = halo_eligible(p, prec);
   if (halo_ok) {
     static bool attr2 = false;
     if (!attr2) {
@@ -630,6 +672,17 @@ void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s) {
     else if (dbg == 2) hipLaunchKernelGGL(conv3_halo_kernel<2>, grid, block, 147456, s, p);
     else if (dbg == 3) hipLaunchKernelGGL(conv3_halo_kernel<3>, grid, block, 147456, s, p);
     else hipLaunchKernelGGL(conv3_halo_kernel<0>, grid, block, 147456, s, p);
+    return;
+  }
+  if (p.c2d) {
+    static bool attr3 = false;
+    if (!attr3) {
+      hipFuncSetAttribute((const void*)conv_gemm_kernel<0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      hipFuncSetAttribute((const void*)conv_gemm_kernel<1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      attr3 = true;
+    }
+    if (prec == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 0, true>), grid, block, 131072, s, p);
+    else hipLaunchKernelGGL((conv_gemm_kernel<0, 0, true>), grid, block, 131072, s, p);
     return;
   }
   if (prec == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 0>), grid, block, 131072, s, p);

@@ -225,10 +225,14 @@ def _ctx_profile(self, enable=True):
     check(self._h, lib().ditree_profile(self._h, int(bool(enable))), "profile")
 
 
+PROFILE_KINDS = ("conv3_halo_kernel", "conv_gemm_kernel", "conv_gemm_kernel<implicit conv2d>")
+
+
 def _ctx_profile_read(self):
-    ms, n = C.c_double(), C.c_int64()
-    check(self._h, lib().ditree_profile_read(self._h, C.byref(ms), C.byref(n)), "profile_read")
-    return ms.value, n.value
+    """-> {kernel name: dict(ms, launches, flops)} for the MFMA kernels since profile(True)."""
+    ms, n, fl = (C.c_double * 3)(), (C.c_int64 * 3)(), (C.c_double * 3)()
+    check(self._h, lib().ditree_profile_read(self._h, ms, n, fl), "profile_read")
+    return {PROFILE_KINDS[k]: dict(ms=ms[k], launches=n[k], flops=fl[k]) for k in range(3)}
 
 
 Context.profile = _ctx_profile

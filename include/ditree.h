@@ -189,11 +189,13 @@ int32_t ditree_denoise(ditree_ctx* ctx, const float* noise, const float* local_m
                        const float* cond, int32_t B, int32_t K, const float* t0, const float* dt,
                        const double* act_norm, double* actions, float* x_out, void* stream);
 
-/* Measurement support: when enabled, every launch of the dominant kernel (the implicit-GEMM
- * conv kernel) is bracketed by hipEvents on its launch stream; ditree_profile_read waits for
- * them and returns the summed kernel time and the launch count since the last enable. */
+/* Measurement support: when enabled, every launch of the MFMA kernels is bracketed by hipEvents on
+ * its launch stream (back-to-back launches share an event); ditree_profile_read waits for them and
+ * returns, per kernel kind k = 0 conv3_halo_kernel, 1 conv_gemm_kernel, 2 conv_gemm_kernel in
+ * implicit-Conv2d mode: summed kernel time ms3[k], launches3[k] and executed FLOPs flops3[k]
+ * (2*M*N*K of every launch) since the last enable. */
 int32_t ditree_profile(ditree_ctx* ctx, int32_t enable);
-int32_t ditree_profile_read(ditree_ctx* ctx, double* gemm_ms, int64_t* gemm_launches);
+int32_t ditree_profile_read(ditree_ctx* ctx, double* ms3, int64_t* launches3, double* flops3);
 
 /* Test / debug support: copy a named internal activation of the last ditree_denoise call
  * (e.g. "d0b1.out", "skip2", "mid2.out", "final.h", "film", "map_emb") as f32
