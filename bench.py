@@ -59,7 +59,7 @@ def synth_inputs(maze, B_total, seed=20260104):
     return nodes, goal, samples, cond, noise
 
 
-def cpu_baseline(maze, nodes, goal, samples, cond, noise, state_dict, n_cand=64, batch=32):
+def cpu_baseline(maze, nodes, goal, samples, cond, noise, state_dict, n_cand=512, batch=64):
     """The oracle (numpy geometry + torch-CPU fp32 denoiser) on a bounded sample of the same workload."""
     from oracle import denoiser as OD
     from oracle import geometry as G

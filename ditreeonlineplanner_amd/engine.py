@@ -211,12 +211,14 @@ class ExpansionEngine:
         return None if g < 0 else g
 
     def fallback_node(self):
-        """planners/RRT.py:233-237 (run_type 0): among nodes 1.., nearest to goal_state xy."""
+        """planners/RRT.py:233-237 (run_type 0): among nodes 1.., the one nearest to goal_state xy
+        (arg-min reduction on the device: the nearest-node kernel with the goal as the single query)."""
         n = self.tree.n_nodes_host
         if n < 2:
             return None
-        d = self.tree.xy[1:n].cpu().numpy() - self.goal_state[:2]          # once per plan, host side
-        return 1 + int(np.argmin(np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])))
+        q = torch.as_tensor(self.goal_state[:2].reshape(1, 2).copy(), device=self.tree.xy.device)
+        idx = self.ctx.nn_argmin(q, self.tree.xy[1:n].contiguous(), n_nodes=n - 1)
+        return 1 + int(idx[0].item())
 
     def path_to(self, node):
         """planners/base_planner.py:342-363: float32 path (edge states + node states) and actions."""

@@ -1,0 +1,153 @@
+"""GPU: the hot path at BASELINE.json's full sizes, checked through size-independent properties and
+oracle comparisons on random subsets (the oracle is far too slow for the full batches)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import geometry as G
+from oracle import rrt as ORRT
+from oracle.tapes import ActionTape
+from tests.util import load_maze
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from ditreeonlineplanner_amd.ops import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def dev(a, dtype=None):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+def _free_states(rng, maze, B):
+    free = np.argwhere(maze == 0)
+    cell = free[rng.integers(0, len(free), B)]
+    xy = G.cell_rowcol_to_xy(cell, maze) + rng.uniform(-0.3, 0.3, (B, 2))
+    return np.concatenate([xy, rng.uniform(-np.pi, np.pi, (B, 1)), rng.uniform(0, 4, (B, 1)),
+                           rng.uniform(0, 1, (B, 1)), rng.uniform(-0.4, 0.4, (B, 1))], axis=1)
+
+
+def test_rollout_65536_x_16(ctx):
+    """BASELINE config 5 shape (65 536 rollouts, T = 16) on the car rollout kernel."""
+    maze = load_maze("random_huge")
+    ctx.upload_maze(maze)
+    rng = np.random.default_rng(5)
+    B, T = 65536, 16
+    st = _free_states(rng, maze, B)
+    acts = np.stack([rng.uniform(-12, 12, (B, T)), rng.uniform(-3, 3, (B, T))], axis=2)
+    goal = G.cell_rowcol_to_xy(np.array([15, 25]), maze)
+    state = dev(st)
+    status, states, aout, steps = ctx.car_rollout(state, dev(acts), goal, A=T)
+    s, k = status.cpu().numpy(), steps.cpu().numpy()
+    S, A_ = states.cpu().numpy(), aout.cpu().numpy()
+    code = s & 0xFF
+    # properties that hold for every candidate
+    assert set(np.unique(code)) <= {0, 1, 2}
+    assert ((k >= 1) & (k <= T)).all() and (k[code == 0] == T).all()
+    assert np.array_equal(S[:, 0], st)
+    rows = np.arange(T + 1)[None, :]
+    assert (S[rows.repeat(B, 0) > k[:, None]] == 0).all()                  # rows after the last executed step stay zero
+    goal_hit = code == 1
+    d = np.linalg.norm(S[np.arange(B), k, :2] - goal, axis=1)
+    assert (d[goal_hit] < 0.5).all()
+    assert np.array_equal(state.cpu().numpy(), S[np.arange(B), k])          # end state = last executed row
+    for b in np.nonzero(goal_hit)[0][:50]:
+        assert (A_[b, k[b]:] == 0).all()
+    # oracle on a random subset
+    sub = rng.choice(B, 768, replace=False)
+    ref = G.rollout_chunk(st[sub], acts[sub], maze, goal, T)
+    assert np.array_equal(code[sub], ref["status"]) and np.array_equal(k[sub], ref["n_steps"])
+    assert np.abs(S[sub] - ref["states"]).max() < 1e-9
+
+
+def test_lidar_8192_poses(ctx):
+    """BASELINE config 4 shape: one 181-ray scan per pose for 8192 poses."""
+    maze = load_maze("boxes")
+    rng = np.random.default_rng(6)
+    B = 8192
+    free = np.argwhere(maze == 0)
+    pick = free[rng.integers(0, len(free), B)]
+    poses = np.stack([pick[:, 1] + rng.uniform(0.05, 0.95, B), pick[:, 0] + rng.uniform(0.05, 0.95, B),
+                      rng.uniform(-np.pi, np.pi, B)], axis=1)
+    dist, ends, hit, vis = ctx.lidar_scan(dev(poses), dev(maze, torch.float32))
+    D, E, Hh, V = dist.cpu().numpy(), ends.cpu().numpy(), hit.cpu().numpy().astype(bool), vis.cpu().numpy()
+    ang = np.deg2rad(poses[:, 2:3] + G.LIDAR_ANGLES_DEG[None, :])
+    assert (D >= 0).all() and (D < 40).all()
+    assert np.abs(E[..., 0] - (poses[:, 0:1] + D * np.cos(ang))).max() < 1e-9
+    assert np.abs(E[..., 1] - (poses[:, 1:2] + D * np.sin(ang))).max() < 1e-9
+    # a hit endpoint lies in an occupied cell; the scanning cell itself is visited, occupied cells never are
+    ex = np.clip(np.floor(E[..., 0]).astype(int), 0, 19)
+    ey = np.clip(np.floor(E[..., 1]).astype(int), 0, 19)
+    assert (maze[ey[Hh], ex[Hh]] == 1).all()
+    assert (V[np.arange(B), pick[:, 0], pick[:, 1]] == 1).all()
+    assert (V.astype(bool) & (maze[None] == 1)).sum() == 0
+    for b in rng.choice(B, 24, replace=False):
+        d, e, v, h = G.lidar_scan(poses[b], maze)
+        assert np.array_equal(Hh[b], h) and np.abs(D[b] - d).max() < 1e-9
+        ref_v = np.zeros(maze.shape, dtype=np.uint8)
+        ref_v[v[:, 1], v[:, 0]] = 1
+        assert np.array_equal(V[b], ref_v)
+
+
+def test_round_of_8192_candidates_vs_oracle(ctx):
+    """One H = 32 round of 8192 candidates (tape actions) against a 1024-node tree: the whole round vs the oracle."""
+    from ditreeonlineplanner_amd.engine import ExpansionEngine
+    maze = load_maze("boxes")
+    rng = np.random.default_rng(7)
+    B, N0, Hh, A = 8192, 1024, 32, 8
+    nodes = _free_states(rng, maze, N0)
+    goal = np.array([*G.cell_rowcol_to_xy([2, 17], maze), 0, 0, 0, 0])
+    pl = ORRT.OraclePlanner(maze, nodes[0], goal, ActionTape(3).sampler(), edge_length=Hh, action_horizon=A,
+                            emulate_sticky_done=False)
+    t = pl.tree
+    for i in range(1, N0):
+        t.states.append(nodes[i].copy()); t.parents.append(0); t.last_action.append(np.zeros(2))
+        t.has_prev.append(True); t.num_visit.append(0); t.edge_states.append(None); t.edge_actions.append(None)
+    s, c = ORRT.RandomTape(1).draw_round(B, 20, 20, goal)
+    ref = pl.expand_round(s, c)
+    eng = ExpansionEngine(ctx, maze, nodes[0], goal, edge_length=Hh, action_horizon=A, batch=B, capacity=N0 + B,
+                          emulate_sticky_done=False)
+    tr = eng.tree
+    nd = dev(nodes)
+    tr.state[:N0] = nd
+    tr.xy[:N0] = nd[:, :2]
+    tr.parent[:N0] = 0
+    tr.parent[0] = -1
+    tr.has_prev[:N0] = 1
+    tr.counters[0] = N0
+    tr.n_nodes_host = N0
+    acts = np.stack([ActionTape(3).actions(np.arange(B), j) for j in range(Hh // A)], axis=1)
+    eng.expand_round(dev(s), dev(c), inject_actions=dev(acts))
+    assert np.array_equal(eng.rb.parent.cpu().numpy(), ref["parent"])
+    assert np.array_equal(eng.rb.status.cpu().numpy() & 0xFF, ref["status"])
+    assert np.array_equal(eng.rb.chunks_run.cpu().numpy(), ref["chunks_run"])
+    assert np.abs(eng.rb.end_state.cpu().numpy() - ref["end_state"]).max() < 1e-9
+    snap = eng.tree_snapshot()
+    assert np.array_equal(snap["parents"][N0:], np.array(pl.tree.parents[N0:]))
+    assert np.abs(snap["states"][N0:] - np.array(pl.tree.states[N0:])).max() < 1e-9
+    assert (eng.goal_node is not None) == (pl.goal_node is not None)
+    # fallback selection on the device == the reference rule (RRT.py:233-237)
+    assert eng.fallback_node() == pl.fallback_node()
+
+
+def test_denoiser_batch_1024_rows_independent(ctx):
+    """Bench-size batch on the bf16 path: any row equals the same row computed in a batch of 16."""
+    from ditreeonlineplanner_amd.model import NoisePredNet
+    net = NoisePredNet(seed=3)
+    net.bind(ctx, precision=0, max_batch=1024)
+    g = torch.Generator().manual_seed(9)
+    B = 1024
+    noise = torch.randn(B, 64, 2, generator=g).cuda()
+    lm = (torch.rand(B, 20, 20, generator=g) > 0.7).float().cuda() * 2 - 1
+    cond = (torch.randn(B, 7, generator=g) * 0.5).cuda()
+    full = ctx.denoise(noise, lm, cond, want_actions=False)
+    assert torch.isfinite(full).all()
+    for lo in (0, 496, 1008):
+        part = ctx.denoise(noise[lo:lo + 16].contiguous(), lm[lo:lo + 16].contiguous(), cond[lo:lo + 16].contiguous(),
+                           want_actions=False)
+        assert torch.equal(part, full[lo:lo + 16])
