@@ -39,6 +39,10 @@ struct ConvGemmParams {
   int c2d, c2_H, c2_W, c2_OW, c2_OHW, c2_stride, c2_pad;
   signed char c2_kh[12], c2_kw[12];
   const void* zero;
+  // split-K (implicit Conv2d mode only): gridDim.y = splitk blocks share a tile, block y handles a
+  // contiguous range of K-steps and writes its partial f32 tile to Out + y * slab_stride elements
+  int splitk;
+  long long slab_stride;
 };
 
 void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s);
@@ -56,8 +60,8 @@ struct TapList {          // live (kh, kw) taps of a Conv2d on a small map
 };
 void launch_im2col2d(const void* in, bool src_f32, void* out, int B, int H, int W, int C, const TapList& taps, int stride,
                      int pad, int OH, int OW, int Kpad, int prec, hipStream_t s);
-void launch_gn2d(const float* in, const float* gamma, const float* beta, const void* res, int relu, void* out, int B,
-                 int HW, int C, float eps, int prec, hipStream_t s);
+void launch_gn2d(const float* in, int nslab, long long slab_stride, const float* gamma, const float* beta, const void* res,
+                 int relu, void* out, int B, int HW, int C, float eps, int prec, hipStream_t s);
 void launch_maxpool2d(const void* in, void* out, int B, int H, int W, int C, int OH, int OW, int prec, hipStream_t s);
 void launch_avgpool2d(const void* in, void* out, int B, int HW, int C, int prec, hipStream_t s);
 void launch_unpack_act(const void* in, int ld, int coff, int Lp, int roff, float* out, int B, int L, int C, int prec,

@@ -74,6 +74,8 @@ struct DenoiserState {
   Act final_h;                   // input of the final 1x1 projection
   const float* lm_ptr = nullptr; // caller's scaled local map of the current call
   void* zero_row = nullptr;      // 256 zero bytes: source of out-of-map taps in implicit Conv2d
+  int last_splitk[4] = {1, 1, 1, 1};       // split-K layout of the conv output the next GroupNorm op reads, per region
+  long long last_slab[4] = {0, 0, 0, 0};
   // optional per-launch timing of the dominant kernel (hipEvents on the launch stream)
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;
@@ -472,7 +474,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
     sub_cap = (Bmax + ENC_SUBS - 1) / ENC_SUBS;
     sub_cap = (sub_cap + 15) / 16 * 16;
     const size_t col_per_sample = 25 * 576;                         // largest im2col footprint per sample (layer1)
-    const size_t gout_per_sample = 100 * 64;                        // largest f32 GEMM output per sample (stem)
+    const size_t gout_per_sample = 9216;                            // f32 GEMM output per sample: stem 100*64, or up to 8 split-K slabs of 9*128
     col_region = (size_t)sub_cap * col_per_sample;
     gout_region = (size_t)sub_cap * gout_per_sample;
     char* col = (char*)dalloc(col_region * ENC_SUBS * E_);
@@ -532,7 +534,29 @@ void DenoiserState::build(int prec_, int Bmax_) {
           p.c2d = 1; p.c2_H = H; p.c2_W = H; p.c2_OW = OH; p.c2_OHW = OH * OH; p.c2_stride = stride; p.c2_pad = pad;
           for (int t = 0; t < tl.n; ++t) { p.c2_kh[t] = tl.kh[t]; p.c2_kw[t] = tl.kw[t]; }
           p.zero = zr;
+          // split-K: these layers have few tiles and long K loops; spread the K-steps over idle CUs
+          const int nk_total = tl.n * (Cin / 64);
+          const int tiles = ((M + 255) / 256) * ((Cout + 255) / 256);
+          int sk = std::max(1, std::min(std::min(8, nk_total / 2), std::max(1, 160 / tiles)));
+          while (sk > 1 && (size_t)sk * OH * OH * Cout > gout_per_sample) --sk;
+          if (sk > 1) {                                   // every split must own at least one K-step
+            const int per = (nk_total + sk - 1) / sk;
+            sk = (nk_total + per - 1) / per;
+          }
+          // measured on MI355X at B = 1024: split-K costs more (extra prologues / epilogues, slab traffic) than
+          // the added parallelism returns (30.5 vs 29.7 ms per round), so it is opt-in: DITREE_SPLITK=1
+          static int use_split = -1;
+          if (use_split < 0) { const char* e = getenv("DITREE_SPLITK"); use_split = (e && atoi(e)) ? 1 : 0; }
+          if (!use_split) sk = 1;
+          p.splitk = sk;
+          p.slab_stride = (long long)M * Cout;
+          last_splitk[reg] = sk;
+          last_slab[reg] = p.slab_stride;
         } else {
+          last_splitk[reg] = 1;
+          last_slab[reg] = 0;
+        }
+        if (!implicit) {
           note_other();
           if (in == nullptr)
             launch_im2col2d(*lm_slot + (size_t)b0 * H * H, true, colr, Bn, H, H, 1, tl, stride, pad, OH, OH, Kpad, pr, s);
@@ -556,8 +580,8 @@ void DenoiserState::build(int prec_, int Bmax_) {
       enc_ops.push_back([=, this](int b0, int Bn, int reg, hipStream_t s) {
         note_other();
         const size_t off = (size_t)b0 * HW * C * E_;
-        launch_gn2d(gout + (size_t)reg * goutreg, ga, be, rp ? rp + off : nullptr, relu ? 1 : 0, op + off, Bn, HW, C, 1e-5f,
-                    pr, s);
+        launch_gn2d(gout + (size_t)reg * goutreg, last_splitk[reg], last_slab[reg], ga, be, rp ? rp + off : nullptr,
+                    relu ? 1 : 0, op + off, Bn, HW, C, 1e-5f, pr, s);
       });
     };
     const int H0 = lm;

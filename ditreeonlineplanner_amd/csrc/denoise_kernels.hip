@@ -272,8 +272,17 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
   const int tile = xcd_remap(blockIdx.x, ntm * ntn);
   const int tm = tile / ntn, tn = tile - tm * ntn;
   const int K = p.taps * p.Cin;
-  const int nk = K / EK;
   const int kpt = p.Cin / EK;                      // K-steps per tap
+  int nk = K / EK;
+  int k_first = 0;                                 // split-K (implicit Conv2d): this block's K-step range
+  if constexpr (C2D) {
+    if (p.splitk > 1) {
+      const int per = (nk + p.splitk - 1) / p.splitk;
+      k_first = blockIdx.y * per;
+      nk = min(nk - k_first, per);
+      p.Out = (char*)p.Out + (long long)blockIdx.y * p.slab_stride * 4;
+    }
+  }
 
   // ---- per-lane staging sources (byte offsets) ------------------------------------------
   const char* Abase = (const char*)p.A;
@@ -299,15 +308,15 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     pa[q] = Abase + aoff[q];
-    pb[q] = Wbase + boff[q];
+    pb[q] = Wbase + boff[q] + (long long)k_first * 128;
   }
-  int kin = 0;                                       // K-step index inside the current tap
+  int kin = C2D ? (k_first % kpt) : 0;               // K-step index inside the current tap
   const long long a_tap_jump = ((long long)p.lda - (long long)p.Cin + EK) * ES;
   // implicit Conv2d: per staged row the sample base, the top-left input pixel of its window and
   // the swizzled slot; the source pointer is rebuilt for every K-step (tap, channel chunk)
   const char* c2_base[4];
   int c2_ih0[4], c2_iw0[4], c2_slot[4];
-  int c2_tap = 0;
+  int c2_tap = C2D ? (k_first / kpt) : 0;
   if constexpr (C2D) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -681,8 +690,9 @@ void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s) {
       hipFuncSetAttribute((const void*)conv_gemm_kernel<1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       attr3 = true;
     }
-    if (prec == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 0, true>), grid, block, 131072, s, p);
-    else hipLaunchKernelGGL((conv_gemm_kernel<0, 0, true>), grid, block, 131072, s, p);
+    const dim3 grid2(ntm * ntn, p.splitk > 1 ? p.splitk : 1);
+    if (prec == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 0, true>), grid2, block, 131072, s, p);
+    else hipLaunchKernelGGL((conv_gemm_kernel<0, 0, true>), grid2, block, 131072, s, p);
     return;
   }
   if (prec == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 0>), grid, block, 131072, s, p);
@@ -870,22 +880,49 @@ void launch_im2col2d(const void* in, bool src_f32, void* out, int B, int H, int 
 // GroupNorm (C/16 groups, local_map_encoder.py:63-76) on the f32 GEMM output [B][HW][C],
 // optional residual add and ReLU (torchvision BasicBlock), writes the activation type.
 template <int PREC>
-__global__ void __launch_bounds__(64) gn2d_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
-                                                  const float* __restrict__ beta, const void* __restrict__ res,
-                                                  int relu, void* __restrict__ out, int HW, int C, float eps) {
+__global__ void __launch_bounds__(64) gn2d_kernel(const float* __restrict__ in, int nslab, long long slab_stride,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  const void* __restrict__ res, int relu, void* __restrict__ out, int HW,
+                                                  int C, float eps) {
   const int groups = C >> 4;
   const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
   const int lane = threadIdx.x;
   const int n = HW * 16;
   const long long base = (long long)b * HW * C + g * 16;
+  // each lane keeps its (up to 4) elements in registers: sum of the split-K partial slabs
+  float v[4];
   float s = 0.f;
-  for (int e = lane; e < n; e += 64) s += in[base + (long long)(e >> 4) * C + (e & 15)];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int e = lane + 64 * t;
+    float x = 0.f;
+    if (e < n) {
+      const long long idx = base + (long long)(e >> 4) * C + (e & 15);
+      for (int sl = 0; sl < nslab; ++sl) x += in[idx + sl * slab_stride];
+    }
+    v[t] = x;
+    s += x;
+  }
+  for (int e = lane + 256; e < n; e += 64) {                 // maps larger than 16 pixels (stem / layer1)
+    const long long idx = base + (long long)(e >> 4) * C + (e & 15);
+    float x = 0.f;
+    for (int sl = 0; sl < nslab; ++sl) x += in[idx + sl * slab_stride];
+    s += x;
+  }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
   const float mean = s / (float)n;
   float q = 0.f;
-  for (int e = lane; e < n; e += 64) {
-    float d = in[base + (long long)(e >> 4) * C + (e & 15)] - mean;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int e = lane + 64 * t;
+    if (e < n) { const float d = v[t] - mean; q += d * d; }
+  }
+  for (int e = lane + 256; e < n; e += 64) {
+    const long long idx = base + (long long)(e >> 4) * C + (e & 15);
+    float x = 0.f;
+    for (int sl = 0; sl < nslab; ++sl) x += in[idx + sl * slab_stride];
+    const float d = x - mean;
     q += d * d;
   }
 #pragma unroll
@@ -894,17 +931,20 @@ __global__ void __launch_bounds__(64) gn2d_kernel(const float* __restrict__ in, 
   for (int e = lane; e < n; e += 64) {
     const long long idx = base + (long long)(e >> 4) * C + (e & 15);
     const int c = g * 16 + (e & 15);
-    float v = (in[idx] - mean) * rstd * gamma[c] + beta[c];
-    if (res != nullptr) v += load_elem<PREC>(res, idx);
-    if (relu) v = v > 0.f ? v : 0.f;
-    store_elem<PREC>(out, idx, v);
+    float x;
+    if (e < 256) x = v[e >> 6];
+    else { x = 0.f; for (int sl = 0; sl < nslab; ++sl) x += in[idx + sl * slab_stride]; }
+    float y = (x - mean) * rstd * gamma[c] + beta[c];
+    if (res != nullptr) y += load_elem<PREC>(res, idx);
+    if (relu) y = y > 0.f ? y : 0.f;
+    store_elem<PREC>(out, idx, y);
   }
 }
-void launch_gn2d(const float* in, const float* gamma, const float* beta, const void* res, int relu, void* out, int B,
-                 int HW, int C, float eps, int prec, hipStream_t s) {
+void launch_gn2d(const float* in, int nslab, long long slab_stride, const float* gamma, const float* beta, const void* res,
+                 int relu, void* out, int B, int HW, int C, float eps, int prec, hipStream_t s) {
   dim3 grid((unsigned)(B * (C >> 4))), block(64);
-  if (prec == 0) hipLaunchKernelGGL(gn2d_kernel<0>, grid, block, 0, s, in, gamma, beta, res, relu, out, HW, C, eps);
-  else hipLaunchKernelGGL(gn2d_kernel<1>, grid, block, 0, s, in, gamma, beta, res, relu, out, HW, C, eps);
+  if (prec == 0) hipLaunchKernelGGL(gn2d_kernel<0>, grid, block, 0, s, in, nslab, slab_stride, gamma, beta, res, relu, out, HW, C, eps);
+  else hipLaunchKernelGGL(gn2d_kernel<1>, grid, block, 0, s, in, nslab, slab_stride, gamma, beta, res, relu, out, HW, C, eps);
 }
 
 // MaxPool2d(3, 2, 1) on NHWC.

@@ -70,6 +70,11 @@ def _bind(ctx, oracle_net, prec, B):
 
 
 LAYERS = [  # (engine buffer, oracle module path)
+    ("enc.pool", "encoder.resnet18.bn1"),            # placeholder path: replaced below by a functional tap
+    ("enc.l1.0.out", "encoder.resnet18.layer1.0"), ("enc.l1.1.out", "encoder.resnet18.layer1.1"),
+    ("enc.l2.0.out", "encoder.resnet18.layer2.0"), ("enc.l2.1.out", "encoder.resnet18.layer2.1"),
+    ("enc.l3.0.out", "encoder.resnet18.layer3.0"), ("enc.l3.1.out", "encoder.resnet18.layer3.1"),
+    ("enc.l4.0.out", "encoder.resnet18.layer4.0"), ("enc.l4.1.out", "encoder.resnet18.layer4.1"),
     ("map_emb", "encoder"), ("d0b1.out", "unet.down_modules.0.0"), ("skip0", "unet.down_modules.0.1"),
     ("d1.in", "unet.down_modules.0.2"), ("d1b1.out", "unet.down_modules.1.0"), ("skip1", "unet.down_modules.1.1"),
     ("d2.in", "unet.down_modules.1.2"), ("d2b1.out", "unet.down_modules.2.0"), ("skip2", "unet.down_modules.2.1"),
@@ -84,6 +89,8 @@ def _oracle_with_taps(net, noise, lm, cond):
     hooks = []
     mods = dict(net.named_modules())
     for name, path in LAYERS:
+        if name == "enc.pool":
+            continue
         m = mods[path]
         if path.endswith(".2"):          # _Down/_Up hold a conv child that is what gets called
             m = m.conv
@@ -103,9 +110,16 @@ def test_denoiser_layers_and_output(ctx, oracle_net, inputs, prec, tol):
     x1 = ctx.denoise(noise.cuda(), lm.cuda(), cond.cuda(), want_actions=False)
     report = {}
     for name, _ in LAYERS:
+        if name == "enc.pool":
+            continue
         got = ctx.debug_read(name, B).cpu().numpy()
         ref = taps[name].numpy()
-        ref = ref.reshape(B, 1, -1) if ref.ndim == 2 else np.transpose(ref, (0, 2, 1))     # (B,C,L) -> (B,L,C)
+        if ref.ndim == 2:
+            ref = ref.reshape(B, 1, -1)
+        elif ref.ndim == 4:                                                                  # (B,C,H,W) -> (B,HW,C)
+            ref = np.transpose(ref.reshape(B, ref.shape[1], -1), (0, 2, 1))
+        else:
+            ref = np.transpose(ref, (0, 2, 1))                                               # (B,C,L) -> (B,L,C)
         report[name] = rel(got, ref)
     report["x1"] = rel(x1.cpu().numpy(), x1_ref)
     os.makedirs(OUT, exist_ok=True)
