@@ -543,10 +543,9 @@ void DenoiserState::build(int prec_, int Bmax_) {
             const int per = (nk_total + sk - 1) / sk;
             sk = (nk_total + per - 1) / per;
           }
-          // measured on MI355X at B = 1024: split-K costs more (extra prologues / epilogues, slab traffic) than
-          // the added parallelism returns (30.5 vs 29.7 ms per round), so it is opt-in: DITREE_SPLITK=1
+          // measured on MI355X at B = 1024: 28.2 ms per round with split-K vs 29.6 without; DITREE_SPLITK=0 disables
           static int use_split = -1;
-          if (use_split < 0) { const char* e = getenv("DITREE_SPLITK"); use_split = (e && atoi(e)) ? 1 : 0; }
+          if (use_split < 0) { const char* e = getenv("DITREE_SPLITK"); use_split = (e && !atoi(e)) ? 0 : 1; }
           if (!use_split) sk = 1;
           p.splitk = sk;
           p.slab_stride = (long long)M * Cout;

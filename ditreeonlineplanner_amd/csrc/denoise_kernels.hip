@@ -72,7 +72,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // tile channel wn*128 + 4*r5 + j.  `smem` must be free for reuse (callers barrier first).
 template <int PREC>
 __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t (&acc)[2][4], char* smem, int tm, int tn,
-                                              int tid, int lane, int r5, int h, int wm, int wn) {
+                                              int tid, int lane, int r5, int h, int wm, int wn,
+                                              long long out_extra_bytes = 0) {
 
   // ---- epilogue ---------------------------------------------------------------------------
   const int c_l = wn * 128 + 4 * r5;                          // lane's 4 consecutive channels in the tile
@@ -246,12 +247,12 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
       const long long oidx = orow * p.ldc + p.out_coff + n0;
       if (p.out_f32 || PREC == 1) {
         f32x4_t o = {v[0], v[1], v[2], v[3]};
-        *(f32x4_t*)((char*)p.Out + oidx * 4) = o;
+        *(f32x4_t*)((char*)p.Out + out_extra_bytes + oidx * 4) = o;
       } else {
         short4_t o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (short)f2bf(v[j]);
-        *(short4_t*)((char*)p.Out + oidx * 2) = o;
+        *(short4_t*)((char*)p.Out + out_extra_bytes + oidx * 2) = o;
       }
     }
   }
@@ -275,13 +276,14 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
   const int kpt = p.Cin / EK;                      // K-steps per tap
   int nk = K / EK;
   int k_first = 0;                                 // split-K (implicit Conv2d): this block's K-step range
+  long long out_extra = 0;
   if constexpr (C2D) {
     if (p.splitk > 1) {
       const int per = (nk + p.splitk - 1) / p.splitk;
       k_first = blockIdx.y * per;
       nk = min(nk - k_first, per);
-      p.Out = (char*)p.Out + (long long)blockIdx.y * p.slab_stride * 4;
-    }
+      out_extra = (long long)blockIdx.y * p.slab_stride * 4;     // never write to `p`: a modified kernarg struct is
+    }                                                            // copied to scratch and every later read spills
   }
 
   // ---- per-lane staging sources (byte offsets) ------------------------------------------
@@ -453,7 +455,7 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
   __syncthreads();
   kstep(smem + ((nk - 1) & 1) * 65536, std::false_type{}, nullptr);
   __syncthreads();                                            // all fragment reads done: LDS reusable
-  gemm_epilogue<PREC>(p, acc, smem, tm, tn, tid, lane, r5, h, wm, wn);
+  gemm_epilogue<PREC>(p, acc, smem, tm, tn, tid, lane, r5, h, wm, wn, out_extra);
 }
 
 // =================================================================================================
