@@ -195,30 +195,70 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
 
     }
 
-    f32x4_t gam = *(const f32x4_t*)(p.gamma + n0);
-    f32x4_t bet = *(const f32x4_t*)(p.beta + n0);
+    // normalise + Mish (+ FiLM | + residual) and store, one 16-row block at a time; the residual rows of
+    // the next block are fetched while the current one is processed (bf16: 8 x 8 B per lane in flight)
+    const f32x4_t gam = *(const f32x4_t*)(p.gamma + n0);
+    const f32x4_t bet = *(const f32x4_t*)(p.beta + n0);
+    short4_t resv[2][8];
+    auto fetch_res = [&](int blk, short4_t (&dst)[8]) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rofs = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const long long rrow = (long long)blk_b[blk] * p.res_Lp + blk_l[blk] + rofs + p.res_off;
+        dst[i] = *(const short4_t*)((const char*)p.Res + (rrow * p.ldres + n0) * 2);
+      }
+    };
+    const bool res_bf16 = (PREC == 0) && p.mode == MODE_GN_MISH_RES;
+    if (res_bf16) fetch_res(0, resv[0]);
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
+      if (res_bf16 && blk < 3) fetch_res(blk + 1, resv[(blk + 1) & 1]);
       f32x4_t fs = {1.f, 1.f, 1.f, 1.f}, fb = {0.f, 0.f, 0.f, 0.f};
       if (p.mode == MODE_GN_MISH_FILM) {
         const float* fr = p.film + (long long)blk_b[blk] * p.film_ld + p.film_off + n0;
         fs = *(const f32x4_t*)fr;
         fb = *(const f32x4_t*)(fr + p.N);
       }
+      float ga[4], be[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float ga = gam[j] * rstd[blk], be = bet[j] - mean[blk] * ga;
+      for (int j = 0; j < 4; ++j) { ga[j] = gam[j] * rstd[blk]; be[j] = bet[j] - mean[blk] * ga[j]; }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float v = acc[blk >> 1][j][(blk & 1) * 8 + i];
-          v = mish_f<PREC>(v * ga + be);
-          acc[blk >> 1][j][(blk & 1) * 8 + i] = v * fs[j] + fb[j];
+      for (int i = 0; i < 8; ++i) {
+        const int ii = (blk & 1) * 8 + i;
+        const int rofs = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int b = blk_b[blk], l = blk_l[blk] + rofs;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = mish_f<PREC>(acc[blk >> 1][j][ii] * ga[j] + be[j]) * fs[j] + fb[j];
+        if (p.mode == MODE_GN_MISH_RES) {
+          if constexpr (PREC == 0) {
+            const short4_t rv = resv[blk & 1][i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += bf2f((unsigned short)rv[j]);
+          } else {
+            const long long rrow = (long long)b * p.res_Lp + l + p.res_off;
+            const f32x4_t rv = *(const f32x4_t*)((const char*)p.Res + (rrow * p.ldres + n0) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += rv[j];
+          }
+        }
+        const long long orow = (long long)b * p.out_Lp + (long long)l * p.out_stride + p.out_off;
+        const long long oidx = orow * p.ldc + p.out_coff + n0;
+        if constexpr (PREC == 1) {
+          const f32x4_t o = {v[0], v[1], v[2], v[3]};
+          *(f32x4_t*)((char*)p.Out + out_extra_bytes + oidx * 4) = o;
+        } else {
+          short4_t o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (short)f2bf(v[j]);
+          *(short4_t*)((char*)p.Out + out_extra_bytes + oidx * 2) = o;
         }
       }
     }
+    return;
   }
 
-  // ---- store (+ residual) --------------------------------------------------------------------
+  // ---- plain store (MODE_BIAS; ragged M / N allowed) ------------------------------------------------
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk) {
 #pragma unroll
@@ -228,30 +268,15 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
       const int m = tm * 256 + wm * 64 + (blk >> 1) * 32 + (blk & 1) * 16 + rofs;
       if (m >= p.M || !n_ok) continue;
       const int b = blk_b[blk], l = blk_l[blk] + rofs;
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[blk >> 1][j][ii];
-      if (p.mode == MODE_GN_MISH_RES) {
-        const long long rrow = (long long)b * p.res_Lp + l + p.res_off;
-        if constexpr (PREC == 0) {
-          short4_t rv = *(const short4_t*)((const char*)p.Res + (rrow * p.ldres + n0) * 2);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += bf2f((unsigned short)rv[j]);
-        } else {
-          f32x4_t rv = *(const f32x4_t*)((const char*)p.Res + (rrow * p.ldres + n0) * 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += rv[j];
-        }
-      }
       const long long orow = (long long)b * p.out_Lp + (long long)l * p.out_stride + p.out_off;
       const long long oidx = orow * p.ldc + p.out_coff + n0;
       if (p.out_f32 || PREC == 1) {
-        f32x4_t o = {v[0], v[1], v[2], v[3]};
+        const f32x4_t o = {acc[blk >> 1][0][ii], acc[blk >> 1][1][ii], acc[blk >> 1][2][ii], acc[blk >> 1][3][ii]};
         *(f32x4_t*)((char*)p.Out + out_extra_bytes + oidx * 4) = o;
       } else {
         short4_t o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (short)f2bf(v[j]);
+        for (int j = 0; j < 4; ++j) o[j] = (short)f2bf(acc[blk >> 1][j][ii]);
         *(short4_t*)((char*)p.Out + out_extra_bytes + oidx * 2) = o;
       }
     }
