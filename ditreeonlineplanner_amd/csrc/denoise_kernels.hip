@@ -106,6 +106,30 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
     float* s_sum = (float*)smem;                              // [16 slots][4 groups]
     float* s_sq = s_sum + 64;
     if (tid < 128) s_sum[tid] = 0.0f;
+    // per-channel / per-sample epilogue operands are requested before the statistics so that their
+    // latency hides under the reductions
+    const f32x4_t gam = *(const f32x4_t*)(p.gamma + n0);
+    const f32x4_t bet = *(const f32x4_t*)(p.beta + n0);
+    f32x4_t film_s[4], film_b[4];
+    if (p.mode == MODE_GN_MISH_FILM) {
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        const float* fr = p.film + (long long)blk_b[blk] * p.film_ld + p.film_off + n0;
+        film_s[blk] = *(const f32x4_t*)fr;
+        film_b[blk] = *(const f32x4_t*)(fr + p.N);
+      }
+    }
+    short4_t resv[2][8];
+    auto fetch_res = [&](int blk, short4_t (&dst)[8]) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rofs = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const long long rrow = (long long)blk_b[blk] * p.res_Lp + blk_l[blk] + rofs + p.res_off;
+        dst[i] = *(const short4_t*)((const char*)p.Res + (rrow * p.ldres + n0) * 2);
+      }
+    };
+    const bool res_bf16 = (PREC == 0) && p.mode == MODE_GN_MISH_RES;
+    if (res_bf16) fetch_res(0, resv[0]);
     __syncthreads();
     const int spt = 256 / p.L;                                // sample slots per tile
     const int gi = c_l / p.group_ch;                          // lane's group within the tile
@@ -197,28 +221,11 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
 
     // normalise + Mish (+ FiLM | + residual) and store, one 16-row block at a time; the residual rows of
     // the next block are fetched while the current one is processed (bf16: 8 x 8 B per lane in flight)
-    const f32x4_t gam = *(const f32x4_t*)(p.gamma + n0);
-    const f32x4_t bet = *(const f32x4_t*)(p.beta + n0);
-    short4_t resv[2][8];
-    auto fetch_res = [&](int blk, short4_t (&dst)[8]) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rofs = (i & 3) + 8 * (i >> 2) + 4 * h;
-        const long long rrow = (long long)blk_b[blk] * p.res_Lp + blk_l[blk] + rofs + p.res_off;
-        dst[i] = *(const short4_t*)((const char*)p.Res + (rrow * p.ldres + n0) * 2);
-      }
-    };
-    const bool res_bf16 = (PREC == 0) && p.mode == MODE_GN_MISH_RES;
-    if (res_bf16) fetch_res(0, resv[0]);
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
       if (res_bf16 && blk < 3) fetch_res(blk + 1, resv[(blk + 1) & 1]);
       f32x4_t fs = {1.f, 1.f, 1.f, 1.f}, fb = {0.f, 0.f, 0.f, 0.f};
-      if (p.mode == MODE_GN_MISH_FILM) {
-        const float* fr = p.film + (long long)blk_b[blk] * p.film_ld + p.film_off + n0;
-        fs = *(const f32x4_t*)fr;
-        fb = *(const f32x4_t*)(fr + p.N);
-      }
+      if (p.mode == MODE_GN_MISH_FILM) { fs = film_s[blk]; fb = film_b[blk]; }
       float ga[4], be[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ga[j] = gam[j] * rstd[blk]; be[j] = bet[j] - mean[blk] * ga[j]; }
