@@ -85,6 +85,7 @@ int32_t ditree_nn_argmin(ditree_ctx* ctx, const double* queries, int32_t q_strid
                          const uint8_t* node_has_prev, double* out_state, double* out_prev_action,
                          uint8_t* out_has_prev, void* stream) {
   if (!ctx) return DITREE_E_ARG;
+  if (B == 0) return DITREE_OK;                       // empty batch: nothing to do (pointers may be null)
   if (!queries || !node_xy || !out_idx || B < 0 || N <= 0 || q_stride < 2)
     return set_err(ctx, DITREE_E_ARG, "nn_argmin: bad argument");
   if (node_state && (!node_last_action || !node_has_prev || !out_state || !out_prev_action || !out_has_prev))
@@ -107,6 +108,7 @@ int32_t ditree_local_map(ditree_ctx* ctx, const double* state, const int32_t* ac
                          const double* axis, double s_global, int32_t scaled, float* out, void* stream) {
   if (!ctx) return DITREE_E_ARG;
   if (!ctx->maze) return set_err(ctx, DITREE_E_STATE, "local_map: no maze uploaded");
+  if (B == 0) return DITREE_OK;
   if (!state || !out || B < 0) return set_err(ctx, DITREE_E_ARG, "local_map: bad argument");
   AxisArg a;
   int rc = fill_axis(ctx, axis, n, &a);
@@ -129,6 +131,7 @@ int32_t ditree_cond_vector(ditree_ctx* ctx, const double* state, const double* p
                            const double* cond_goal, int32_t B, const double* norm, double local_map_size, float* out,
                            void* stream) {
   if (!ctx) return DITREE_E_ARG;
+  if (B == 0) return DITREE_OK;
   if (!state || !prev_action || !has_prev || !cond_goal || !norm || !out || B < 0)
     return set_err(ctx, DITREE_E_ARG, "cond_vector: bad argument");
   if (B == 0) return DITREE_OK;
@@ -145,6 +148,7 @@ int32_t ditree_car_rollout(ditree_ctx* ctx, double* state_io, const double* acti
                            double* prev_action_io, uint8_t* has_prev_io, void* stream) {
   if (!ctx) return DITREE_E_ARG;
   if (!ctx->maze) return set_err(ctx, DITREE_E_STATE, "car_rollout: no maze uploaded");
+  if (B == 0) return DITREE_OK;
   if (!state_io || !actions || !status_io || !goal_xy || B < 0 || A <= 0 || act_stride < 2 * (int64_t)A)
     return set_err(ctx, DITREE_E_ARG, "car_rollout: bad argument");
   if (states_out && states_stride < 6 * (int64_t)(A + 1)) return set_err(ctx, DITREE_E_ARG, "car_rollout: states_stride");
@@ -161,6 +165,7 @@ int32_t ditree_lidar_scan(ditree_ctx* ctx, const double* poses, int32_t B, const
                           int32_t cols, double* dist, double* endpoints, uint8_t* hit, uint8_t* visited,
                           void* stream) {
   if (!ctx) return DITREE_E_ARG;
+  if (B == 0) return DITREE_OK;
   if (!poses || !maze || !dist || !endpoints || !hit || B < 0 || rows <= 0 || cols <= 0 ||
       (int64_t)rows * cols > 30000)
     return set_err(ctx, DITREE_E_ARG, "lidar_scan: bad argument (rows*cols <= 30000)");
