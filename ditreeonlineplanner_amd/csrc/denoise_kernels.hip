@@ -444,6 +444,16 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
           for (int j = 0; j < 4; ++j)
             acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][mb], bfr[ks & 1][j], acc[mb][j], 0, 0, 0);
       }
+      // pin the order: the next tile's LDS-DMA first (it has the whole step to land), then for every
+      // sub-step the reads of the following one ahead of its own 8 MFMAs (true fragment double buffering;
+      // left alone hipcc sinks the reads behind the MFMAs and waits for LDS in front of every group)
+      if constexpr (STAGE) __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      }
     } else {
 #pragma unroll
       for (int sl = 0; sl < 8; ++sl) {                       // 16-B slot = 4 floats = k 4*sl .. 4*sl+3
@@ -521,10 +531,14 @@ __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
   const int nc = p.Cin >> 6;
   const long long K = 3LL * p.Cin;
 
-  // ---- staging sources: wave-uniform base + 32-bit per-lane byte offsets ---------------------------
+  // ---- staging sources: buffer addressing -- a wave-uniform descriptor per operand (SGPRs), a 32-bit
+  // per-lane byte offset (9 VGPRs in all) and a wave-uniform scalar offset per K-step; no 64-bit
+  // vector pointers are kept live across the loop
   unsigned pa[5], pb[4];
   const char* const a_base = (const char*)p.A + ((long long)tm * S * Lp + p.in_off) * p.lda * 2;
   const char* const w_base = (const char*)p.W + ((long long)tn * 256) * K * 2;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const int r = (w + 8 * i) * 8 + (lane >> 3);                     // LDS row of the A block
@@ -539,16 +553,14 @@ __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
     const int c = (r & 128) + 4 * (r & 31) + ((r >> 5) & 3);
     pb[q] = (unsigned)(((long long)c * K + slot * 8) * 2);
   }
-  const long long w_tap = (long long)p.Cin * 2;                      // bytes between taps in a weight row
+  const int w_tap = p.Cin * 2;                                       // bytes between taps in a weight row
   auto issue_a = [&](int c, int i) {                                 // piece i of chunk c
-    const char* sbase = a_base + (long long)c * 128;
-    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(sbase + pa[i]),
-                                     (LDS_AS void*)(smem + (c & 1) * A_BUF + (w + 8 * i) * 1024), 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (LDS_AS void*)(smem + (c & 1) * A_BUF + (w + 8 * i) * 1024), 16,
+                                             pa[i], c * 128, 0, 0);
   };
   auto issue_w = [&](int c, int t, int q) {                          // piece q of step (c, t)
-    const char* sbase = w_base + (long long)c * 128 + t * w_tap;
-    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(sbase + pb[q]),
-                                     (LDS_AS void*)(smem + W_BASE + ((c + t) & 1) * W_BUF + (w * 4 + q) * 1024), 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (LDS_AS void*)(smem + W_BASE + ((c + t) & 1) * W_BUF + (w * 4 + q) * 1024),
+                                             16, pb[q], c * 128 + t * w_tap, 0, 0);
   };
 
   // ---- fragment addressing ---------------------------------------------------------------------
@@ -613,6 +625,16 @@ __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
       rd(1, c, T, 3);
       mm8(0);
     }
+    // Pin the issue order the pipeline is built on (hipcc otherwise sinks every fragment read behind the
+    // MFMAs that free its registers and then waits for LDS in front of each MFMA group):
+    // ks0..ks2: the 6 reads of the next sub-step first, then the 8 MFMAs of the current one.
+    if constexpr (DBG == 0 || DBG == 3) {
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      }
+    }
     if constexpr (HAS_NEXT) {
       // this wave's reads of W(s) / A(c) are complete, the DMA of step s+1 has landed
       if constexpr (VM == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -629,9 +651,20 @@ __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
       for (int j = 0; j < 4; ++j) {
         if constexpr (DBG != 2) mm(1, mb, j);
         const int i = mb * 4 + j;
-        if constexpr (ISSUE_W && DBG != 1 ) { if (i < 4) issue_w(c2, T2, i); }
-        if constexpr (ISSUE_A && DBG != 1 ) { if (i >= 3) issue_a(c + 2, i - 3); }
+        if constexpr (ISSUE_W && DBG != 1) { if (i < 4) issue_w(c2, T2, i); }
+        if constexpr (ISSUE_A && DBG != 1) { if (i >= 3) issue_a(c + 2, i - 3); }
       }
+    // after the barrier: the 6 reads of the next K-step first, then MFMA : LDS-DMA interleaved
+    if constexpr (DBG == 0 || DBG == 3) {
+      if constexpr (HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 6, 1);
+      constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? 5 : 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        if (i < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+      }
+      if constexpr (NV > 8) __builtin_amdgcn_sched_group_barrier(0x020, NV - 8, 1);
+    }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
