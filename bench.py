@@ -115,9 +115,12 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local)
     pg = None
-    if world > 1:
+    force_dist = world == 1 and os.environ.get("DITREE_FORCE_DIST", "0") == "1"     # RCCL path on a single GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")          # keep RCCL's banner off stdout: rank 0 prints one JSON line
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from ditreeonlineplanner_amd import _lib
@@ -134,6 +137,7 @@ def main():
     net.bind(ctx, precision=_lib.PREC_BF16, max_batch=Bper)
     eng = ExpansionEngine(ctx, maze, nodes[0], goal, edge_length=H, action_horizon=A, pred_horizon=P, batch=Btot,
                           capacity=N0 + Btot, rank=rank, world_size=world, emulate_sticky_done=False)
+    eng.force_allgather = force_dist
     dev = ctx.device
     t = eng.tree
     nd = torch.as_tensor(nodes, device=dev)
@@ -216,7 +220,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(maze, nodes, goal, samples, cond, noise, net.state_dict())
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -628,7 +628,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
     // Pin the issue order the pipeline is built on (hipcc otherwise sinks every fragment read behind the
     // MFMAs that free its registers and then waits for LDS in front of each MFMA group):
     // ks0..ks2: the 6 reads of the next sub-step first, then the 8 MFMAs of the current one.
-    if constexpr (DBG == 0 || DBG == 3) {
+    if constexpr (DBG == 0) {
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
         __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
         if constexpr (ISSUE_A && DBG != 1) { if (i >= 3) issue_a(c + 2, i - 3); }
       }
     // after the barrier: the 6 reads of the next K-step first, then MFMA : LDS-DMA interleaved
-    if constexpr (DBG == 0 || DBG == 3) {
+    if constexpr (DBG == 0) {
       if constexpr (HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 6, 1);
       constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? 5 : 0);
 #pragma unroll
@@ -704,13 +704,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
     step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, c);
   }
   __syncthreads();
-  if constexpr (DBG == 3) {
-    ConvGemmParams q = p;
-    q.mode = MODE_BIAS;                               // ablation: plain store, no GroupNorm / Mish / FiLM / residual
-    gemm_epilogue<0>(q, acc, smem, tm, tn, tid, lane, r5, h, wm, wn);
-  } else {
-    gemm_epilogue<0>(p, acc, smem, tm, tn, tid, lane, r5, h, wm, wn);
-  }
+  gemm_epilogue<0>(p, acc, smem, tm, tn, tid, lane, r5, h, wm, wn);
 }
 
 static bool halo_eligible(const ConvGemmParams& p, int prec) {
@@ -741,12 +735,10 @@ void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s) {
       hipFuncSetAttribute((const void*)conv3_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
       hipFuncSetAttribute((const void*)conv3_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
       hipFuncSetAttribute((const void*)conv3_halo_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
-      hipFuncSetAttribute((const void*)conv3_halo_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
       attr2 = true;
     }
     if (dbg == 1) hipLaunchKernelGGL(conv3_halo_kernel<1>, grid, block, 147456, s, p);
     else if (dbg == 2) hipLaunchKernelGGL(conv3_halo_kernel<2>, grid, block, 147456, s, p);
-    else if (dbg == 3) hipLaunchKernelGGL(conv3_halo_kernel<3>, grid, block, 147456, s, p);
     else hipLaunchKernelGGL(conv3_halo_kernel<0>, grid, block, 147456, s, p);
     return;
   }

@@ -101,17 +101,40 @@ def allgather_round_fields(fields, per, rank, world, group=None):
     """
     import torch.distributed as dist
     backend = dist.get_backend(group)
+    pairs = []
     for t in fields:
         if t.shape[0] < per * world:
             raise ValueError("round buffers must hold ceil(B / world) * world candidates")
         flat = t[: per * world]
-        mine = flat[rank * per:(rank + 1) * per]
-        if backend == "gloo" and flat.is_cuda:
-            host = torch.empty(flat.shape, dtype=flat.dtype)
-            dist.all_gather_into_tensor(host, mine.cpu().contiguous(), group=group)
-            flat.copy_(host)
-        else:
-            dist.all_gather_into_tensor(flat, mine.clone(), group=group)
+        pairs.append((flat, flat[rank * per:(rank + 1) * per]))
+    if backend == "gloo":
+        for flat, mine in pairs:
+            if flat.is_cuda:
+                host = torch.empty(flat.shape, dtype=flat.dtype)
+                dist.all_gather_into_tensor(host, mine.cpu().contiguous(), group=group)
+                flat.copy_(host)
+            else:
+                dist.all_gather_into_tensor(flat, mine.clone(), group=group)
+        return
+    # RCCL: seven small collectives per round (measured 0.4 ms of a 26 ms round on one MI355X).  With
+    # DITREE_COALESCE=1 they are issued as one grouped launch through torch's coalescing manager
+    # (no measurable gain on one GPU, so the plain, universally supported calls are the default).
+    import os
+    sends = [mine.clone() for _, mine in pairs]
+    cm = getattr(dist, "_coalescing_manager", None) if os.environ.get("DITREE_COALESCE", "0") == "1" else None
+    if cm is not None and not _COALESCE_BROKEN[0]:
+        try:
+            with cm(group=group, device=pairs[0][0].device, async_ops=False):
+                for (flat, _), snd in zip(pairs, sends):
+                    dist.all_gather_into_tensor(flat, snd, group=group)
+            return
+        except Exception:                              # pragma: no cover - depends on the torch build
+            _COALESCE_BROKEN[0] = True
+    for (flat, _), snd in zip(pairs, sends):
+        dist.all_gather_into_tensor(flat, snd, group=group)
+
+
+_COALESCE_BROKEN = [False]
 
 
 class ExpansionEngine:
@@ -131,6 +154,7 @@ class ExpansionEngine:
         self.sticky = int(bool(emulate_sticky_done))
         self.norm = np.ascontiguousarray(CAR_NORM if norm is None else norm, dtype=np.float64)
         self.rank, self.world, self.pg = rank, world_size, process_group
+        self.force_allgather = False        # run the collective even with one rank (exercises the RCCL path on 1 GPU)
         self.tree = DeviceTree(ctx, capacity, self.n_chunks, self.A)
         self.rb = RoundBuffers(ctx, batch, self.n_chunks, self.A)
         self.axis = local_axis(local_map_size, local_map_scale)
@@ -189,7 +213,7 @@ class ExpansionEngine:
             rd = self.rb.desc(lo, n)
             check(self.ctx._h, lib().ditree_expand_round(self.ctx._h, C.byref(self.tree.desc), C.byref(rd),
                                                           C.byref(rp), self.ctx.stream), "expand_round")
-        if self.world > 1:
+        if self.world > 1 or self.force_allgather:
             self._allgather_round(B, per)
         if accept:
             return self.accept(B)
