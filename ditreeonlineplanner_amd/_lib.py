@@ -44,7 +44,7 @@ class RoundParams(C.Structure):
                 ("noise", C.c_void_p), ("inject_actions", C.c_void_p), ("P", C.c_int32), ("K", C.c_int32),
                 ("t0", C.POINTER(C.c_float)), ("dt", C.POINTER(C.c_float)), ("norm", C.POINTER(C.c_double)),
                 ("goal_xy", C.POINTER(C.c_double)), ("axis", C.POINTER(C.c_double)), ("lm_n", C.c_int32),
-                ("lm_size", C.c_double), ("s_global", C.c_double)]
+                ("lm_size", C.c_double), ("s_global", C.c_double), ("early_exit", C.c_int32)]
 
 
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double

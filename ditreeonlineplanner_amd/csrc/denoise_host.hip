@@ -534,9 +534,11 @@ void DenoiserState::build(int prec_, int Bmax_) {
           p.c2d = 1; p.c2_H = H; p.c2_W = H; p.c2_OW = OH; p.c2_OHW = OH * OH; p.c2_stride = stride; p.c2_pad = pad;
           for (int t = 0; t < tl.n; ++t) { p.c2_kh[t] = tl.kh[t]; p.c2_kw[t] = tl.kw[t]; }
           p.zero = zr;
-          // split-K: these layers have few tiles and long K loops; spread the K-steps over idle CUs
+          // split-K: these layers have few tiles and long K loops; spread the K-steps over idle CUs.  The
+          // factor depends on the layer only (sized for 1024 candidates), never on the batch, so that a
+          // candidate's result does not depend on which other candidates share its launch (bitwise).
           const int nk_total = tl.n * (Cin / 64);
-          const int tiles = ((M + 255) / 256) * ((Cout + 255) / 256);
+          const int tiles = ((1024 * OH * OH + 255) / 256) * ((Cout + 255) / 256);
           int sk = std::max(1, std::min(std::min(8, nk_total / 2), std::max(1, 160 / tiles)));
           while (sk > 1 && (size_t)sk * OH * OH * Cout > gout_per_sample) --sk;
           if (sk > 1) {                                   // every split must own at least one K-step
@@ -683,9 +685,9 @@ static int parse_manifest(DenoiserState* st, const char* manifest, int64_t n_flo
   return 0;
 }
 
-int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const float* local_map, const float* cond,
-                int B, int K, const float* t0, const float* dt, const double* act_norm, double* actions, float* x_out,
-                hipStream_t s) {
+int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const int32_t* noise_idx, const float* local_map,
+                const float* cond, int B, int K, const float* t0, const float* dt, const double* act_norm, double* actions,
+                float* x_out, hipStream_t s) {
   DenoiserState* st = ctx->dn;
   if (!st || !st->loaded) return set_err(ctx, DITREE_E_STATE, "denoise: weights not loaded");
   if (st->prec < 0) return set_err(ctx, DITREE_E_STATE, "denoise: call ditree_denoise_reserve first");
@@ -697,8 +699,11 @@ int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const
   {
     const size_t row = (size_t)st->P * st->D * 4;         // one candidate's (P, D) f32 noise
     if (noise_stride < (int64_t)st->P * st->D) return set_err(ctx, DITREE_E_ARG, "denoise: noise stride");
-    HIP_TRY(ctx, hipMemcpy2DAsync(st->x_cur, row, noise, (size_t)noise_stride * 4, row, (size_t)B,
-                                  hipMemcpyDeviceToDevice, s));
+    if (noise_idx)                                       // compacted round: row r takes candidate noise_idx[r]'s noise
+      launch_gather_rows_f32(noise, noise_stride, noise_idx, st->x_cur, st->P * st->D, B, s);
+    else
+      HIP_TRY(ctx, hipMemcpy2DAsync(st->x_cur, row, noise, (size_t)noise_stride * 4, row, (size_t)B,
+                                    hipMemcpyDeviceToDevice, s));
   }
   st->lm_ptr = local_map;
   {
@@ -827,7 +832,7 @@ int32_t ditree_denoise(ditree_ctx* ctx, const float* noise, const float* local_m
                        float* x_out, void* stream) {
   if (!ctx) return DITREE_E_ARG;
   if (!ctx->dn) return set_err(ctx, DITREE_E_STATE, "denoise: weights not loaded");
-  return denoise_run(ctx, noise, (int64_t)ctx->dn->P * ctx->dn->D, local_map, cond, B, K, t0, dt, act_norm, actions, x_out,
+  return denoise_run(ctx, noise, (int64_t)ctx->dn->P * ctx->dn->D, nullptr, local_map, cond, B, K, t0, dt, act_norm, actions, x_out,
                      (hipStream_t)stream);
 }
 

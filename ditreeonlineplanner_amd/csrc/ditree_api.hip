@@ -9,10 +9,10 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
                            int64_t act_stride, int32_t* status_io, int B, int A, double gx, double gy,
                            double* states_out, int64_t states_stride, double* actions_out, int64_t actout_stride,
                            int32_t* steps_out, int64_t steps_stride, int32_t* chunks_run, double* prev_action_io,
-                           uint8_t* has_prev_io, hipStream_t s);
-int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const float* local_map, const float* cond,
-                int B, int K, const float* t0, const float* dt, const double* act_norm, double* actions, float* x_out,
-                hipStream_t s);
+                           uint8_t* has_prev_io, const int32_t* idx, int act_dense, hipStream_t s);
+int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const int32_t* noise_idx, const float* local_map,
+                const float* cond, int B, int K, const float* t0, const float* dt, const double* act_norm, double* actions,
+                float* x_out, hipStream_t s);
 void denoise_destroy(ditree_ctx* ctx);
 
 int set_err(ditree_ctx* ctx, int code, const std::string& msg) {
@@ -48,6 +48,9 @@ void ditree_ctx_destroy(ditree_ctx* ctx) {
   if (ctx->lmap) hipFree(ctx->lmap);
   if (ctx->cond) hipFree(ctx->cond);
   if (ctx->act64) hipFree(ctx->act64);
+  if (ctx->alive_idx) hipFree(ctx->alive_idx);
+  if (ctx->alive_cnt) hipFree(ctx->alive_cnt);
+  if (ctx->alive_cnt_host) hipHostFree(ctx->alive_cnt_host);
   delete ctx;
 }
 
@@ -114,7 +117,7 @@ int32_t ditree_local_map(ditree_ctx* ctx, const double* state, const int32_t* ac
   int rc = fill_axis(ctx, axis, n, &a);
   if (rc) return rc;
   if (B == 0) return DITREE_OK;
-  launch_local_map(ctx->maze, ctx->rows, ctx->cols, state, active, B, n, a, s_global, scaled, out,
+  launch_local_map(ctx->maze, ctx->rows, ctx->cols, state, active, nullptr, B, n, a, s_global, scaled, out,
                    (hipStream_t)stream);
   HIP_TRY(ctx, hipGetLastError());
   return DITREE_OK;
@@ -137,7 +140,7 @@ int32_t ditree_cond_vector(ditree_ctx* ctx, const double* state, const double* p
   if (B == 0) return DITREE_OK;
   NormArg nm;
   fill_norm(norm, &nm);
-  launch_cond_vector(state, prev_action, has_prev, cond_goal, B, nm, local_map_size, out, (hipStream_t)stream);
+  launch_cond_vector(state, prev_action, has_prev, cond_goal, nullptr, B, nm, local_map_size, out, (hipStream_t)stream);
   HIP_TRY(ctx, hipGetLastError());
   return DITREE_OK;
 }
@@ -206,7 +209,7 @@ static int ensure_scratch(ditree_ctx* ctx, int B, int lm_n, int P) {
   if (B <= ctx->scratch_B && lm_n <= ctx->scratch_lm && P <= ctx->scratch_P) return DITREE_OK;
   HIP_TRY(ctx, hipDeviceSynchronize());
   void** ptrs[] = {(void**)&ctx->cur_state, (void**)&ctx->prev_action, (void**)&ctx->has_prev, (void**)&ctx->lmap,
-                   (void**)&ctx->cond, (void**)&ctx->act64};
+                   (void**)&ctx->cond, (void**)&ctx->act64, (void**)&ctx->alive_idx, (void**)&ctx->alive_cnt};
   for (auto p : ptrs) {
     if (*p) HIP_TRY(ctx, hipFree(*p));
     *p = nullptr;
@@ -220,6 +223,9 @@ static int ensure_scratch(ditree_ctx* ctx, int B, int lm_n, int P) {
   HIP_TRY(ctx, hipMalloc((void**)&ctx->lmap, (size_t)nb * nl * nl * sizeof(float)));
   HIP_TRY(ctx, hipMalloc((void**)&ctx->cond, (size_t)nb * 7 * sizeof(float)));
   HIP_TRY(ctx, hipMalloc((void**)&ctx->act64, (size_t)nb * np * 2 * sizeof(double)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->alive_idx, (size_t)nb * sizeof(int32_t)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->alive_cnt, 16));
+  if (!ctx->alive_cnt_host) HIP_TRY(ctx, hipHostMalloc((void**)&ctx->alive_cnt_host, 16, hipHostMallocDefault));
   ctx->scratch_B = nb;
   ctx->scratch_lm = nl;
   ctx->scratch_P = np;
@@ -253,28 +259,42 @@ int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditr
   launch_nn_argmin(p->samples, 6, B, tree->xy, p->n_nodes, round->parent, tree->state, tree->last_action,
                    tree->has_prev, ctx->cur_state, ctx->prev_action, ctx->has_prev, s);
   const int64_t st_stride = (int64_t)nC * (A + 1) * 6, ac_stride = (int64_t)nC * A * 2;
-  for (int j = 0; j < nC; ++j) {
+  // Early exit (p->early_exit): after every chunk the still-alive candidates are compacted into an index
+  // list and the next chunk's map / conditioning / denoiser / rollout run on those rows only -- what the
+  // reference does by abandoning a collided edge (planners/RRT.py:179-184).  Costs one 4-byte D2H per chunk.
+  int n_run = B;                              // rows processed in the current chunk
+  const int32_t* idx = nullptr;               // nullptr = identity (chunk 0, or early exit disabled)
+  for (int j = 0; j < nC && n_run > 0; ++j) {
     const double* acts;
     int64_t act_stride;
+    int act_dense = 1;
     if (p->inject_actions) {
       acts = p->inject_actions + (size_t)j * P * 2;
       act_stride = (int64_t)nC * P * 2;
+      act_dense = 0;                          // the tape is indexed by candidate
     } else {
-      launch_local_map(ctx->maze, ctx->rows, ctx->cols, ctx->cur_state, round->status, B, p->lm_n, ax, p->s_global,
-                       1, ctx->lmap, s);
-      launch_cond_vector(ctx->cur_state, ctx->prev_action, ctx->has_prev, p->cond_goal, B, nm, p->lm_size,
+      launch_local_map(ctx->maze, ctx->rows, ctx->cols, ctx->cur_state, round->status, idx, n_run, p->lm_n, ax,
+                       p->s_global, 1, ctx->lmap, s);
+      launch_cond_vector(ctx->cur_state, ctx->prev_action, ctx->has_prev, p->cond_goal, idx, n_run, nm, p->lm_size,
                          ctx->cond, s);
       double an[4] = {p->norm[12], p->norm[13], p->norm[14], p->norm[15]};
-      rc = denoise_run(ctx, p->noise + (size_t)j * P * 2, (int64_t)nC * P * 2, ctx->lmap, ctx->cond, B, p->K, p->t0,
-                       p->dt, an, ctx->act64, nullptr, s);
+      rc = denoise_run(ctx, p->noise + (size_t)j * P * 2, (int64_t)nC * P * 2, idx, ctx->lmap, ctx->cond, n_run, p->K,
+                       p->t0, p->dt, an, ctx->act64, nullptr, s);
       if (rc) return rc;
       acts = ctx->act64;
       act_stride = (int64_t)P * 2;
     }
-    launch_car_rollout_ex(ctx->maze, ctx->rows, ctx->cols, ctx->cur_state, acts, act_stride, round->status, B, A,
+    launch_car_rollout_ex(ctx->maze, ctx->rows, ctx->cols, ctx->cur_state, acts, act_stride, round->status, n_run, A,
                           p->goal_xy[0], p->goal_xy[1], round->states + (size_t)j * (A + 1) * 6, st_stride,
                           round->actions + (size_t)j * A * 2, ac_stride, round->chunk_steps + j, nC,
-                          round->chunks_run, ctx->prev_action, ctx->has_prev, s);
+                          round->chunks_run, ctx->prev_action, ctx->has_prev, idx, act_dense, s);
+    if (p->early_exit && j + 1 < nC) {
+      launch_compact_alive(round->status, B, ctx->alive_idx, ctx->alive_cnt, s);
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->alive_cnt_host, ctx->alive_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      HIP_TRY(ctx, hipStreamSynchronize(s));
+      n_run = *ctx->alive_cnt_host;
+      idx = ctx->alive_idx;
+    }
   }
   HIP_TRY(ctx, hipMemcpyAsync(round->end_state, ctx->cur_state, (size_t)B * 6 * sizeof(double),
                               hipMemcpyDeviceToDevice, s));

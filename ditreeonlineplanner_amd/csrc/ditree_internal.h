@@ -36,6 +36,9 @@ struct ditree_ctx {
   float* cond = nullptr;            // (B,7)
   double* act64 = nullptr;          // (B,P,2)
   int scratch_lm = 0, scratch_P = 0;
+  int32_t* alive_idx = nullptr;     // (B,) compacted candidate indices (early-exit rounds)
+  int32_t* alive_cnt = nullptr;     // device scalar
+  int32_t* alive_cnt_host = nullptr;  // pinned host copy
   DenoiserState* dn = nullptr;
 };
 
@@ -54,11 +57,14 @@ void launch_nn_argmin(const double* queries, int q_stride, int B, const double* 
                       const uint8_t* node_has_prev, double* out_state, double* out_prev_action,
                       uint8_t* out_has_prev, hipStream_t s);
 void launch_local_map(const unsigned char* maze, int rows, int cols, const double* state,
-                      const int32_t* active, int B, int n, const AxisArg& axis, double s_global,
-                      int scaled, float* out, hipStream_t s);
+                      const int32_t* active, const int32_t* idx, int B, int n, const AxisArg& axis,
+                      double s_global, int scaled, float* out, hipStream_t s);
 void launch_cond_vector(const double* state, const double* prev_action, const uint8_t* has_prev,
-                        const double* cond_goal, int B, const NormArg& nm, double lm_size, float* out,
-                        hipStream_t s);
+                        const double* cond_goal, const int32_t* idx, int B, const NormArg& nm, double lm_size,
+                        float* out, hipStream_t s);
+void launch_compact_alive(const int32_t* status, int B, int32_t* idx_out, int32_t* count, hipStream_t s);
+void launch_gather_rows_f32(const float* src, int64_t src_stride, const int32_t* idx, float* dst, int row_floats, int n,
+                            hipStream_t s);
 void launch_car_rollout(const unsigned char* maze, int rows, int cols, double* state_io,
                         const double* actions, int64_t act_stride, int32_t* status_io, int B, int A,
                         double gx, double gy, double* states_out, int64_t states_stride,

@@ -106,18 +106,19 @@ void launch_nn_argmin(const double* queries, int q_stride, int B, const double* 
 // One workgroup per candidate; maze staged in LDS; one thread per output cell.
 __global__ void __launch_bounds__(256)
 local_map_kernel(const unsigned char* __restrict__ maze, int rows, int cols, const double* __restrict__ state,
-                 const int32_t* __restrict__ active, int n, AxisArg axis, double s_global, int scaled,
-                 float* __restrict__ out) {
+                 const int32_t* __restrict__ active, const int32_t* __restrict__ idx, int n, AxisArg axis,
+                 double s_global, int scaled, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int b = blockIdx.x;
+  const int ob = blockIdx.x;                                        // dense output row
+  const int b = idx ? idx[ob] : ob;                                 // candidate (compacted rounds pass an index list)
   if (active != nullptr && active[b] != DITREE_ST_OK) return;      // block-uniform
   stage_maze(lds, maze, rows * cols);
   const double x = state[(size_t)b * 6 + 0], y = state[(size_t)b * 6 + 1], th = state[(size_t)b * 6 + 2];
   const double c = cos(th), sn = sin(th);
   // base_planner.py:113-114 with maze_size_scaling = 1: centre = (W/2, H/2); RRT.py:166
   const double cx = (double)cols / 2.0, cy = (double)rows / 2.0;
-  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
-    int i = idx / n, j = idx - i * n;                               // meshgrid: x_local[i][j] = xs[j], y_local = ys[i]
+  for (int cell = threadIdx.x; cell < n * n; cell += blockDim.x) {
+    int i = cell / n, j = cell - i * n;                             // meshgrid: x_local[i][j] = xs[j], y_local = ys[i]
     double xl = axis.v[j], yl = axis.v[i];
     double xg = c * xl - sn * yl + x;                               // map_utils.py:443
     double yg = sn * xl + c * yl + y;                               // :444
@@ -127,24 +128,27 @@ local_map_kernel(const unsigned char* __restrict__ maze, int rows, int cols, con
     int yi = (fy >= 0.0) ? ((fy < (double)rows) ? (int)fy : rows - 1) : 0;
     int xi = (fx >= 0.0) ? ((fx < (double)cols) ? (int)fx : cols - 1) : 0;
     float m = (float)lds[yi * cols + xi];
-    out[(size_t)b * n * n + idx] = scaled ? (m * 2.0f - 1.0f) : m;
+    out[(size_t)ob * n * n + cell] = scaled ? (m * 2.0f - 1.0f) : m;
   }
 }
 void launch_local_map(const unsigned char* maze, int rows, int cols, const double* state, const int32_t* active,
-                      int B, int n, const AxisArg& axis, double s_global, int scaled, float* out, hipStream_t s) {
+                      const int32_t* idx, int B, int n, const AxisArg& axis, double s_global, int scaled, float* out,
+                      hipStream_t s) {
   size_t lds = ((size_t)rows * cols + 15) & ~(size_t)15;
-  hipLaunchKernelGGL(local_map_kernel, dim3(B), dim3(256), lds, s, maze, rows, cols, state, active, n, axis,
+  hipLaunchKernelGGL(local_map_kernel, dim3(B), dim3(256), lds, s, maze, rows, cols, state, active, idx, n, axis,
                      s_global, scaled, out);
 }
 
 // ------------------------------------------------------------------------- conditioning vector
 __global__ void cond_vector_kernel(const double* __restrict__ state, const double* __restrict__ prev_action,
-                                   const uint8_t* __restrict__ has_prev, const double* __restrict__ cond_goal, int B,
-                                   NormArg nm, double lm_size, float* __restrict__ out) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+                                   const uint8_t* __restrict__ has_prev, const double* __restrict__ cond_goal,
+                                   const int32_t* __restrict__ idx, int B, NormArg nm, double lm_size,
+                                   float* __restrict__ out) {
+  const int ob = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ob >= B) return;
+  const int b = idx ? idx[ob] : ob;
   const double* st = state + (size_t)b * 6;
-  float* o = out + (size_t)b * 7;
+  float* o = out + (size_t)ob * 7;
   // fm_policy.py:76,108,110,112: normalise in f64, drop x,y,psi, cast to f32
 #pragma unroll
   for (int k = 0; k < 3; ++k) o[k] = (float)((st[3 + k] - nm.obs_mean[3 + k]) / nm.obs_std[3 + k]);
@@ -168,10 +172,10 @@ __global__ void cond_vector_kernel(const double* __restrict__ state, const doubl
   o[6] = tanhf(ry / sc);
 }
 void launch_cond_vector(const double* state, const double* prev_action, const uint8_t* has_prev,
-                        const double* cond_goal, int B, const NormArg& nm, double lm_size, float* out,
-                        hipStream_t s) {
+                        const double* cond_goal, const int32_t* idx, int B, const NormArg& nm, double lm_size,
+                        float* out, hipStream_t s) {
   hipLaunchKernelGGL(cond_vector_kernel, dim3((B + 255) / 256), dim3(256), 0, s, state, prev_action, has_prev,
-                     cond_goal, B, nm, lm_size, out);
+                     cond_goal, idx, B, nm, lm_size, out);
 }
 
 // ------------------------------------------------------------------------- collision
@@ -225,16 +229,17 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
                    int A, double gx, double gy, double* __restrict__ states_out, int64_t states_stride,
                    double* __restrict__ actions_out, int64_t actout_stride, int32_t* __restrict__ steps_out,
                    int64_t steps_stride, int32_t* __restrict__ chunks_run, double* __restrict__ prev_action_io,
-                   uint8_t* __restrict__ has_prev_io) {
+                   uint8_t* __restrict__ has_prev_io, const int32_t* __restrict__ idx, int act_dense) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   stage_maze(lds, maze, rows * cols);
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const int ob = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ob >= B) return;
+  const int b = idx ? idx[ob] : ob;                 // compacted rounds: actions are dense (row ob), the rest per candidate
   if (status_io[b] != DITREE_ST_OK) return;
   double s[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) s[k] = state_io[(size_t)b * 6 + k];
-  const double* act = actions + (size_t)b * act_stride;
+  const double* act = actions + (size_t)(act_dense ? ob : b) * act_stride;
   double* so = states_out ? states_out + (size_t)b * states_stride : nullptr;
   double* ao = actions_out ? actions_out + (size_t)b * actout_stride : nullptr;
   if (so) {
@@ -312,11 +317,11 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
                            int64_t act_stride, int32_t* status_io, int B, int A, double gx, double gy,
                            double* states_out, int64_t states_stride, double* actions_out, int64_t actout_stride,
                            int32_t* steps_out, int64_t steps_stride, int32_t* chunks_run, double* prev_action_io,
-                           uint8_t* has_prev_io, hipStream_t s) {
+                           uint8_t* has_prev_io, const int32_t* idx, int act_dense, hipStream_t s) {
   size_t lds = ((size_t)rows * cols + 15) & ~(size_t)15;
   hipLaunchKernelGGL(car_rollout_kernel, dim3((B + 255) / 256), dim3(256), lds, s, maze, rows, cols, state_io,
                      actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out,
-                     actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io);
+                     actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense);
 }
 void launch_car_rollout(const unsigned char* maze, int rows, int cols, double* state_io, const double* actions,
                         int64_t act_stride, int32_t* status_io, int B, int A, double gx, double gy,
@@ -324,7 +329,7 @@ void launch_car_rollout(const unsigned char* maze, int rows, int cols, double* s
                         int32_t* steps_out, double* prev_action_io, uint8_t* has_prev_io, hipStream_t s) {
   launch_car_rollout_ex(maze, rows, cols, state_io, actions, act_stride, status_io, B, A, gx, gy, states_out,
                         states_stride, actions_out, actout_stride, steps_out, 1, nullptr, prev_action_io,
-                        has_prev_io, s);
+                        has_prev_io, nullptr, 1, s);
 }
 
 // ------------------------------------------------------------------------- lidar
@@ -449,6 +454,54 @@ void launch_round_begin(int32_t* status, int32_t* chunks_run, int32_t* chunk_ste
                         hipStream_t s) {
   hipLaunchKernelGGL(round_begin_kernel, dim3((B + 255) / 256), dim3(256), 0, s, status, chunks_run, chunk_steps, B,
                      n_chunks);
+}
+
+// ------------------------------------------------------------------------- alive compaction
+// idx_out[0..n) = candidates whose status is still DITREE_ST_OK, in candidate order; *count = n.
+// One workgroup, ordered prefix sum (the denoiser then runs on the n alive rows only).
+__global__ void __launch_bounds__(1024) compact_alive_kernel(const int32_t* __restrict__ status, int B,
+                                                             int32_t* __restrict__ idx_out, int32_t* __restrict__ count) {
+  __shared__ int s_wave_sum[16];
+  const int tid = threadIdx.x;
+  int base = 0;
+  for (int start = 0; start < B; start += blockDim.x) {
+    const int b = start + tid;
+    const int alive = (b < B && status[b] == DITREE_ST_OK) ? 1 : 0;
+    int v = alive;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int o = __shfl_up(v, d);
+      if ((tid & 63) >= d) v += o;
+    }
+    if ((tid & 63) == 63) s_wave_sum[tid >> 6] = v;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+      if (w < (tid >> 6)) woff += s_wave_sum[w];
+      total += s_wave_sum[w];
+    }
+    if (alive) idx_out[base + woff + v - 1] = b;
+    base += total;
+    __syncthreads();
+  }
+  if (tid == 0) *count = base;
+}
+void launch_compact_alive(const int32_t* status, int B, int32_t* idx_out, int32_t* count, hipStream_t s) {
+  hipLaunchKernelGGL(compact_alive_kernel, dim3(1), dim3(1024), 0, s, status, B, idx_out, count);
+}
+
+// rows of a strided f32 matrix gathered by candidate index (the chunk's noise for the alive candidates)
+__global__ void gather_rows_f32_kernel(const float* __restrict__ src, int64_t src_stride, const int32_t* __restrict__ idx,
+                                       float* __restrict__ dst, int row_floats, int n) {
+  const int r = blockIdx.x;
+  if (r >= n) return;
+  const float* s = src + (size_t)idx[r] * src_stride;
+  float* d = dst + (size_t)r * row_floats;
+  for (int k = threadIdx.x; k < row_floats; k += blockDim.x) d[k] = s[k];
+}
+void launch_gather_rows_f32(const float* src, int64_t src_stride, const int32_t* idx, float* dst, int row_floats, int n,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(n), dim3(128), 0, s, src, src_stride, idx, dst, row_floats, n);
 }
 
 // ------------------------------------------------------------------------- accept + commit

@@ -143,7 +143,7 @@ class ExpansionEngine:
     def __init__(self, ctx: Context, maze, start_state, goal_state, edge_length=64, action_horizon=8,
                  pred_horizon=64, local_map_size=20, local_map_scale=0.2, s_global=1.0, batch=1024,
                  capacity=65536, k_steps=1, emulate_sticky_done=True, norm=CAR_NORM, rank=0, world_size=1,
-                 process_group=None):
+                 process_group=None, early_exit=False):
         self.ctx = ctx
         self.maze = np.asarray(maze, dtype=np.float32)
         self.H, self.A, self.P = edge_length, action_horizon, pred_horizon
@@ -152,6 +152,7 @@ class ExpansionEngine:
         self.batch = batch
         self.k_steps = k_steps
         self.sticky = int(bool(emulate_sticky_done))
+        self.early_exit = int(bool(early_exit))    # skip later chunks of collided / finished candidates
         self.norm = np.ascontiguousarray(CAR_NORM if norm is None else norm, dtype=np.float64)
         self.rank, self.world, self.pg = rank, world_size, process_group
         self.force_allgather = False        # run the collective even with one rank (exercises the RCCL path on 1 GPU)
@@ -209,6 +210,7 @@ class ExpansionEngine:
             keep.append(a)
             setattr(rp, name, p)
         rp.lm_n, rp.lm_size, rp.s_global = self.lm_n, float(self.lm_n), float(self.s_global)
+        rp.early_exit = self.early_exit
         if n > 0:
             rd = self.rb.desc(lo, n)
             check(self.ctx._h, lib().ditree_expand_round(self.ctx._h, C.byref(self.tree.desc), C.byref(rd),

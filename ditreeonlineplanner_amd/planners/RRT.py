@@ -4,6 +4,8 @@ Constructor kwargs, ``plan() -> (path f32 (P,6)|None, actions f32 (A,2)|None)``,
 ``update_maze``, ``results`` and ``node_list`` follow the reference.  Extra kwargs:
   ``batch``            candidates per round (default 256; 1 = the reference's sequential order),
   ``max_candidates``   deterministic budget instead of / in addition to the wall-clock budget,
+  ``early_exit``       (default True) later chunks of collided / finished candidates are skipped, as the
+                       reference abandons a collided edge; results are identical either way,
   ``edge_length``      = prop_duration[0] (the reference's per-visit schedule needs sequential
                        visits; a schedule with more than one entry raises NotImplementedError).
 ``run_type`` > 0 (reference-path tracking / sampling-bias maps) is the "next" scope row.
@@ -46,7 +48,7 @@ class RRT_Planner(BasePlanner):
             local_map_size=int(lm), local_map_scale=self.local_map_scale, s_global=self.s_global, batch=self.batch,
             capacity=self.capacity, k_steps=getattr(sampler, "num_diffusion_iters", 1),
             norm=getattr(sampler, "norm", None) if getattr(sampler, "norm", None) is not None else None,
-            emulate_sticky_done=kwargs.get("emulate_sticky_done", True))
+            emulate_sticky_done=kwargs.get("emulate_sticky_done", True), early_exit=kwargs.get("early_exit", True))
         self._engine.env_goal = np.asarray(self.env.goal, dtype=np.float64)
 
     # ------------------------------------------------------------------ reference surface

@@ -223,6 +223,7 @@ typedef struct {
   int32_t lm_n;                  /* local_map_size */
   double lm_size;                /* the divisor of the goal conditioning (local_map_size) */
   double s_global;
+  int32_t early_exit;            /* != 0: compact the alive candidates after every chunk (RRT.py:179-184) */
 } ditree_round_params;
 
 int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,

@@ -151,3 +151,45 @@ def test_denoiser_batch_1024_rows_independent(ctx):
         part = ctx.denoise(noise[lo:lo + 16].contiguous(), lm[lo:lo + 16].contiguous(), cond[lo:lo + 16].contiguous(),
                            want_actions=False)
         assert torch.equal(part, full[lo:lo + 16])
+
+
+def test_early_exit_round_is_bit_identical(ctx):
+    """Compacting the alive candidates after every chunk (the reference abandons a collided edge,
+    RRT.py:179-184) must not change any result: denoiser rows are independent of the batch composition."""
+    from ditreeonlineplanner_amd.engine import ExpansionEngine
+    from ditreeonlineplanner_amd.model import NoisePredNet
+    maze = load_maze("boxes")
+    rng = np.random.default_rng(8)
+    B, N0, Hh, A = 512, 256, 32, 8
+    nodes = _free_states(rng, maze, N0)
+    goal = np.array([*G.cell_rowcol_to_xy([2, 17], maze), 0, 0, 0, 0])
+    net = NoisePredNet(seed=5)
+    net.bind(ctx, precision=0, max_batch=B)
+    s, c = ORRT.RandomTape(2).draw_round(B, 20, 20, goal)
+    noise = torch.randn(B, Hh // A, 64, 2, generator=torch.Generator().manual_seed(4)).cuda()
+    out = []
+    for ee in (False, True):
+        eng = ExpansionEngine(ctx, maze, nodes[0], goal, edge_length=Hh, action_horizon=A, batch=B, capacity=N0 + B,
+                              emulate_sticky_done=False, early_exit=ee)
+        tr = eng.tree
+        nd = dev(nodes)
+        tr.state[:N0] = nd
+        tr.xy[:N0] = nd[:, :2]
+        tr.parent[:N0] = 0
+        tr.parent[0] = -1
+        tr.has_prev[:N0] = 1
+        tr.counters[0] = N0
+        tr.n_nodes_host = N0
+        eng.expand_round(dev(s), dev(c), noise=noise)
+        out.append((eng.rb.status.cpu().numpy().copy(), eng.rb.chunks_run.cpu().numpy().copy(),
+                    eng.rb.end_state.cpu().numpy().copy(), eng.rb.states.cpu().numpy().copy(),
+                    eng.tree_snapshot()))
+    a, b = out
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    run = a[1]
+    for cand in range(B):                       # chunks that were run hold identical rows; skipped ones are never read
+        k = run[cand]
+        assert np.array_equal(a[3][cand, :k], b[3][cand, :k])
+    assert np.array_equal(a[2], b[2])
+    assert np.array_equal(a[4]["parents"], b[4]["parents"]) and np.array_equal(a[4]["states"], b[4]["states"])
+    assert (a[0] & 0xFF == 2).sum() > 20        # some candidates did collide, so compaction was exercised

@@ -152,9 +152,9 @@ def _scenario(g, tag):
     return maze, start, goal
 
 
-def _run_engine(ctx, maze, start, goal, tape_seed, budget, batch):
+def _run_engine(ctx, maze, start, goal, tape_seed, budget, batch, early_exit=False):
     from ditreeonlineplanner_amd.engine import ExpansionEngine
-    eng = ExpansionEngine(ctx, maze, start, goal, batch=batch, capacity=4096)
+    eng = ExpansionEngine(ctx, maze, start, goal, batch=batch, capacity=4096, early_exit=early_exit)
     rt = ORRT.RandomTape(42)
     at = ActionTape(tape_seed)
     done = 0
@@ -188,14 +188,15 @@ def test_engine_b1_reproduces_reference_trace(ctx, tag):
 
 
 @pytest.mark.parametrize("batch", [7, 64, 256])
-def test_engine_rounds_vs_oracle_rounds(ctx, batch):
+@pytest.mark.parametrize("early_exit", [False, True])
+def test_engine_rounds_vs_oracle_rounds(ctx, batch, early_exit):
     maze = load_maze("boxes")
     start = np.array([*G.cell_rowcol_to_xy([17, 2], maze), np.deg2rad(45.0), 0, 0, 0])
     goal = np.array([*G.cell_rowcol_to_xy([2, 17], maze), 0, 0, 0, 0])
     budget = batch * 6
     pl = ORRT.OraclePlanner(maze, start, goal, ActionTape(99).sampler())
     reached, path, actions = pl.plan(ORRT.RandomTape(42), budget, batch=batch)
-    eng = _run_engine(ctx, maze, start, goal, 99, budget, batch)
+    eng = _run_engine(ctx, maze, start, goal, 99, budget, batch, early_exit)
     snap = eng.tree_snapshot()
     assert np.array_equal(snap["parents"], np.array(pl.tree.parents))
     assert np.abs(snap["states"] - np.array(pl.tree.states)).max() < 1e-9
