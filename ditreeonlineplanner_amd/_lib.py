@@ -30,7 +30,8 @@ class Tree(C.Structure):
                 ("state", C.c_void_p), ("xy", C.c_void_p), ("parent", C.c_void_p),
                 ("last_action", C.c_void_p), ("has_prev", C.c_void_p), ("num_visit", C.c_void_p),
                 ("edge_states", C.c_void_p), ("edge_actions", C.c_void_p),
-                ("edge_nstates", C.c_void_p), ("edge_nactions", C.c_void_p), ("counters", C.c_void_p)]
+                ("edge_nstates", C.c_void_p), ("edge_nactions", C.c_void_p), ("obstacle_ahead", C.c_void_p),
+                ("counters", C.c_void_p)]
 
 
 class Round(C.Structure):
@@ -63,6 +64,8 @@ SIGNATURES = {
     "ditree_car_rollout": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _pd, _vp, _i64, _vp, _i64, _vp, _vp,
                                   _vp, _vp]),
     "ditree_lidar_scan": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ditree_obstacle_ahead": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
+    "ditree_fallback_select": (_i32, [_vp, C.POINTER(Tree), _i32, _pd, _pd, _i32, _vp, _vp]),
     "ditree_accept": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), _i32, _vp]),
     "ditree_load_weights": (_i32, [_vp, _vp, _i64, C.c_char_p, _vp]),
     "ditree_denoise_reserve": (_i32, [_vp, _i32, _i32]),

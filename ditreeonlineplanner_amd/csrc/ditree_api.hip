@@ -51,6 +51,7 @@ void ditree_ctx_destroy(ditree_ctx* ctx) {
   if (ctx->alive_idx) hipFree(ctx->alive_idx);
   if (ctx->alive_cnt) hipFree(ctx->alive_cnt);
   if (ctx->alive_cnt_host) hipHostFree(ctx->alive_cnt_host);
+  if (ctx->path_dev) hipFree(ctx->path_dev);
   delete ctx;
 }
 
@@ -178,6 +179,53 @@ int32_t ditree_lidar_scan(ditree_ctx* ctx, const double* poses, int32_t B, const
   return DITREE_OK;
 }
 
+static AheadArg ahead_samples() {               // np.linspace(0, 1.5, 30): arange(30) * (1.5 / 29), endpoint forced
+  AheadArg a;
+  const double step = 1.5 / 29.0;
+  for (int i = 0; i < 30; ++i) a.t[i] = (double)i * step;
+  a.t[29] = 1.5;
+  return a;
+}
+
+int32_t ditree_obstacle_ahead(ditree_ctx* ctx, const double* state, int32_t stride, int32_t B, uint8_t* out,
+                              void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!ctx->maze) return set_err(ctx, DITREE_E_STATE, "obstacle_ahead: no maze uploaded");
+  if (B == 0) return DITREE_OK;
+  if (!state || !out || B < 0 || stride < 3) return set_err(ctx, DITREE_E_ARG, "obstacle_ahead: bad argument");
+  const AheadArg a = ahead_samples();
+  launch_obstacle_ahead(ctx->maze, ctx->rows, ctx->cols, state, stride, B, a, out, (hipStream_t)stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+static int check_tree(ditree_ctx* ctx, const ditree_tree* t);
+
+int32_t ditree_fallback_select(ditree_ctx* ctx, const ditree_tree* tree, int32_t n_nodes, const double* goal_xy,
+                               const double* path, int32_t P, int32_t* out_node, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  int rc = check_tree(ctx, tree);
+  if (rc) return rc;
+  if (!goal_xy || !out_node || n_nodes < 1 || n_nodes > tree->capacity || (path && P <= 0))
+    return set_err(ctx, DITREE_E_ARG, "fallback_select: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const double* pd = nullptr;
+  if (path) {
+    if (P > ctx->path_cap) {
+      if (ctx->path_dev) HIP_TRY(ctx, hipFree(ctx->path_dev));
+      ctx->path_dev = nullptr;
+      HIP_TRY(ctx, hipMalloc((void**)&ctx->path_dev, (size_t)P * 2 * sizeof(double)));
+      ctx->path_cap = P;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->path_dev, path, (size_t)P * 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));            // `path` is caller-owned host memory
+    pd = ctx->path_dev;
+  }
+  launch_fallback_select(*tree, n_nodes, goal_xy[0], goal_xy[1], pd, P, out_node, s);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
 static int check_tree(ditree_ctx* ctx, const ditree_tree* t) {
   if (!t || !t->state || !t->xy || !t->parent || !t->last_action || !t->has_prev || !t->num_visit ||
       !t->edge_states || !t->edge_actions || !t->edge_nstates || !t->edge_nactions || !t->counters ||
@@ -200,7 +248,9 @@ int32_t ditree_accept(ditree_ctx* ctx, const ditree_tree* tree, const ditree_rou
   rc = check_round(ctx, round);
   if (rc) return rc;
   if (round->B == 0) return DITREE_OK;
-  launch_accept(*tree, *round, emulate_sticky, (hipStream_t)stream);
+  if (tree->obstacle_ahead && !ctx->maze) return set_err(ctx, DITREE_E_STATE, "accept: obstacle-ahead flags need the maze");
+  const AheadArg ts = ahead_samples();
+  launch_accept(*tree, *round, emulate_sticky, ctx->maze, ctx->rows, ctx->cols, ts, (hipStream_t)stream);
   HIP_TRY(ctx, hipGetLastError());
   return DITREE_OK;
 }

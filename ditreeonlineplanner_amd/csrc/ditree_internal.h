@@ -39,6 +39,8 @@ struct ditree_ctx {
   int32_t* alive_idx = nullptr;     // (B,) compacted candidate indices (early-exit rounds)
   int32_t* alive_cnt = nullptr;     // device scalar
   int32_t* alive_cnt_host = nullptr;  // pinned host copy
+  double* path_dev = nullptr;       // reference path xy for the fallback selection
+  int path_cap = 0;
   DenoiserState* dn = nullptr;
 };
 
@@ -76,4 +78,10 @@ void launch_round_begin(int32_t* status, int32_t* chunks_run, int32_t* chunk_ste
                         hipStream_t s);
 void launch_round_chunk_end(const int32_t* chunk_status_in, int32_t* status, int32_t* chunks_run,
                             const double* cur_state, double* end_state, int B, hipStream_t s);
-void launch_accept(const ditree_tree& t, const ditree_round& r, int emulate_sticky, hipStream_t s);
+struct AheadArg { double t[30]; };
+void launch_accept(const ditree_tree& t, const ditree_round& r, int emulate_sticky, const unsigned char* maze, int rows,
+                   int cols, const AheadArg& ts, hipStream_t s);
+void launch_obstacle_ahead(const unsigned char* maze, int rows, int cols, const double* state, int stride, int B,
+                           const AheadArg& ts, uint8_t* out, hipStream_t s);
+void launch_fallback_select(const ditree_tree& t, int n_nodes, double gx, double gy, const double* path_dev, int P,
+                            int32_t* out_node, hipStream_t s);

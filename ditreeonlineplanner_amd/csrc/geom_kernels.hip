@@ -504,6 +504,97 @@ void launch_gather_rows_f32(const float* src, int64_t src_stride, const int32_t*
   hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(n), dim3(128), 0, s, src, src_stride, idx, dst, row_floats, n);
 }
 
+// ------------------------------------------------------------------------- obstacle ahead
+// planners/RRT.py:61-81: samples = linspace(0, 1.5, 30)[:, None] @ [[cos(-psi), sin(-psi)]] + (col, row) with
+// (row, col) = cell_xy_to_rowcol(xy, floor_enable=False); astype('int') truncates toward zero; clip; any.
+__device__ __forceinline__ bool obstacle_ahead_dev(double x, double y, double psi, const unsigned char* mz, int H, int W,
+                                                   const AheadArg& ts) {
+  const double row = ((double)H / 2.0 - y) / 1.0, col = (x + (double)W / 2.0) / 1.0;     // car_env.py:196-201
+  const double c = cos(-psi), sn = sin(-psi);
+  bool any = false;
+#pragma unroll 1
+  for (int i = 0; i < 30; ++i) {
+    const double px = ts.t[i] * c + col, py = ts.t[i] * sn + row;
+    // numpy's astype(int) of NaN / out-of-range is INT64_MIN -> clipped to 0
+    long long qx = (px == px && fabs(px) < 9.0e18) ? (long long)px : (long long)-1;
+    long long qy = (py == py && fabs(py) < 9.0e18) ? (long long)py : (long long)-1;
+    const int ix = qx < 0 ? 0 : (qx > W - 1 ? W - 1 : (int)qx);
+    const int iy = qy < 0 ? 0 : (qy > H - 1 ? H - 1 : (int)qy);
+    any |= mz[iy * W + ix] != 0;
+  }
+  return any;
+}
+__global__ void obstacle_ahead_kernel(const unsigned char* __restrict__ maze, int rows, int cols,
+                                      const double* __restrict__ state, int stride, int B, AheadArg ts,
+                                      uint8_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  stage_maze(lds, maze, rows * cols);
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* s = state + (size_t)b * stride;
+  out[b] = obstacle_ahead_dev(s[0], s[1], s[2], lds, rows, cols, ts) ? 1 : 0;
+}
+void launch_obstacle_ahead(const unsigned char* maze, int rows, int cols, const double* state, int stride, int B,
+                           const AheadArg& ts, uint8_t* out, hipStream_t s) {
+  size_t lds = ((size_t)rows * cols + 15) & ~(size_t)15;
+  hipLaunchKernelGGL(obstacle_ahead_kernel, dim3((B + 255) / 256), dim3(256), lds, s, maze, rows, cols, state, stride, B,
+                     ts, out);
+}
+
+// ------------------------------------------------------------------------- fallback selection
+// planners/RRT.py:233-254 over nodes 1..n-1.  One workgroup; every thread scans a strided subset and keeps
+// (key, index) with first-occurrence ties, then a block reduction.
+__global__ void __launch_bounds__(1024) fallback_select_kernel(ditree_tree t, int n, double gx, double gy,
+                                                               const double* __restrict__ path, int P,
+                                                               int32_t* __restrict__ out_node) {
+  __shared__ double s_key[1024];
+  __shared__ int s_idx[1024];
+  const int tid = threadIdx.x;
+  // minimise `key`: cost for the goal-distance rule, -progress for the along-path rule
+  double best = __builtin_huge_val();
+  int bidx = 0x7fffffff;
+  int free_seen = 0;
+  for (int i = 1 + tid; i < n; i += blockDim.x) {
+    const double x = t.xy[(size_t)i * 2], y = t.xy[(size_t)i * 2 + 1];
+    const bool obs = t.obstacle_ahead != nullptr && t.obstacle_ahead[i] != 0;
+    free_seen |= !obs;
+    double key;
+    if (path == nullptr) {
+      const double dx = x - gx, dy = y - gy;
+      key = sqrt(fma(dy, dy, dx * dx)) + 10e3 * (obs ? 1.0 : 0.0);      // np.linalg.norm (1-D) + 10e3 * flag
+    } else {
+      int prog = -1;
+      if (!obs) {
+        double bd = __builtin_huge_val();
+        for (int k = 0; k < P; ++k) {
+          const double dx = x - path[2 * k], dy = y - path[2 * k + 1];
+          const double d = sqrt(dx * dx + dy * dy);                      // np.linalg.norm(axis=1): no fused dot
+          if (d < bd) { bd = d; prog = k; }
+        }
+      }
+      key = -(double)prog;
+    }
+    if (key < best) { best = key; bidx = i; }
+  }
+  s_key[tid] = best;
+  s_idx[tid] = bidx;
+  const int any_free = __syncthreads_or(free_seen);
+  for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
+    if (tid < off) {
+      const double ok = s_key[tid + off];
+      const int oi = s_idx[tid + off];
+      if (ok < s_key[tid] || (ok == s_key[tid] && oi < s_idx[tid])) { s_key[tid] = ok; s_idx[tid] = oi; }
+    }
+    __syncthreads();
+  }
+  // RRT.py:227-232: np.all(has_obstacle_ahead) (true for an empty list) -> no plan
+  if (tid == 0) *out_node = (!any_free || s_idx[0] == 0x7fffffff) ? -1 : s_idx[0];
+}
+void launch_fallback_select(const ditree_tree& t, int n_nodes, double gx, double gy, const double* path_dev, int P,
+                            int32_t* out_node, hipStream_t s) {
+  hipLaunchKernelGGL(fallback_select_kernel, dim3(1), dim3(1024), 0, s, t, n_nodes, gx, gy, path_dev, P, out_node);
+}
+
 // ------------------------------------------------------------------------- accept + commit
 // Phase 1 (one workgroup): the reference's sequential accept order (RRT.py:179-217) as a
 // scan.  counters: [0] n_nodes [1] goal node [2] env.done latched [3] chunk iterations
@@ -595,7 +686,8 @@ accept_scan_kernel(ditree_tree t, ditree_round r, int emulate_sticky) {
 // Phase 2: one wave per candidate copies the accepted edge into its node slot, dropping
 // all-zero rows (RRT.py:196-199).
 __global__ void __launch_bounds__(64)
-accept_commit_kernel(ditree_tree t, ditree_round r) {
+accept_commit_kernel(ditree_tree t, ditree_round r, const unsigned char* __restrict__ maze, int rows, int cols,
+                     AheadArg ts) {
   const int b = blockIdx.x;
   const int id = r.node_id[b];
   if (id < 0) return;
@@ -653,12 +745,15 @@ accept_commit_kernel(ditree_tree t, ditree_round r) {
     t.num_visit[id] = 0;
     t.edge_nstates[id] = ns;
     t.edge_nactions[id] = na;
+    if (t.obstacle_ahead != nullptr)                                   // RRT.py:202-205 (run_type > 0)
+      t.obstacle_ahead[id] = obstacle_ahead_dev(endst[0], endst[1], endst[2], maze, rows, cols, ts) ? 1 : 0;
   }
   __syncthreads();
   if (lane < 2) t.last_action[(size_t)id * 2 + lane] = (na > 0) ? ea[(size_t)(na - 1) * 2 + lane] : 0.0;
 }
 
-void launch_accept(const ditree_tree& t, const ditree_round& r, int emulate_sticky, hipStream_t s) {
+void launch_accept(const ditree_tree& t, const ditree_round& r, int emulate_sticky, const unsigned char* maze, int rows,
+                   int cols, const AheadArg& ts, hipStream_t s) {
   hipLaunchKernelGGL(accept_scan_kernel, dim3(1), dim3(1024), 0, s, t, r, emulate_sticky);
-  hipLaunchKernelGGL(accept_commit_kernel, dim3(r.B), dim3(64), 0, s, t, r);
+  hipLaunchKernelGGL(accept_commit_kernel, dim3(r.B), dim3(64), 0, s, t, r, maze, rows, cols, ts);
 }

@@ -25,7 +25,7 @@ CNT_NODES, CNT_GOAL, CNT_LATCH, CNT_ITERS, CNT_CANDS, CNT_STICKY, CNT_OVERFLOW, 
 
 
 class DeviceTree:
-    def __init__(self, ctx: Context, capacity: int, n_chunks: int, A: int):
+    def __init__(self, ctx: Context, capacity: int, n_chunks: int, A: int, track_obstacle_ahead: bool = False):
         dev = ctx.device
         self.capacity, self.n_chunks, self.A = capacity, n_chunks, A
         f64, i32, u8 = torch.float64, torch.int32, torch.uint8
@@ -40,9 +40,12 @@ class DeviceTree:
         self.edge_nstates = torch.zeros(capacity, dtype=i32, device=dev)
         self.edge_nactions = torch.zeros(capacity, dtype=i32, device=dev)
         self.counters = torch.zeros(8, dtype=i32, device=dev)
-        self.desc = Tree(capacity, n_chunks, A, *[t.data_ptr() for t in (
+        # RRT.py:202-205: per-node check_obstacle_ahead flag, kept only for run_type > 0
+        self.obstacle_ahead = torch.zeros(capacity, dtype=u8, device=dev) if track_obstacle_ahead else None
+        self.desc = Tree(capacity, n_chunks, A, *[None if t is None else t.data_ptr() for t in (
             self.state, self.xy, self.parent, self.last_action, self.has_prev, self.num_visit,
-            self.edge_states, self.edge_actions, self.edge_nstates, self.edge_nactions, self.counters)])
+            self.edge_states, self.edge_actions, self.edge_nstates, self.edge_nactions, self.obstacle_ahead,
+            self.counters)])
         self.n_nodes_host = 0
 
     def reset(self, start_state):
@@ -55,6 +58,8 @@ class DeviceTree:
         self.num_visit.zero_()
         self.edge_nstates[0] = 0
         self.edge_nactions[0] = 0
+        if self.obstacle_ahead is not None:
+            self.obstacle_ahead.zero_()
         self.counters.zero_()
         self.counters[CNT_NODES] = 1
         self.counters[CNT_GOAL] = -1
@@ -143,7 +148,7 @@ class ExpansionEngine:
     def __init__(self, ctx: Context, maze, start_state, goal_state, edge_length=64, action_horizon=8,
                  pred_horizon=64, local_map_size=20, local_map_scale=0.2, s_global=1.0, batch=1024,
                  capacity=65536, k_steps=1, emulate_sticky_done=True, norm=CAR_NORM, rank=0, world_size=1,
-                 process_group=None, early_exit=False):
+                 process_group=None, early_exit=False, run_type=0):
         self.ctx = ctx
         self.maze = np.asarray(maze, dtype=np.float32)
         self.H, self.A, self.P = edge_length, action_horizon, pred_horizon
@@ -156,7 +161,9 @@ class ExpansionEngine:
         self.norm = np.ascontiguousarray(CAR_NORM if norm is None else norm, dtype=np.float64)
         self.rank, self.world, self.pg = rank, world_size, process_group
         self.force_allgather = False        # run the collective even with one rank (exercises the RCCL path on 1 GPU)
-        self.tree = DeviceTree(ctx, capacity, self.n_chunks, self.A)
+        self.run_type = int(run_type)
+        self.init_main_path = None          # (P, >=2) reference path of an earlier plan (run_type > 0)
+        self.tree = DeviceTree(ctx, capacity, self.n_chunks, self.A, track_obstacle_ahead=self.run_type > 0)
         self.rb = RoundBuffers(ctx, batch, self.n_chunks, self.A)
         self.axis = local_axis(local_map_size, local_map_scale)
         from .common.fm_utils import get_timesteps
@@ -237,11 +244,25 @@ class ExpansionEngine:
         return None if g < 0 else g
 
     def fallback_node(self):
-        """planners/RRT.py:233-237 (run_type 0): among nodes 1.., the one nearest to goal_state xy
-        (arg-min reduction on the device: the nearest-node kernel with the goal as the single query)."""
+        """planners/RRT.py:227-254.  run_type 0: among nodes 1.., the one nearest to goal_state xy (arg-min
+        reduction on the device: the nearest-node kernel with the goal as the single query).  run_type > 0:
+        None when every node has an obstacle ahead; else nearest to the goal with +1e4 on flagged nodes, or --
+        with a reference path -- the unflagged node whose nearest path point lies furthest along it."""
         n = self.tree.n_nodes_host
         if n < 2:
             return None
+        if self.run_type > 0:
+            out = torch.empty(1, dtype=torch.int32, device=self.tree.xy.device)
+            g, gp = _dbl(self.goal_state[:2])
+            if self.init_main_path is not None:
+                pa, pp = _dbl(np.asarray(self.init_main_path)[:, :2])
+                P = pa.shape[0]
+            else:
+                pa, pp, P = None, None, 0
+            check(self.ctx._h, lib().ditree_fallback_select(self.ctx._h, C.byref(self.tree.desc), n, gp, pp, P,
+                                                             out.data_ptr(), self.ctx.stream), "fallback_select")
+            node = int(out.item())
+            return None if node < 0 else node
         q = torch.as_tensor(self.goal_state[:2].reshape(1, 2).copy(), device=self.tree.xy.device)
         idx = self.ctx.nn_argmin(q, self.tree.xy[1:n].contiguous(), n_nodes=n - 1)
         return 1 + int(idx[0].item())

@@ -159,6 +159,17 @@ class Context:
                                                  self.stream), "car_rollout")
         return status, states, aout, steps
 
+    # ------------------------------------------------------------------ obstacle ahead
+    def obstacle_ahead(self, state):
+        """planners/RRT.py:61-81 for a batch of states (B, >=3) f64 on the uploaded maze -> (B,) u8."""
+        dev = self.device
+        _chk(state, torch.float64, "state", dev)
+        B = state.shape[0]
+        out = torch.empty(B, dtype=torch.uint8, device=dev)
+        check(self._h, lib().ditree_obstacle_ahead(self._h, _ptr(state), state.shape[1] if B else 6, B, _ptr(out),
+                                                    self.stream), "obstacle_ahead")
+        return out
+
     # ------------------------------------------------------------------ lidar
     def lidar_scan(self, poses, maze_dev, want_visited=True):
         dev = self.device

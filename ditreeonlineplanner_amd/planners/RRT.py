@@ -8,7 +8,10 @@ Constructor kwargs, ``plan() -> (path f32 (P,6)|None, actions f32 (A,2)|None)``,
                        reference abandons a collided edge; results are identical either way,
   ``edge_length``      = prop_duration[0] (the reference's per-visit schedule needs sequential
                        visits; a schedule with more than one entry raises NotImplementedError).
-``run_type`` > 0 (reference-path tracking / sampling-bias maps) is the "next" scope row.
+``run_type`` 0 ("Original") and 1 ("Original+Ref": obstacle-ahead flags per node, sampling biased to the
+part of ``init_main_path`` behind the obstacle, furthest-along-path fallback) are covered; ``run_type`` >= 2
+draws samples from the reference's sampling-probability maps (car_env.py:102-126, base_planner.py:181),
+which is outside this engine.
 """
 from __future__ import annotations
 
@@ -35,8 +38,8 @@ class RRT_Planner(BasePlanner):
         self.plan_count = 0
         self.init_main_path = None
         self.run_type = kwargs.get("run_type", 0)
-        if self.run_type != 0:
-            raise NotImplementedError("run_type > 0 is a later scope row (SURVEY 8(f))")
+        if self.run_type >= 2:
+            raise NotImplementedError("run_type >= 2 samples from the sampling-probability maps (out of scope)")
         self.env.run_type = self.run_type
         self.batch = int(kwargs.get("batch", 256))
         self.max_candidates = kwargs.get("max_candidates", None)
@@ -48,7 +51,8 @@ class RRT_Planner(BasePlanner):
             local_map_size=int(lm), local_map_scale=self.local_map_scale, s_global=self.s_global, batch=self.batch,
             capacity=self.capacity, k_steps=getattr(sampler, "num_diffusion_iters", 1),
             norm=getattr(sampler, "norm", None) if getattr(sampler, "norm", None) is not None else None,
-            emulate_sticky_done=kwargs.get("emulate_sticky_done", True), early_exit=kwargs.get("early_exit", True))
+            emulate_sticky_done=kwargs.get("emulate_sticky_done", True), early_exit=kwargs.get("early_exit", True),
+            run_type=self.run_type)
         self._engine.env_goal = np.asarray(self.env.goal, dtype=np.float64)
 
     # ------------------------------------------------------------------ reference surface
@@ -98,15 +102,47 @@ class RRT_Planner(BasePlanner):
         idx = self.ctx.nn_argmin(q, t.xy, n_nodes=t.n_nodes_host)
         return self.node_list[int(idx[0].item())]
 
-    def draw_round(self, B):
-        """B x [random_node_sample -> conditioning coin] in the reference's RNG call order
-        (base_planner.py:162-207, RRT.py:153-156)."""
+    def check_obstacle_ahead(self, state):
+        """RRT.py:61-81 through the device op (the accept kernel evaluates the same function per new node)."""
+        self.ctx.upload_maze(np.asarray(self.maze, dtype=np.float32))
+        st = torch.as_tensor(np.asarray(state, dtype=np.float64).reshape(1, -1), device=self.ctx.device)
+        return bool(self.ctx.obstacle_ahead(st)[0].item())
+
+    def extract_path_after_obstacle(self):
+        """RRT.py:83-111: xy of ``init_main_path`` from the point nearest to the env state onwards, cut to what
+        lies behind the first blocked stretch (host side: once per plan over a few hundred points)."""
+        xy = self.init_main_path[:, :2].copy()
+        here = self.env.state[:2]
+        first = int(np.argmin(np.linalg.norm(here - self.init_main_path[:, :2], axis=1)))
+        xy = xy[first:, :]
+        cells = np.array([self.env.cell_xy_to_rowcol(q).astype("int") for q in xy])
+        blocked = self.maze[cells[:, 0], cells[:, 1]] == 1
+        hits = np.flatnonzero(blocked)
+        k = int(hits[0]) if hits.size else -1          # no crossing: the reference starts from the last point
+        cell = cells[k]
+        while self.maze[cell[0], cell[1]] == 1 and k < len(cells):
+            cell = cells[k]
+            k += 1
+        return xy[k:]
+
+    def draw_round(self, B, remain_init_path=None):
+        """B x [sample -> conditioning goal] in the reference's RNG call order (base_planner.py:162-207,
+        RRT.py:134-140,153-156).  run_type 0: random_node_sample, then the goal-conditioning coin.
+        run_type > 0: with a remaining reference path, np.random.choice of one of its points kept with
+        probability 0.6 (else random_node_sample); the conditioning goal is the sample itself."""
         s = np.zeros((B, 6))
         c = np.zeros((B, 2))
         for i in range(B):
-            smp = self.random_node_sample()
-            s[i] = smp[0]
-            c[i] = smp[0, :2] if random.random() > self.goal_conditioning_bias else self.goal_state[:2]
+            if remain_init_path is not None:
+                k = np.random.choice(np.arange(len(remain_init_path)))
+                smp = self.random_node_sample() if random.random() < 0.4 else remain_init_path[k][np.newaxis]
+            else:
+                smp = self.random_node_sample()
+            s[i, : smp.shape[1]] = smp[0]
+            if self.run_type == 0:
+                c[i] = smp[0, :2] if random.random() > self.goal_conditioning_bias else self.goal_state[:2]
+            else:
+                c[i] = smp[0, :2]
         return s, c
 
     # ------------------------------------------------------------------ plan
@@ -118,11 +154,15 @@ class RRT_Planner(BasePlanner):
         start_time = time.time()
         drawn = 0
         goal = None
+        remain = None
+        if self.run_type > 0 and self.init_main_path is not None:
+            remain = self.extract_path_after_obstacle()
+        eng.init_main_path = self.init_main_path if self.run_type > 0 else None
         while (time.time() - start_time) < self.time_budget:
             if self.max_candidates is not None and drawn >= self.max_candidates:
                 break
             B = self.batch if self.max_candidates is None else min(self.batch, self.max_candidates - drawn)
-            s, c = self.draw_round(B)
+            s, c = self.draw_round(B, remain)
             noise = torch.randn((B, eng.n_chunks, eng.P, 2), device=dev)
             cnt = eng.expand_round(torch.as_tensor(s, device=dev), torch.as_tensor(c, device=dev), noise=noise)
             drawn += B
@@ -133,7 +173,7 @@ class RRT_Planner(BasePlanner):
         if goal is not None:
             self.env.done = True
             return self.handle_goal_reached(goal, iters, start_time)
-        node = eng.fallback_node()                          # RRT.py:233-237
+        node = eng.fallback_node()                          # RRT.py:227-254
         if node is None:
             return self.handle_goal_not_reached(iters, start_time)
         return self.handle_goal_reached(node, iters, start_time)

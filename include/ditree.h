@@ -134,6 +134,7 @@ typedef struct {
   double* edge_actions;      /* (cap, n_chunks*A, 2)      zero-row-filtered, RRT.py:196-197 */
   int32_t* edge_nstates;     /* (cap,) rows kept */
   int32_t* edge_nactions;    /* (cap,) */
+  uint8_t* obstacle_ahead;   /* (cap,) or NULL: planners/RRT.py:61-81 flag of every appended node (run_type > 0) */
   int32_t* counters;         /* [0] n_nodes, [1] goal node (-1 none), [2] env.done latched
                                 (car_env.py:254,266 "sticky done"), [3] chunk iterations,
                                 [4] candidates processed, [5] sticky-done triggered */
@@ -159,6 +160,22 @@ typedef struct {
  * env.done defect described in DESIGN.md. */
 int32_t ditree_accept(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
                       int32_t emulate_sticky, void* stream);
+
+/* planners/RRT.py:61-81 check_obstacle_ahead on the uploaded maze: 30 samples over 1.5 cells ahead of the
+ * heading in (col, row) space, int-truncated and clipped, any occupied.
+ *   state [dev] (B, stride) f64 (x, y, psi used); out [dev] (B,) u8.  The sample offsets are
+ *   np.linspace(0, 1.5, 30) = i * (1.5 / 29), last = 1.5, evaluated in f64 as numpy does. */
+int32_t ditree_obstacle_ahead(ditree_ctx* ctx, const double* state, int32_t stride, int32_t B,
+                              uint8_t* out, void* stream);
+
+/* planners/RRT.py:233-254 fallback node when the budget ends without reaching the goal, over nodes
+ * 1..n-1 of the tree: path == NULL: argmin ||xy - goal|| + 1e4 * obstacle_ahead; path != NULL
+ * ([host] (P, 2) f64 = init_main_path xy): argmax of the nearest path index (-1 when an obstacle is
+ * ahead).  First occurrence wins, as np.argmin / np.argmax.  out_node [dev] i32 (tree index), or -1 when
+ * every node has an obstacle ahead or the tree holds only the start (RRT.py:227-232: no plan). */
+int32_t ditree_fallback_select(ditree_ctx* ctx, const ditree_tree* tree, int32_t n_nodes,
+                               const double* goal_xy /*[host] 2*/, const double* path /*[host] or NULL*/,
+                               int32_t P, int32_t* out_node, void* stream);
 
 /* ------------------------------------------------------------------ denoiser */
 

@@ -60,12 +60,44 @@ class RandomTape:
             cond = np.asarray(goal_state, dtype=np.float64)[:2].copy()
         return sample, cond
 
+    def draw_candidate_ref(self, remain_path, width, length, goal_state, goal_sample_rate=0.15, max_v=5.0):
+        """run_type > 0 (RRT.py:134-140,153-156): with a remaining reference path, pick one of its points
+        (np.random.choice) and keep it with probability 0.6, else a random_node_sample(); the
+        conditioning goal is always the sample's xy."""
+        if remain_path is not None:
+            node_idx = self.np.choice(np.arange(len(remain_path)))
+            explore = self.py.random() < 0.4
+        else:
+            node_idx, explore = None, True
+        if explore:
+            if self.py.random() > goal_sample_rate:
+                x = self.np.uniform(-width / 2, width / 2, size=(1, 1))
+                y = self.np.uniform(-length / 2, length / 2, size=(1, 1))
+                th = self.np.uniform(-np.pi, np.pi, size=(1, 1))
+                v = self.np.uniform(-max_v, max_v, size=(1, 1))
+                thr = self.np.uniform(-1, 1, size=(1, 1))
+                st = self.np.uniform(-0.40, 0.40, size=(1, 1))
+                sample = np.concatenate((x, y, th, v, thr, st), axis=1)[0]
+            else:
+                sample = np.array(goal_state, dtype=np.float64).copy()
+        else:
+            sample = np.zeros(6)
+            sample[:2] = remain_path[node_idx]            # float32 path point (only xy is ever used)
+        return sample, sample[:2].copy()
+
     def draw_round(self, B, width, length, goal_state, **kw):
         s = np.zeros((B, 6))
         c = np.zeros((B, 2))
         for i in range(B):
             s[i], c[i] = self.draw_candidate(width, length, goal_state, **kw)
         return s, c
+
+
+def cell_center_f32(xy, maze):
+    """env.reset(options) puts the env state at the centre of the start cell in a float32 array
+    (car_env.py:215-229); planner.reset derives that cell from start_state (RRT.py:38-40)."""
+    rc = G.cell_xy_to_rowcol(np.asarray(xy, dtype=np.float64), maze)
+    return G.cell_rowcol_to_xy(rc, maze).astype(np.float32)
 
 
 class OracleTree:
@@ -93,7 +125,7 @@ class OraclePlanner:
 
     def __init__(self, maze, start_state, goal_state, sampler, edge_length=64, action_horizon=8,
                  local_map_size=20, local_map_scale=0.2, s_global=1.0, goal_sample_rate=0.15,
-                 goal_conditioning_bias=0.85, emulate_sticky_done=True):
+                 goal_conditioning_bias=0.85, emulate_sticky_done=True, run_type=0, init_main_path=None):
         self.maze = np.asarray(maze, dtype=np.float32)
         self.start_state = np.asarray(start_state, dtype=np.float64)
         self.goal_state = np.asarray(goal_state, dtype=np.float64)
@@ -110,6 +142,9 @@ class OraclePlanner:
         self.sticky = emulate_sticky_done
         self.env_done_latched = False
         self.sticky_triggered = False
+        self.run_type = run_type
+        self.init_main_path = None if init_main_path is None else np.asarray(init_main_path)
+        self.obstacle_ahead = []       # per node 1.. (RRT.py:202-205)
         self.iterations = 0            # the reference's iter_num (chunk iterations)
         self.candidates = 0
         self.goal_node = None
@@ -168,6 +203,7 @@ class OraclePlanner:
                 s0 = np.asarray(t.states)[parent[b]]
                 node = self._append(s0.copy(), parent[b], np.stack([s0, s0]), all_actions[b, 0, :1].copy())
                 accepted.append(node)
+                self.obstacle_ahead.append(bool(G.check_obstacle_ahead(s0, self.maze)[0]) if self.run_type > 0 else False)
                 self.goal_node = node
                 break
             self.iterations += int(chunks_run[b])
@@ -185,6 +221,7 @@ class OraclePlanner:
             es = es[~(es == 0).all(axis=1)]                          # RRT.py:198-199
             node = self._append(cur[b].copy(), parent[b], es, ea)
             accepted.append(node)
+            self.obstacle_ahead.append(bool(G.check_obstacle_ahead(cur[b], self.maze)[0]) if self.run_type > 0 else False)
             if final_status[b] == G.STATUS_GOAL:
                 self.goal_node = node
                 break
@@ -208,28 +245,69 @@ class OraclePlanner:
         return len(t.states) - 1
 
     # ------------------------------------------------------------------ driver
+    def remaining_reference_path(self):
+        """RRT.py:83-111 extract_path_after_obstacle (float32 arithmetic, as the reference's arrays):
+        the part of init_main_path behind the first obstacle it crosses, seen from the env state
+        (= centre of the start cell after planner.reset)."""
+        P = np.asarray(self.init_main_path)[:, :2].astype(np.float32)
+        cur = np.float32(cell_center_f32(self.start_state[:2], self.maze))
+        closest = int(np.argmin(np.linalg.norm(cur - P, axis=1)))
+        rest = P[closest:].copy()
+        H, W = self.maze.shape
+        rc = np.stack([np.floor((np.float32(H / 2) - rest[:, 1]) / np.float32(1)), np.floor((rest[:, 0] + np.float32(W / 2)) / np.float32(1))],
+                      axis=1).astype(int)
+        k = -1
+        for i, pnt in enumerate(rc):
+            if self.maze[pnt[0], pnt[1]] == 1:
+                k = i
+                break
+        cp = rc[k]
+        while self.maze[cp[0], cp[1]] == 1 and k < len(rc):
+            cp = rc[k]
+            k += 1
+        return rest[k:]
+
     def plan(self, tape: RandomTape, n_candidates: int, batch: int = 1):
         """Run rounds of ``batch`` candidates until the goal is reached or ``n_candidates``
         were drawn (the reference's wall-clock budget replaced by a candidate budget)."""
         H, W = self.maze.shape
+        remain = None
+        if self.run_type > 0 and self.init_main_path is not None:
+            remain = self.remaining_reference_path()
         while self.goal_node is None and self.candidates < n_candidates:
             B = min(batch, n_candidates - self.candidates)
-            s, c = tape.draw_round(B, W, H, self.goal_state, goal_sample_rate=self.gsr,
-                                   goal_conditioning_bias=self.gcb)
+            if self.run_type == 0:
+                s, c = tape.draw_round(B, W, H, self.goal_state, goal_sample_rate=self.gsr,
+                                       goal_conditioning_bias=self.gcb)
+            else:
+                s, c = np.zeros((B, 6)), np.zeros((B, 2))
+                for i in range(B):
+                    s[i], c[i] = tape.draw_candidate_ref(remain, W, H, self.goal_state, goal_sample_rate=self.gsr)
             self.expand_round(s, c)
         reached = self.goal_node is not None
-        node = self.goal_node if reached else self.fallback_node()
+        if reached:
+            node = self.goal_node
+        elif self.run_type > 0 and all(self.obstacle_ahead):          # np.all([]) is True (RRT.py:227-232)
+            return False, None, None
+        else:
+            node = self.fallback_node()
         path, actions = self.path_to(node) if node is not None else (None, None)
         return reached, path, actions
 
     def fallback_node(self):
-        """RRT.py:233-237 (run_type 0): node nearest to the goal among nodes 1.."""
+        """RRT.py:233-254: nearest to the goal (+1e4 when an obstacle is ahead), or -- with a reference
+        path and run_type > 0 -- the node that got furthest along init_main_path."""
         if len(self.tree) < 2:
             return None
         xy = self.tree.xy()[1:]
-        d = xy - self.goal_state[:2]
-        dist = G.norm2(d[:, 0], d[:, 1])
-        return 1 + int(np.argmin(dist))
+        obs = np.array(self.obstacle_ahead, dtype=bool) if self.run_type > 0 else np.zeros(len(xy), dtype=bool)
+        if self.run_type == 0 or self.init_main_path is None:
+            d = xy - self.goal_state[:2]
+            cost = G.norm2(d[:, 0], d[:, 1]) + 10e3 * obs.astype(int)
+            return 1 + int(np.argmin(cost))
+        P = np.asarray(self.init_main_path)[:, :2]
+        prog = np.array([int(np.argmin(np.linalg.norm(q - P, axis=1))) if not o else -1 for q, o in zip(xy, obs)])
+        return 1 + int(np.argmax(prog))
 
     def path_to(self, node):
         """base_planner.py:342-363: float32 concatenation of edge states + node states."""

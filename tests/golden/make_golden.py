@@ -372,6 +372,104 @@ def run_reference_planner(scn, n_candidates, tape_seed):
                 candidates=counter["cand"])
 
 
+def _ref_planner(maze, start, goal, tape_seed, budget, run_type, counter):
+    env = ORRT.OracleCarEnv(maze_map=maze, collision_checking=False, run_type=run_type)
+    smp = _TapeSampler(ActionTape(tape_seed), counter)
+    planner = ref_rrt.RRT_Planner(start, goal, env_id="carmaze", environment=env, sampler=smp,
+                                  prediction_type="actions", action_horizon=8, local_map_size=20,
+                                  local_map_scale=0.2, global_map_scale=1.0, goal_conditioning_bias=0.85,
+                                  prop_duration=[64], time_budget=budget, max_iter=300, verbose=False,
+                                  run_type=run_type)
+    planner.device = "cpu"
+    orig_sample = planner.random_node_sample
+    orig_nearest = planner.nearest_node
+
+    def counted_nearest(sample):                       # one call per candidate whatever the sample source
+        counter["cand"] += 1
+        return orig_nearest(sample)
+    planner.nearest_node = counted_nearest
+    return planner, env
+
+
+def _plan_with_candidate_clock(planner, counter):
+    import random
+    real_time = ref_rrt.time.time
+    ref_rrt.time.time = lambda: float(counter["cand"])
+    try:
+        random.seed(42)
+        np.random.seed(42)
+        counter["cand"] = 0
+        return planner.plan()
+    finally:
+        ref_rrt.time.time = real_time
+
+
+def _tree_of(planner):
+    nodes = planner.node_list
+    index = {id(n): i for i, n in enumerate(nodes)}
+    parents = np.array([-1 if n.parent is None else index[id(n.parent)] for n in nodes], dtype=np.int32)
+    return parents, np.array([n.state for n in nodes])
+
+
+def gen_traces_run_type1(out):
+    """run_type 1 ("Original+Ref"): obstacle-ahead flags, reference-path sampling after an obstacle was
+    scanned onto the main path, furthest-along-path fallback (RRT.py:61-111,134-140,153-156,202-254)."""
+    maze = load_maze("boxes")
+    env0 = ORRT.OracleCarEnv(maze_map=maze)
+    start = np.array([*env0.cell_rowcol_to_xy(np.array([17, 2])), np.deg2rad(45.0), 0.0, 0.0, 0.0])
+    goal = np.array([*env0.cell_rowcol_to_xy(np.array([2, 17])), 0.0, 0.0, 0.0, 0.0])
+    seed, n1, n2 = 77, 300, 300
+    counter = {"cand": 0}
+    planner, env = _ref_planner(maze.copy(), start, goal, seed, n1, 1, counter)
+    planner.reset()
+    path1, act1 = _plan_with_candidate_clock(planner, counter)
+    par1, st1 = _tree_of(planner)
+    # obstacle-ahead known answers on the stage-1 tree and on random poses
+    rng = np.random.default_rng(107)
+    poses = np.concatenate([st1[:, :3], random_poses(rng, maze, 512, oob_frac=0.0)])
+    poses = poses[np.abs(poses[:, 0]) < 9.9]
+    poses = poses[np.abs(poses[:, 1]) < 9.9]
+    ahead = np.array([bool(planner.check_obstacle_ahead(np.concatenate([p, np.zeros(3)]))) for p in poses])
+    mine = G.check_obstacle_ahead(np.concatenate([poses, np.zeros((len(poses), 3))], axis=1), maze)
+    assert np.array_equal(ahead, mine)
+    out["rt1_ahead_poses"] = poses
+    out["rt1_ahead_expected"] = ahead
+    pl = ORRT.OraclePlanner(maze, start, goal, ActionTape(seed).sampler(), run_type=1)
+    r1, opath1, oact1 = pl.plan(ORRT.RandomTape(42), n1, batch=1)
+    assert not pl.sticky_triggered
+    assert np.array_equal(np.array(pl.tree.parents, dtype=np.int32), par1) and np.array_equal(np.array(pl.tree.states), st1)
+    assert (path1 is None) == (opath1 is None)
+    assert path1 is not None, "stage 1 produced no reference path; change the seed"
+    assert np.array_equal(path1, opath1) and np.array_equal(act1, oact1)
+    # stage 2: an obstacle appears on the reference path, re-plan from the start with the path as guide
+    cells = np.floor(np.stack([10.0 - path1[:, 1], path1[:, 0] + 10.0], axis=1)).astype(int)
+    k = int(len(cells) * 0.6)
+    maze2 = maze.copy()
+    maze2[cells[k][0], cells[k][1]] = 1
+    planner.update_maze(maze2)
+    planner.init_main_path = path1.copy()
+    planner.time_budget = n2
+    planner.reset(start_state=start, goal_state=goal)
+    path2, act2 = _plan_with_candidate_clock(planner, counter)
+    par2, st2 = _tree_of(planner)
+    pl2 = ORRT.OraclePlanner(maze2, start, goal, ActionTape(seed).sampler(), run_type=1, init_main_path=path1)
+    r2, opath2, oact2 = pl2.plan(ORRT.RandomTape(42), n2, batch=1)
+    assert not pl2.sticky_triggered
+    assert np.array_equal(np.array(pl2.tree.parents, dtype=np.int32), par2), "run_type 1 stage 2 parents"
+    assert np.array_equal(np.array(pl2.tree.states), st2)
+    assert (path2 is None) == (opath2 is None)
+    if path2 is not None:
+        assert np.array_equal(path2, opath2) and np.array_equal(act2, oact2)
+    out.update(rt1_seed=np.array(seed), rt1_budgets=np.array([n1, n2]), rt1_start=start, rt1_goal=goal,
+               rt1_parents1=par1, rt1_states1=st1, rt1_path1=path1, rt1_actions1=act1,
+               rt1_maze2=maze2, rt1_parents2=par2, rt1_states2=st2,
+               rt1_path2=np.zeros((0, 6), np.float32) if path2 is None else path2,
+               rt1_actions2=np.zeros((0, 2), np.float32) if act2 is None else act2,
+               rt1_has_path2=np.array(path2 is not None))
+    print(f"run_type 1: stage 1 {len(par1)} nodes, stage 2 {len(par2)} nodes, path2={'yes' if path2 is not None else 'none'}; "
+          f"oracle planner == reference planner; obstacle-ahead {ahead.mean():.2f} true on {len(poses)} poses")
+
+
 def gen_traces(out):
     scns = {
         "race": ("Race Track", "Race_Track", 1, 1, 270, 1, 10),
@@ -418,6 +516,7 @@ def main():
     gen_timesteps(meta)
     gen_unet(net)
     gen_traces(traces)
+    gen_traces_run_type1(traces)
     np.savez_compressed(os.path.join(HERE, "geometry.npz"), **geo)
     np.savez_compressed(os.path.join(HERE, "network.npz"), **net)
     np.savez_compressed(os.path.join(HERE, "traces.npz"), **traces)

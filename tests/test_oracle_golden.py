@@ -119,6 +119,32 @@ def test_planner_trace_matches_reference(tag):
     assert pl.iterations == int(g[f"trace_{tag}_iterations"]) and not pl.sticky_triggered
 
 
+def test_run_type1_trace_matches_reference():
+    """run_type 1: obstacle-ahead known answers and the two-stage trace of the reference planner
+    (RRT.py:61-111,134-140,202-254)."""
+    g = golden("traces")
+    maze = load_maze("boxes")
+    poses = g["rt1_ahead_poses"]
+    st = np.concatenate([poses, np.zeros((len(poses), 3))], axis=1)
+    assert np.array_equal(G.check_obstacle_ahead(st, maze), g["rt1_ahead_expected"])
+    start, goal, seed = g["rt1_start"], g["rt1_goal"], int(g["rt1_seed"])
+    n1, n2 = [int(v) for v in g["rt1_budgets"]]
+    pl = ORRT.OraclePlanner(maze, start, goal, ActionTape(seed).sampler(), run_type=1)
+    _, path1, act1 = pl.plan(ORRT.RandomTape(42), n1, batch=1)
+    assert np.array_equal(np.array(pl.tree.parents), g["rt1_parents1"])
+    assert np.array_equal(np.array(pl.tree.states), g["rt1_states1"])
+    assert np.array_equal(path1, g["rt1_path1"]) and np.array_equal(act1, g["rt1_actions1"])
+    pl2 = ORRT.OraclePlanner(g["rt1_maze2"], start, goal, ActionTape(seed).sampler(), run_type=1, init_main_path=path1)
+    _, path2, act2 = pl2.plan(ORRT.RandomTape(42), n2, batch=1)
+    assert np.array_equal(np.array(pl2.tree.parents), g["rt1_parents2"])
+    assert np.array_equal(np.array(pl2.tree.states), g["rt1_states2"])
+    if bool(g["rt1_has_path2"]):
+        assert np.array_equal(path2, g["rt1_path2"]) and np.array_equal(act2, g["rt1_actions2"])
+    else:
+        assert path2 is None
+    assert not pl.sticky_triggered and not pl2.sticky_triggered
+
+
 def test_rounds_reduce_to_sequential_when_independent():
     """B > 1 rounds: every candidate's parent index must refer to the round-start snapshot."""
     maze = load_maze("boxes")
