@@ -199,6 +199,25 @@ int32_t ditree_obstacle_ahead(ditree_ctx* ctx, const double* state, int32_t stri
   return DITREE_OK;
 }
 
+int32_t ditree_follow_plan(ditree_ctx* ctx, double* state_io, const float* actions, int32_t n_actions,
+                           int32_t action_idx, const float* path_xy, int32_t P, float* known_maze,
+                           const float* true_maze, float* scanned_maze, const double* goal_xy, double dt,
+                           double scan_time, double* executed, int32_t* result, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!ctx->maze) return set_err(ctx, DITREE_E_STATE, "follow_plan: no maze uploaded");
+  if (!state_io || !known_maze || !true_maze || !scanned_maze || !goal_xy || !result || n_actions < 0 ||
+      action_idx < 0 || action_idx > n_actions || P < 0 || (n_actions > 0 && !actions) || (P > 0 && !path_xy) ||
+      (n_actions > action_idx && !executed))
+    return set_err(ctx, DITREE_E_ARG, "follow_plan: bad argument");
+  if (5 * (((size_t)ctx->rows * ctx->cols + 15) & ~(size_t)15) > 64 * 1024)
+    return set_err(ctx, DITREE_E_ARG, "follow_plan: maze too large for the LDS-resident loop (<= 13104 cells)");
+  launch_follow_plan(state_io, actions, n_actions, action_idx, path_xy, P, known_maze, true_maze, scanned_maze,
+                     ctx->maze, ctx->rows, ctx->cols, goal_xy[0], goal_xy[1], dt, scan_time, executed, result,
+                     (hipStream_t)stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
 static int check_tree(ditree_ctx* ctx, const ditree_tree* t);
 
 int32_t ditree_fallback_select(ditree_ctx* ctx, const ditree_tree* tree, int32_t n_nodes, const double* goal_xy,

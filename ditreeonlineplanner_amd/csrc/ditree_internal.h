@@ -85,3 +85,7 @@ void launch_obstacle_ahead(const unsigned char* maze, int rows, int cols, const 
                            const AheadArg& ts, uint8_t* out, hipStream_t s);
 void launch_fallback_select(const ditree_tree& t, int n_nodes, double gx, double gy, const double* path_dev, int P,
                             int32_t* out_node, hipStream_t s);
+void launch_follow_plan(double* state_io, const float* actions, int n_actions, int action_idx, const float* path, int P,
+                        float* known, const float* truth, float* scanned, unsigned char* known_codes, int rows, int cols,
+                        double gx, double gy, double dt, double scan_time, double* executed, int32_t* result,
+                        hipStream_t s);

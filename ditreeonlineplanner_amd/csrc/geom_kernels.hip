@@ -221,6 +221,25 @@ __device__ __forceinline__ bool car_collides(double x, double y, double psi, con
   return f || b;
 }
 
+// car_env.py:356-396 _update_state: clip the action, explicit dynamics, one Euler step of 1/50 s.
+__device__ __forceinline__ void car_euler_step(double* s, double a0r, double a1r) {
+  // car_env.py:32,47-53
+  const double dt = 1.0 / 50.0, m = 0.043, C1 = 0.5, C2 = 15.5, Cm1 = 0.28, Cm2 = 0.05, Cr0 = 0.011, Cr2 = 0.006;
+  // np.clip(action, [-10,-2], [10,2]) car_env.py:371; NaN propagates like numpy
+  double a0 = a0r < -10.0 ? -10.0 : (a0r > 10.0 ? 10.0 : a0r);
+  double a1 = a1r < -2.0 ? -2.0 : (a1r > 2.0 ? 2.0 : a1r);
+  const double psi = s[2], v = s[3], D = s[4], dl = s[5];
+  double Fxd = (Cm1 - Cm2 * v) * D - Cr2 * (v * v) - Cr0 * tanh(5.0 * v);     // :380
+  double ang = psi + C1 * dl;
+  double d0 = v * cos(ang), d1 = v * sin(ang), d2 = v * C2 * dl, d3 = (Fxd / m) * cos(C1 * dl);
+  s[0] = s[0] + dt * d0;
+  s[1] = s[1] + dt * d1;
+  s[2] = s[2] + dt * d2;
+  s[3] = s[3] + dt * d3;
+  s[4] = s[4] + dt * a0;
+  s[5] = s[5] + dt * a1;
+}
+
 // ------------------------------------------------------------------------- rollout
 // One thread per candidate: A Euler steps, each with goal + collision test, early exit.
 __global__ void __launch_bounds__(256)
@@ -246,27 +265,13 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
 #pragma unroll
     for (int k = 0; k < 6; ++k) so[k] = s[k];                                   // states_sequence[0] = state
   }
-  // car_env.py:32,47-53
-  const double dt = 1.0 / 50.0, m = 0.043, C1 = 0.5, C2 = 15.5, Cm1 = 0.28, Cm2 = 0.05, Cr0 = 0.011, Cr2 = 0.006;
   int status = DITREE_ST_OK;
   int steps = 0;
   double la0 = 0.0, la1 = 0.0;
   int i = 0;
   for (; i < A; ++i) {
     const double a0r = act[2 * i], a1r = act[2 * i + 1];
-    // np.clip(action, [-10,-2], [10,2]) car_env.py:371; NaN propagates like numpy
-    double a0 = a0r < -10.0 ? -10.0 : (a0r > 10.0 ? 10.0 : a0r);
-    double a1 = a1r < -2.0 ? -2.0 : (a1r > 2.0 ? 2.0 : a1r);
-    const double psi = s[2], v = s[3], D = s[4], dl = s[5];
-    double Fxd = (Cm1 - Cm2 * v) * D - Cr2 * (v * v) - Cr0 * tanh(5.0 * v);     // :380
-    double ang = psi + C1 * dl;
-    double d0 = v * cos(ang), d1 = v * sin(ang), d2 = v * C2 * dl, d3 = (Fxd / m) * cos(C1 * dl);
-    s[0] = s[0] + dt * d0;
-    s[1] = s[1] + dt * d1;
-    s[2] = s[2] + dt * d2;
-    s[3] = s[3] + dt * d3;
-    s[4] = s[4] + dt * a0;
-    s[5] = s[5] + dt * a1;
+    car_euler_step(s, a0r, a1r);
     steps = i + 1;
     if (so) {
 #pragma unroll
@@ -358,6 +363,67 @@ __device__ __forceinline__ bool border_solve(double rx, double ry, double dx, do
   return true;
 }
 
+// One ray of Lidar2DSim._cast_ray + the endpoint re-derivation of scan() (lidar_2d_sim.py:18-98).  `mz` holds
+// 1 for occupied cells, visited cells are OR-ed into `vis`.
+__device__ __forceinline__ void lidar_ray(double x0, double y0, double yaw, int ray, const unsigned char* mz, int rows,
+                                          int cols, unsigned char* vis, double* d_out, double* ex_out, double* ey_out,
+                                          bool* hit_out) {
+  // maze_width, maze_height = maze_data.shape (sic, :51): "width" = rows
+  const double mw = (double)rows, mh = (double)cols;
+  const double angle = -180.0 + 2.0 * (double)ray;                 // np.arange(-180, 182, 2)
+  const double ang = (yaw + angle) * (M_PI / 180.0);               // np.deg2rad(yaw + angle) (:53-54)
+  const double rx = cos(ang), ry = sin(ang);
+  // borders Left, Right, Bottom, Top (:57-62): origin b0, direction d
+  const double bx[4] = {0.0, mw, 0.0, 0.0}, by[4] = {0.0, 0.0, 0.0, mh};
+  const double dxs[4] = {0.0, 0.0, mw, mw}, dys[4] = {mh, mh, 0.0, 0.0};
+  double lx = x0, ly = y0;
+  bool found = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (found) continue;
+    double t, s;
+    if (border_solve(rx, ry, dxs[k], dys[k], bx[k] - x0, by[k] - y0, &t, &s)) {
+      if (t >= 0.0 && s <= 1.0 && s >= 0.0) {                        // :74
+        lx = t * rx + x0;
+        ly = t * ry + y0;
+        found = true;
+      }
+    }
+  }
+  const double vx = lx - x0, vy = ly - y0;
+  const double len = sqrt(fma(vy, vy, vx * vx));                     // np.linalg.norm (ddot = one fma)
+  const double step = 0.1 / len;                                     // :85
+  // len(np.arange(0, 1, step)) = ceil((1 - 0) / step)
+  double nf = ceil(1.0 / step);
+  long long n = (found && nf > 0.0 && nf < 1e9) ? (long long)nf : 0;
+  bool h = false;
+  double ox = lx, oy = ly;
+  for (long long i = 0; i < n; ++i) {
+    double t = (double)i * step;                                     // arange value start + i*delta
+    double px = x0 + t * vx, py = y0 + t * vy;                       // :86
+    double fx = floor(px), fy = floor(py);
+    int qx = fx >= 0.0 ? (fx < mw ? (int)fx : rows - 1) : 0;         // clip to [0, maze_width-1]  (:89)
+    int qy = fy >= 0.0 ? (fy < mh ? (int)fy : cols - 1) : 0;         // clip to [0, maze_height-1]
+    // maze_data[q_y, q_x] (:91): q_y indexes rows.  On non-square maps the reference's swapped
+    // clip bounds can index past the array (IndexError); clamp so the device never faults.
+    int rr = min(qy, rows - 1), cc = min(qx, cols - 1);
+    if (mz[rr * cols + cc] == 1) {
+      h = true;
+      ox = px;
+      oy = py;
+      break;
+    }
+    vis[rr * cols + cc] = 1;                                         // benign race: all writers store 1
+  }
+  double ex = ox - x0, ey = oy - y0;
+  double d = sqrt(fma(ey, ey, ex * ex));                             // :96
+  d = d < 0.0 ? 0.0 : (d > 300.0 ? 300.0 : d);                       // scan(): np.clip(d, 0, max_range) (:33)
+  *d_out = d;
+  *ex_out = x0 + d * rx;                                             // :36-39
+  *ey_out = y0 + d * ry;
+  *hit_out = h;
+}
+
 __global__ void __launch_bounds__(192)
 lidar_scan_kernel(const double* __restrict__ poses, const float* __restrict__ maze, int rows, int cols,
                   double* __restrict__ dist, double* __restrict__ endpoints, uint8_t* __restrict__ hit,
@@ -374,60 +440,13 @@ lidar_scan_kernel(const double* __restrict__ poses, const float* __restrict__ ma
   const int b = blockIdx.x;
   const int ray = threadIdx.x;
   const double x0 = poses[(size_t)b * 3 + 0], y0 = poses[(size_t)b * 3 + 1], yaw = poses[(size_t)b * 3 + 2];
-  // maze_width, maze_height = maze_data.shape (sic, :51): "width" = rows
-  const double mw = (double)rows, mh = (double)cols;
   if (ray < DITREE_LIDAR_RAYS) {
-    const double angle = -180.0 + 2.0 * (double)ray;                 // np.arange(-180, 182, 2)
-    const double ang = (yaw + angle) * (M_PI / 180.0);               // np.deg2rad(yaw + angle) (:53-54)
-    const double rx = cos(ang), ry = sin(ang);
-    // borders Left, Right, Bottom, Top (:57-62): origin b0, direction d
-    const double bx[4] = {0.0, mw, 0.0, 0.0}, by[4] = {0.0, 0.0, 0.0, mh};
-    const double dxs[4] = {0.0, 0.0, mw, mw}, dys[4] = {mh, mh, 0.0, 0.0};
-    double lx = x0, ly = y0;
-    bool found = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (found) continue;
-      double t, s;
-      if (border_solve(rx, ry, dxs[k], dys[k], bx[k] - x0, by[k] - y0, &t, &s)) {
-        if (t >= 0.0 && s <= 1.0 && s >= 0.0) {                        // :74
-          lx = t * rx + x0;
-          ly = t * ry + y0;
-          found = true;
-        }
-      }
-    }
-    const double vx = lx - x0, vy = ly - y0;
-    const double len = sqrt(fma(vy, vy, vx * vx));                     // np.linalg.norm (ddot = one fma)
-    const double step = 0.1 / len;                                     // :85
-    // len(np.arange(0, 1, step)) = ceil((1 - 0) / step)
-    double nf = ceil(1.0 / step);
-    long long n = (found && nf > 0.0 && nf < 1e9) ? (long long)nf : 0;
-    bool h = false;
-    double ox = lx, oy = ly;
-    for (long long i = 0; i < n; ++i) {
-      double t = (double)i * step;                                     // arange value start + i*delta
-      double px = x0 + t * vx, py = y0 + t * vy;                       // :86
-      double fx = floor(px), fy = floor(py);
-      int qx = fx >= 0.0 ? (fx < mw ? (int)fx : rows - 1) : 0;         // clip to [0, maze_width-1]  (:89)
-      int qy = fy >= 0.0 ? (fy < mh ? (int)fy : cols - 1) : 0;         // clip to [0, maze_height-1]
-      // maze_data[q_y, q_x] (:91): q_y indexes rows.  On non-square maps the reference's swapped
-      // clip bounds can index past the array (IndexError); clamp so the device never faults.
-      int rr = min(qy, rows - 1), cc = min(qx, cols - 1);
-      if (mz[rr * cols + cc] == 1) {
-        h = true;
-        ox = px;
-        oy = py;
-        break;
-      }
-      vis[rr * cols + cc] = 1;                                         // benign race: all writers store 1
-    }
-    double ex = ox - x0, ey = oy - y0;
-    double d = sqrt(fma(ey, ey, ex * ex));                             // :96
-    d = d < 0.0 ? 0.0 : (d > 300.0 ? 300.0 : d);                       // scan(): np.clip(d, 0, max_range) (:33)
+    double d, ex, ey;
+    bool h;
+    lidar_ray(x0, y0, yaw, ray, mz, rows, cols, vis, &d, &ex, &ey, &h);
     dist[(size_t)b * DITREE_LIDAR_RAYS + ray] = d;
-    endpoints[((size_t)b * DITREE_LIDAR_RAYS + ray) * 2 + 0] = x0 + d * rx;   // :36-39
-    endpoints[((size_t)b * DITREE_LIDAR_RAYS + ray) * 2 + 1] = y0 + d * ry;
+    endpoints[((size_t)b * DITREE_LIDAR_RAYS + ray) * 2 + 0] = ex;
+    endpoints[((size_t)b * DITREE_LIDAR_RAYS + ray) * 2 + 1] = ey;
     hit[(size_t)b * DITREE_LIDAR_RAYS + ray] = h ? 1 : 0;
   }
   if (visited != nullptr) {
@@ -440,6 +459,131 @@ void launch_lidar_scan(const double* poses, int B, const float* maze, int rows, 
   size_t n = ((size_t)rows * cols + 15) & ~(size_t)15;
   hipLaunchKernelGGL(lidar_scan_kernel, dim3(B), dim3(192), 2 * n, s, poses, maze, rows, cols, dist, endpoints,
                      hit, visited);
+}
+
+// ------------------------------------------------------------------------- plan following (online loop)
+// run_scenarios_with_lidar_DiTree.py:470-506 (run_type < 4) as ONE launch: execute the plan's actions one env step
+// at a time (propagate_action_sequence_env: step, goal test, collision test against the KNOWN maze), and every
+// time the accumulated step time exceeds scan_time scan the TRUE maze from the pose (scan_and_update_maze,
+// :112-127), write the ray end cells into the known / scanned mazes and test the planned path for a crossing
+// (check_no_obstacles_in_path, :158-181).  One workgroup: thread 0 integrates, threads 0..180 cast the rays,
+// all threads scan the path.  The three mazes live in LDS for the whole launch.
+__device__ __forceinline__ unsigned char maze_code(float v) {
+  int c = (int)v;
+  return (v == (float)c && c >= 0 && c < 256) ? (unsigned char)c : (unsigned char)255;
+}
+__global__ void __launch_bounds__(256)
+follow_plan_kernel(double* __restrict__ state_io, const float* __restrict__ actions, int n_actions, int action_idx,
+                   const float* __restrict__ path, int P, float* __restrict__ known, const float* __restrict__ truth,
+                   float* __restrict__ scanned, unsigned char* __restrict__ known_codes, int rows, int cols, double gx,
+                   double gy, double dt, double scan_time, double* __restrict__ executed, int32_t* __restrict__ result) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int ncell = rows * cols, pad = (ncell + 15) & ~15;
+  unsigned char* kn = lds;                 // known maze codes
+  unsigned char* tr = lds + pad;           // true maze: 1 = occupied
+  unsigned char* sc = lds + 2 * pad;       // scanned maze codes
+  unsigned char* vis = lds + 3 * pad;      // cells visited by the current scan
+  unsigned char* dirty = lds + 4 * pad;    // cells of known / scanned written by this launch
+  __shared__ double s[6];
+  __shared__ int sh_event, sh_obstacle, sh_scan, sh_done;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < ncell; i += blockDim.x) {
+    kn[i] = maze_code(known[i]);
+    tr[i] = truth[i] == 1.0f ? 1 : 0;
+    sc[i] = maze_code(scanned[i]);
+    vis[i] = 0;
+    dirty[i] = 0;
+  }
+  if (tid < 6) s[tid] = state_io[tid];
+  if (tid == 0) { sh_event = -1; sh_obstacle = 0x7fffffff; sh_scan = 0; sh_done = 0; }
+  __syncthreads();
+  double t_acc = 0.0;                      // thread 0 only
+  int idx = action_idx, n_scans = 0;
+  const float hf = (float)((double)rows / 2.0), wf = (float)((double)cols / 2.0);
+  while (idx < n_actions) {
+    if (tid == 0) {
+      double st[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) st[k] = s[k];
+      car_euler_step(st, (double)actions[2 * idx], (double)actions[2 * idx + 1]);
+      const double ex = st[0] - gx, ey = st[1] - gy;
+      const bool done = sqrt(fma(ey, ey, ex * ex)) < 0.5;                        // car_env.py:346-351
+      if (car_collides(st[0], st[1], st[2], kn, rows, cols)) {                   // base_planner.py:306 -> done is None
+        sh_event = 2;
+      } else {
+        double* eo = executed + (size_t)(idx - action_idx) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { s[k] = st[k]; eo[k] = st[k]; }
+        sh_done = done ? 1 : 0;
+        t_acc += dt;
+        sh_scan = t_acc > scan_time ? 1 : 0;
+        if (sh_scan) t_acc = 0.0;
+      }
+    }
+    __syncthreads();
+    if (sh_event == 2) break;
+    ++idx;
+    if (sh_scan) {
+      ++n_scans;
+      // pose in fractional cell units (col, row), yaw in radians (:113-116)
+      const double px = (s[0] + (double)cols / 2.0) / 1.0, py = ((double)rows / 2.0 - s[1]) / 1.0, yaw = s[2];
+      double d, ex = 0.0, ey = 0.0;
+      bool h;
+      if (tid < DITREE_LIDAR_RAYS) lidar_ray(px, py, yaw, tid, tr, rows, cols, vis, &d, &ex, &ey, &h);
+      __syncthreads();
+      for (int i = tid; i < ncell; i += blockDim.x) {                            // scanned[visited] = 2 (:121)
+        if (vis[i]) { sc[i] = 2; dirty[i] = 1; vis[i] = 0; }
+      }
+      __syncthreads();
+      if (tid < DITREE_LIDAR_RAYS) {                                             // end cells -> occupied (:119-122)
+        const double fx = floor(ex), fy = floor(ey);
+        if (fx >= 0.0 && fx < (double)cols && fy >= 0.0 && fy < (double)rows) {
+          const int c = (int)fy * cols + (int)fx;
+          kn[c] = 1;
+          sc[c] = 1;
+          dirty[c] = 1;
+        }
+      }
+      __syncthreads();
+      int first = 0x7fffffff;                                                    // :158-181 in the path's float32
+      for (int i = tid; i < P; i += blockDim.x) {
+        const float row = (hf - path[2 * i + 1]) / 1.0f, col = (path[2 * i] + wf) / 1.0f;
+        const float fr = floorf(row), fc = floorf(col);
+        if (fr >= 0.0f && fr < (float)rows && fc >= 0.0f && fc < (float)cols && sc[(int)fr * cols + (int)fc] == 1) {
+          first = i;
+          break;
+        }
+      }
+      if (first != 0x7fffffff) atomicMin(&sh_obstacle, first);
+      __syncthreads();
+    }
+    if (sh_done) { if (tid == 0) sh_event = 1; break; }
+    if (sh_obstacle != 0x7fffffff) { if (tid == 0) sh_event = 3; break; }
+    __syncthreads();                       // thread 0 rewrites sh_scan / s in the next iteration
+  }
+  __syncthreads();
+  for (int i = tid; i < ncell; i += blockDim.x) {
+    if (dirty[i]) {
+      known[i] = (float)kn[i];
+      scanned[i] = (float)sc[i];
+    }
+    known_codes[i] = kn[i];
+  }
+  if (tid < 6) state_io[tid] = s[tid];
+  if (tid == 0) {
+    result[0] = sh_event < 0 ? 0 : sh_event;
+    result[1] = idx;
+    result[2] = sh_obstacle == 0x7fffffff ? -1 : sh_obstacle;
+    result[3] = n_scans;
+  }
+}
+void launch_follow_plan(double* state_io, const float* actions, int n_actions, int action_idx, const float* path, int P,
+                        float* known, const float* truth, float* scanned, unsigned char* known_codes, int rows, int cols,
+                        double gx, double gy, double dt, double scan_time, double* executed, int32_t* result,
+                        hipStream_t s) {
+  size_t pad = ((size_t)rows * cols + 15) & ~(size_t)15;
+  hipLaunchKernelGGL(follow_plan_kernel, dim3(1), dim3(256), 5 * pad, s, state_io, actions, n_actions, action_idx, path,
+                     P, known, truth, scanned, known_codes, rows, cols, gx, gy, dt, scan_time, executed, result);
 }
 
 // ------------------------------------------------------------------------- round bookkeeping

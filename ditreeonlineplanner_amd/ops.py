@@ -170,6 +170,30 @@ class Context:
                                                     self.stream), "obstacle_ahead")
         return out
 
+    # ------------------------------------------------------------------ online plan following
+    def follow_plan(self, state, actions, action_idx, path_xy, known, true_maze, scanned, goal_xy, dt, scan_time):
+        """run_scenarios_with_lidar_DiTree.py:470-506 in one launch (see include/ditree.h).  All tensors on the
+        device: state (6) f64 [in/out], actions (n, 2) f32, path_xy (P, 2) f32, known / scanned (R, C) f32
+        [in/out], true_maze (R, C) f32.  Returns (executed (k, 6) f64, event, next action index, obstacle index)."""
+        dev = self.device
+        _chk(state, torch.float64, "state", dev)
+        _chk(actions, torch.float32, "actions", dev)
+        _chk(path_xy, torch.float32, "path_xy", dev)
+        for nm, t in (("known", known), ("true_maze", true_maze), ("scanned", scanned)):
+            _chk(t, torch.float32, nm, dev)
+            if tuple(t.shape) != tuple(known.shape):
+                raise ValueError(f"{nm}: maze shapes differ")
+        n = actions.shape[0]
+        executed = torch.zeros(max(n - int(action_idx), 0), 6, dtype=torch.float64, device=dev)
+        result = torch.zeros(4, dtype=torch.int32, device=dev)
+        g, gp = _dbl(np.asarray(goal_xy, dtype=np.float64)[:2])
+        check(self._h, lib().ditree_follow_plan(self._h, _ptr(state), _ptr(actions), n, int(action_idx), _ptr(path_xy),
+                                                 path_xy.shape[0], _ptr(known), _ptr(true_maze), _ptr(scanned), gp,
+                                                 float(dt), float(scan_time), _ptr(executed), _ptr(result),
+                                                 self.stream), "follow_plan")
+        event, nxt, obstacle, _ = [int(v) for v in result.cpu().numpy()]
+        return executed[: nxt - int(action_idx)], event, nxt, obstacle
+
     # ------------------------------------------------------------------ lidar
     def lidar_scan(self, poses, maze_dev, want_visited=True):
         dev = self.device

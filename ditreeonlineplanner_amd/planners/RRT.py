@@ -76,6 +76,13 @@ class RRT_Planner(BasePlanner):
         self.env.maze_map = new_maze
         self._engine.update_maze(self.maze)
 
+    def adopt_maze(self, new_maze):
+        """Take a known maze whose device copy is already current (online.follow_plan refreshes it in its own
+        launch): same bookkeeping as ``update_maze`` without the upload."""
+        self.maze = np.float32(new_maze)
+        self.env.maze_map = new_maze
+        self._engine.maze = self.maze
+
     @property
     def node_list(self):
         """Materialise ``Node`` objects from the device tree (RRT.py:42, base_planner.py:24-34)."""

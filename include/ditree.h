@@ -177,6 +177,28 @@ int32_t ditree_fallback_select(ditree_ctx* ctx, const ditree_tree* tree, int32_t
                                const double* goal_xy /*[host] 2*/, const double* path /*[host] or NULL*/,
                                int32_t P, int32_t* out_node, void* stream);
 
+/* Plan following of the online driver (run_scenarios_with_lidar_DiTree.py:470-506, run_type < 4) fused into
+ * one launch: per action one env step with goal test and collision test against the KNOWN maze
+ * (planners/base_planner.py:257-320 with a single action); whenever the accumulated step time exceeds
+ * scan_time, scan_and_update_maze (:112-127: lidar scan of the TRUE maze from the pose, ray end cells written
+ * as occupied into the known and the scanned maze, visited cells = 2) and check_no_obstacles_in_path
+ * (:158-181, evaluated in the path's float32).  Stops at the first event.
+ *   state_io [dev] (6) f64 in/out; actions [dev] (n_actions, 2) f32 (the plan's dtype); path_xy [dev] (P, 2) f32;
+ *   known / scanned [dev] (rows, cols) f32 in/out, true_maze [dev] (rows, cols) f32 (rows, cols = the uploaded
+ *   maze's; the ctx's own copy of the known maze is refreshed, so no re-upload is needed before the next
+ *   expansion round); goal_xy [host] 2; executed [dev] (n_actions - action_idx, 6) f64: state after every
+ *   executed action; result [dev] 4 x i32: event (DITREE_EV_*), next action index, first blocked path index
+ *   or -1, number of scans.  Ray end cells outside the map (only possible without border walls, where the
+ *   reference raises IndexError) are dropped.  rows * cols <= 13104 (five byte maps of the maze stay in LDS). */
+#define DITREE_EV_ACTIONS_DONE 0
+#define DITREE_EV_GOAL 1
+#define DITREE_EV_COLLISION 2
+#define DITREE_EV_OBSTACLE 3
+int32_t ditree_follow_plan(ditree_ctx* ctx, double* state_io, const float* actions, int32_t n_actions,
+                           int32_t action_idx, const float* path_xy, int32_t P, float* known_maze,
+                           const float* true_maze, float* scanned_maze, const double* goal_xy /*[host] 2*/,
+                           double dt, double scan_time, double* executed, int32_t* result, void* stream);
+
 /* ------------------------------------------------------------------ denoiser */
 
 /* Upload the denoiser weights (reference: run_scenarios.py:157-185, state-dict keys

@@ -505,7 +505,171 @@ def gen_traces(out):
               f"{r['iterations']} chunk-iterations, oracle planner == reference planner")
 
 
+def _driver_functions(names):
+    """Functions of run_scenarios_with_lidar_DiTree.py taken from its text: the script's top-level imports
+    (playsound, minari, gymnasium, drone_env ...) are absent here, so it cannot be imported as a module."""
+    import ast
+    path = os.path.join(REF, "run_scenarios_with_lidar_DiTree.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    mod = ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names], type_ignores=[])
+    ns = {"np": np, "plt": None}
+    exec(compile(mod, path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def _drive(maze, start, waypoints_rc, v_des=0.6, max_steps=4000, switch=0.25):
+    """Test scaffolding: a waypoint-following controller on the oracle dynamics that yields a drivable
+    (states f32, actions f32) plan through a corridor maze, as a planner would return it."""
+    wp = [np.array(G.cell_rowcol_to_xy(rc, maze)) for rc in waypoints_rc]
+    s = np.asarray(start, dtype=np.float64).copy()
+    acts, states, k = [], [s.copy()], 0
+    for _ in range(max_steps):
+        while k < len(wp) - 1 and np.hypot(*(wp[k] - s[:2])) < switch:
+            k += 1
+        if k == len(wp) - 1 and np.hypot(*(wp[k] - s[:2])) < 0.2:
+            break
+        err = np.arctan2(wp[k][1] - s[1], wp[k][0] - s[0]) - s[2]
+        err = (err + np.pi) % (2 * np.pi) - np.pi
+        a1 = np.clip((np.clip(0.8 * err, -0.35, 0.35) - s[5]) * 10, -2, 2)
+        vd = v_des * (0.4 if abs(err) > 0.5 else 1.0)
+        a0 = np.clip((np.clip(0.5 * (vd - s[3]) + 0.06, -0.5, 1.0) - s[4]) * 20, -10, 10)
+        a = np.array([a0, a1], dtype=np.float32)
+        s = G.car_step(s[None], a.astype(np.float64)[None])[0]
+        assert not G.is_colliding_car(s[None, :3], maze)[0]
+        acts.append(a)
+        states.append(s.copy())
+    return np.array(states, dtype=np.float32), np.array(acts, dtype=np.float32)
+
+
+def gen_online(out):
+    """Online driver steps (run_scenarios_with_lidar_DiTree.py:112-127,158-181,470-506): lidar scan of the true
+    maze written into the known / scanned mazes, path-crossing check, and the action-execution loop, driven with the
+    reference planner's propagate_action_sequence_env and the reference's Lidar2DSim."""
+    from oracle import online as OO
+    ref_scan, ref_check = _driver_functions(["scan_and_update_maze", "check_no_obstacles_in_path"])
+    tr = np.load(os.path.join(HERE, "traces.npz"))
+    cases = []
+
+    def scenario(tag):
+        maze = load_maze(str(tr[f"trace_{tag}_maze_name"]))
+        sr, sc, sdeg, gr, gc = [int(v) for v in tr[f"trace_{tag}_scenario"]]
+        start = np.array([*G.cell_rowcol_to_xy([sr, sc], maze), np.deg2rad(float(sdeg)), 0, 0, 0])
+        goal = np.array([*G.cell_rowcol_to_xy([gr, gc], maze), 0, 0, 0, 0])
+        return maze, start, goal, tr[f"trace_{tag}_path"], tr[f"trace_{tag}_actions"]
+
+    def run_case(tag, scn, true_maze, acts, goal_state):
+        maze, start, _, path, _ = scn
+        counter = {"cand": 0}
+        planner, env = _ref_planner(maze.copy(), start, goal_state, 1, 10, 1, counter)
+        env.lidar2dsim = RefLidar()
+        planner.reset(start_state=start, goal_state=goal_state)
+        known, scanned = maze.copy(), maze.copy()
+        oknown, oscanned = maze.copy(), maze.copy()
+        ref_scan(planner, known, true_maze, scanned)                       # :415-416 initial scan (float32 env state)
+        OO.scan_and_update_maze(env.state, oknown, true_maze, oscanned)
+        assert np.array_equal(known, oknown) and np.array_equal(scanned, oscanned), "initial scan"
+        res = {"known0": known.copy(), "scanned0": scanned.copy()}
+        # :432-506 (run_type < 4) restated around the reference pieces
+        env.reset_done()
+        cur = start.copy()
+        idx, obstacle, t_acc, done = 0, -1, 0, False
+        executed = []
+        env.set_state(cur)
+        while idx < acts.shape[0] and obstacle < 0 and not done:
+            nxt, done, _, visited = planner.propagate_action_sequence_env(cur, acts[idx, np.newaxis])
+            if done is None:
+                break
+            executed.append(visited[0, 1, :])
+            cur = nxt
+            env.set_state(cur)
+            idx += 1
+            t_acc += env.dt
+            if t_acc > env.lidar2dsim.scan_time:
+                ref_scan(planner, known, true_maze, scanned)
+                obstacle = ref_check(planner, scanned, path)
+                t_acc = 0
+        event = OO.EV_COLLISION if done is None else OO.EV_GOAL if done else OO.EV_OBSTACLE if obstacle >= 0 \
+            else OO.EV_ACTIONS_DONE
+        o = OO.follow_plan(start, acts, 0, path, oknown, true_maze, oscanned, env.goal, dt=env.dt,
+                           scan_time=env.lidar2dsim.scan_time)
+        assert o["event"] == event and o["action_idx"] == idx and o["obstacle_idx"] == obstacle, (tag, o["event"], event)
+        assert np.array_equal(o["executed"], np.array(executed).reshape(-1, 6)) and np.array_equal(o["state"], cur)
+        assert np.array_equal(known, oknown) and np.array_equal(scanned, oscanned), "mazes after the loop"
+        res.update(maze=maze, start=start, path=path, true=true_maze, actions=acts,
+                   goal_xy=np.asarray(env.goal, dtype=np.float64), known1=known.copy(), scanned1=scanned.copy(),
+                   executed=np.array(executed).reshape(-1, 6), result=np.array([event, idx, obstacle], dtype=np.int64),
+                   state=cur)
+        note = f"{tag}: event {event} after {idx}/{len(acts)} actions, obstacle idx {obstacle}"
+        return res, note, planner
+
+    def keep(tag, res, note):
+        for k, v in res.items():
+            out[f"online_{tag}_{k}"] = v
+        cases.append(note)
+
+    boxes = scenario("boxes")
+    maze, start, goal, path, actions = boxes
+    H = maze.shape[0]
+    cells = np.floor(np.stack([H / 2 - path[:, 1], path[:, 0] + maze.shape[1] / 2], axis=1)).astype(int)
+    # visible: an obstacle early on the path is seen by the first scan
+    tm = maze.copy()
+    k = int(len(cells) * 0.25)
+    tm[cells[k][0], cells[k][1]] = 1
+    res, note, planner = run_case("visible", boxes, tm, actions, goal)
+    assert res["result"][0] == OO.EV_OBSTACLE
+    keep("visible", res, note)
+    # free: the whole plan is executed
+    res, note, _ = run_case("free", boxes, maze.copy(), actions, goal)
+    assert res["result"][0] == OO.EV_ACTIONS_DONE
+    keep("free", res, note)
+    exe = res["executed"]
+    # goal: the goal cell lies on the executed trajectory
+    gs = goal.copy()
+    gs[:2] = exe[len(exe) // 2, :2]
+    res, note, _ = run_case("goal", boxes, maze.copy(), actions, gs)
+    assert res["result"][0] == OO.EV_GOAL
+    keep("goal", res, note)
+    # collision: an open-loop swerve that leaves the planned corridor
+    swerve = np.stack([np.full(600, 1.5), 0.6 * np.sign(np.sin(np.arange(600) / 40.0))], axis=1).astype(np.float32)
+    res, note, _ = run_case("collision", boxes, maze.copy(), swerve, goal)
+    assert res["result"][0] == OO.EV_COLLISION
+    keep("collision", res, note)
+    # hidden: in a corridor maze an obstacle behind a corner is found by a later scan
+    # (the reference's Lidar2DSim only works on square maps: its clip bounds are swapped, lidar_2d_sim.py:89-91)
+    rmaze = load_maze("val_maze_15")
+    rstart = np.array([*G.cell_rowcol_to_xy([1, 1], rmaze), np.deg2rad(270.0), 0, 0, 0])
+    rgoal = np.array([*G.cell_rowcol_to_xy([13, 13], rmaze), 0, 0, 0, 0])
+    rpath, ract = _drive(rmaze, rstart, [[5, 1], [9, 1], [9, 3], [9, 5]])
+    race = (rmaze, rstart, rgoal, rpath, ract)
+    tm = rmaze.copy()
+    tm[9, 4] = 1
+    res, note, _ = run_case("hidden", race, tm, ract, rgoal)
+    assert res["result"][0] == OO.EV_OBSTACLE and res["result"][1] > 100, note
+    keep("hidden", res, note)
+    res, note, _ = run_case("track", race, rmaze.copy(), ract, rgoal)
+    assert res["result"][0] == OO.EV_ACTIONS_DONE
+    keep("track", res, note)
+    # path-crossing check alone on perturbed scanned mazes (float32 path arithmetic)
+    rng = np.random.default_rng(11)
+    expected, marks = [], []
+    for _ in range(32):
+        sc = maze.copy()
+        rc = rng.integers(1, 19, size=(3, 2))
+        sc[rc[:, 0], rc[:, 1]] = 1
+        expected.append(ref_check(planner, sc, path))
+        assert expected[-1] == OO.check_no_obstacles_in_path(sc, path)
+        marks.append(rc)
+    out["online_check_marks"], out["online_check_expected"] = np.array(marks), np.array(expected)
+    print("online driver steps: " + "; ".join(cases) + f"; path check {np.sum(np.array(expected) >= 0)}/32 crossings; "
+          "oracle == reference")
+
+
 def main():
+    if sys.argv[1:] == ["online"]:
+        online = {}
+        gen_online(online)
+        np.savez_compressed(os.path.join(HERE, "online.npz"), **online)
+        return
     geo, net, traces, meta = {}, {}, {}, {}
     gen_collision(geo)
     gen_local_map(geo)
@@ -520,6 +684,9 @@ def main():
     np.savez_compressed(os.path.join(HERE, "geometry.npz"), **geo)
     np.savez_compressed(os.path.join(HERE, "network.npz"), **net)
     np.savez_compressed(os.path.join(HERE, "traces.npz"), **traces)
+    online = {}
+    gen_online(online)
+    np.savez_compressed(os.path.join(HERE, "online.npz"), **online)
     with open(os.path.join(HERE, "timesteps.json"), "w") as f:
         json.dump(meta, f, indent=1)
     print("wrote golden fixtures to", HERE)

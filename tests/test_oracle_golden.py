@@ -145,6 +145,29 @@ def test_run_type1_trace_matches_reference():
     assert not pl.sticky_triggered and not pl2.sticky_triggered
 
 
+@pytest.mark.parametrize("tag", ["visible", "free", "goal", "collision", "hidden", "track"])
+def test_online_loop_matches_reference(tag):
+    """run_scenarios_with_lidar_DiTree.py:112-127,158-181,470-506 (oracle/online.py) vs the reference-driven loop."""
+    from oracle import online as OO
+    g = golden("online")
+    k = lambda n: g[f"online_{tag}_{n}"]
+    known, scanned = k("known0").copy(), k("scanned0").copy()
+    o = OO.follow_plan(k("start"), k("actions"), 0, k("path"), known, k("true"), scanned, k("goal_xy"))
+    assert [o["event"], o["action_idx"], o["obstacle_idx"]] == [int(v) for v in k("result")]
+    assert np.array_equal(o["executed"], k("executed")) and np.array_equal(o["state"], k("state"))
+    assert np.array_equal(known, k("known1")) and np.array_equal(scanned, k("scanned1"))
+
+
+def test_online_path_check_known_answers():
+    from oracle import online as OO
+    g = golden("online")
+    maze, path = g["online_free_maze"], g["online_free_path"]
+    for marks, exp in zip(g["online_check_marks"], g["online_check_expected"]):
+        sc = maze.copy()
+        sc[marks[:, 0], marks[:, 1]] = 1
+        assert OO.check_no_obstacles_in_path(sc, path) == int(exp)
+
+
 def test_rounds_reduce_to_sequential_when_independent():
     """B > 1 rounds: every candidate's parent index must refer to the round-start snapshot."""
     maze = load_maze("boxes")
