@@ -13,6 +13,7 @@ import torch
 
 from .lidar_sim.lidar_2d_sim import Lidar2DSim
 from .ops import default_context
+from .prob_sampling_utils import combine_log_blend, edt_prior, gaussian_map
 
 
 class _Box:
@@ -43,12 +44,20 @@ class CarEnv:
         self.done = False
         self.terminated = False
         self.run_type = run_type
-        if run_type >= 2:
-            raise NotImplementedError("sampling-bias maps (run_type >= 2) are a later scope row (SURVEY 8(f).2)")
-        self.prob_map = np.zeros_like(self._maze_map)
         self._state = np.zeros(6)
         self._ctx = ctx
         self._maze_version = 0
+        # sampling-probability map per run_type (car_env.py:100-110; the constructor passes (row, col) to
+        # gaussian_map where the later updates pass (col, row))
+        self.prior = edt_prior(self._maze_map)
+        if run_type < 2:
+            self.prob_map = np.zeros_like(self._maze_map.copy())
+        elif run_type == 2:
+            self.prob_map = self.prior
+        else:
+            self.gaussian_pdf, _, _ = gaussian_map(self.cell_xy_to_rowcol(self.state[:2]),
+                                                   self.cell_xy_to_rowcol(self.goal[:2]))
+            self.prob_map = combine_log_blend(self.prior, self.gaussian_pdf)
 
     # ------------------------------------------------------------------ maze / geometry helpers
     @property
@@ -63,8 +72,14 @@ class CarEnv:
 
     @maze_map.setter
     def maze_map(self, new_maze_map):
+        """car_env.py:117-128: a new known maze also refreshes the EDT prior and the sampling map."""
         self._maze_map = np.asarray(new_maze_map)
         self._maze_version += 1
+        self.prior = edt_prior(self._maze_map)
+        if self.run_type == 2:
+            self.prob_map = self.prior
+        elif self.run_type >= 3:
+            self.update_prob_map_by_loc()
 
     @property
     def maze_size_scaling(self):
@@ -94,7 +109,11 @@ class CarEnv:
         return np.floor(ret) if floor_enable else ret
 
     def update_prob_map_by_loc(self):
-        pass
+        """car_env.py:130-137: prior log-blended with the Gaussian from the current cell to the goal cell."""
+        here = self.cell_xy_to_rowcol(self.state[:2])[::-1]
+        there = self.cell_xy_to_rowcol(self.goal[:2])[::-1]
+        self.gaussian_pdf, _, _ = gaussian_map(here, there)
+        self.prob_map = combine_log_blend(self.prior, self.gaussian_pdf)
 
     # ------------------------------------------------------------------ gym-like API
     def reset(self, *, seed=None, options=None, **kwargs):

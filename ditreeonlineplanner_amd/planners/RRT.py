@@ -8,10 +8,10 @@ Constructor kwargs, ``plan() -> (path f32 (P,6)|None, actions f32 (A,2)|None)``,
                        reference abandons a collided edge; results are identical either way,
   ``edge_length``      = prop_duration[0] (the reference's per-visit schedule needs sequential
                        visits; a schedule with more than one entry raises NotImplementedError).
-``run_type`` 0 ("Original") and 1 ("Original+Ref": obstacle-ahead flags per node, sampling biased to the
-part of ``init_main_path`` behind the obstacle, furthest-along-path fallback) are covered; ``run_type`` >= 2
-draws samples from the reference's sampling-probability maps (car_env.py:102-126, base_planner.py:181),
-which is outside this engine.
+All of the reference's ``run_type`` values: 0 "Original"; 1 "Original+Ref" (obstacle-ahead flags per node, sampling
+biased to the part of ``init_main_path`` behind the obstacle, furthest-along-path fallback); 2 "OM+Ref" (sample
+positions drawn from the EDT prior); 3 "OM+LB+Ref" (prior log-blended with the start -> goal Gaussian, refreshed at
+every plan); 4 adds the driver's forced re-plan and is the same as 3 inside the planner.
 """
 from __future__ import annotations
 
@@ -38,8 +38,6 @@ class RRT_Planner(BasePlanner):
         self.plan_count = 0
         self.init_main_path = None
         self.run_type = kwargs.get("run_type", 0)
-        if self.run_type >= 2:
-            raise NotImplementedError("run_type >= 2 samples from the sampling-probability maps (out of scope)")
         self.env.run_type = self.run_type
         self.batch = int(kwargs.get("batch", 256))
         self.max_candidates = kwargs.get("max_candidates", None)
@@ -161,6 +159,9 @@ class RRT_Planner(BasePlanner):
         start_time = time.time()
         drawn = 0
         goal = None
+        orig_prob_map = self.env.prob_map.copy()             # RRT.py:122-125
+        if self.run_type >= 3:
+            self.env.update_prob_map_by_loc()
         remain = None
         if self.run_type > 0 and self.init_main_path is not None:
             remain = self.extract_path_after_obstacle()
@@ -177,6 +178,7 @@ class RRT_Planner(BasePlanner):
             if goal is not None:
                 break
         iters = int(eng.tree.counters[CNT_ITERS].item())
+        self.env.prob_map = orig_prob_map
         if goal is not None:
             self.env.done = True
             return self.handle_goal_reached(goal, iters, start_time)

@@ -141,11 +141,24 @@ class BasePlanner(abc.ABC):
         return obs, done, acts, st_full[: len(acts) + 1][None, :]
 
     # ------------------------------------------------------------------ sampling (host, reference RNG order)
+    def sample_row_col_from_probability_map(self):
+        """planners/base_planner.py:157-160: one categorical draw over the env's sampling-probability map."""
+        pm = self.env.prob_map
+        flat = np.random.choice(pm.size, size=1, p=pm.ravel())
+        row, col = np.unravel_index(flat, pm.shape)
+        return row[np.newaxis], col[np.newaxis]
+
     def random_node_sample(self, batch_size=1):
-        """planners/base_planner.py:162-207 (car, run_type < 2): python ``random`` then ``np.random``."""
+        """planners/base_planner.py:162-207 (car): python ``random`` then ``np.random``; run_type >= 2 draws the
+        position as the centre of a cell of the sampling-probability map instead of uniformly."""
         if random.random() > self.goal_sample_rate:
-            x = np.random.uniform(-self.map_width / 2, self.map_width / 2, size=(batch_size, 1))
-            y = np.random.uniform(-self.map_length / 2, self.map_length / 2, size=(batch_size, 1))
+            if getattr(self, "run_type", 0) >= 2:
+                rows, cols = self.sample_row_col_from_probability_map()
+                x, y = self.env.cell_rowcol_to_xy(np.array([rows[0], cols[0]]))
+                x, y = x[np.newaxis], y[np.newaxis]
+            else:
+                x = np.random.uniform(-self.map_width / 2, self.map_width / 2, size=(batch_size, 1))
+                y = np.random.uniform(-self.map_length / 2, self.map_length / 2, size=(batch_size, 1))
             theta = np.random.uniform(-np.pi, np.pi, size=(batch_size, 1))
             v = np.random.uniform(-self.max_v, self.max_v, size=(batch_size, 1))
             throttle = np.random.uniform(-1, 1, size=(batch_size, 1))

@@ -106,9 +106,9 @@ class DiffusionSampler(nn.Module):
             last = np.zeros((B, self.action_dim))
             has_prev = np.zeros(B, dtype=np.uint8)
         g = np.broadcast_to(np.asarray(goal, dtype=np.float64).reshape(-1, 2), (B, 2))
-        cond = ctx.cond_vector(state, torch.as_tensor(np.array(last, dtype=np.float64), device=dev),
+        cond = ctx.cond_vector(state, torch.as_tensor(np.ascontiguousarray(last, dtype=np.float64), device=dev),
                                torch.as_tensor(has_prev, device=dev),
-                               torch.as_tensor(np.array(g, dtype=np.float64), device=dev), self.local_map_size, self.norm)
+                               torch.as_tensor(np.ascontiguousarray(g, dtype=np.float64), device=dev), self.local_map_size, self.norm)
         lm = torch.as_tensor(local_map, dtype=torch.float32, device=dev)
         if lm.dim() == 2:
             lm = lm.unsqueeze(0)

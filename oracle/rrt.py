@@ -41,12 +41,23 @@ class RandomTape:
         self.py = _pyrandom.Random(seed)
         self.np = np.random.RandomState(seed)
 
-    def draw_candidate(self, width, length, goal_state, goal_sample_rate=0.15,
-                       goal_conditioning_bias=0.85, max_v=5.0):
-        """base_planner.py:162-207 + RRT.py:153-156 -> (sample (6,), cond_goal_xy (2,))."""
-        if self.py.random() > goal_sample_rate:
+    def _xy(self, width, length, prob_map):
+        """base_planner.py:181-187: uniform over the map, or (run_type >= 2) the centre of a cell drawn from
+        the sampling-probability map."""
+        if prob_map is None:
             x = self.np.uniform(-width / 2, width / 2, size=(1, 1))
             y = self.np.uniform(-length / 2, length / 2, size=(1, 1))
+            return x, y
+        from .prob_maps import draw_cell
+        row, col = draw_cell(self.np, prob_map)
+        xy = G.cell_rowcol_to_xy(np.array([row, col]), prob_map)
+        return np.array([[xy[0]]]), np.array([[xy[1]]])
+
+    def draw_candidate(self, width, length, goal_state, goal_sample_rate=0.15,
+                       goal_conditioning_bias=0.85, max_v=5.0, prob_map=None):
+        """base_planner.py:162-207 + RRT.py:153-156 -> (sample (6,), cond_goal_xy (2,))."""
+        if self.py.random() > goal_sample_rate:
+            x, y = self._xy(width, length, prob_map)
             th = self.np.uniform(-np.pi, np.pi, size=(1, 1))
             v = self.np.uniform(-max_v, max_v, size=(1, 1))
             thr = self.np.uniform(-1, 1, size=(1, 1))
@@ -60,7 +71,8 @@ class RandomTape:
             cond = np.asarray(goal_state, dtype=np.float64)[:2].copy()
         return sample, cond
 
-    def draw_candidate_ref(self, remain_path, width, length, goal_state, goal_sample_rate=0.15, max_v=5.0):
+    def draw_candidate_ref(self, remain_path, width, length, goal_state, goal_sample_rate=0.15, max_v=5.0,
+                           prob_map=None):
         """run_type > 0 (RRT.py:134-140,153-156): with a remaining reference path, pick one of its points
         (np.random.choice) and keep it with probability 0.6, else a random_node_sample(); the
         conditioning goal is always the sample's xy."""
@@ -71,8 +83,7 @@ class RandomTape:
             node_idx, explore = None, True
         if explore:
             if self.py.random() > goal_sample_rate:
-                x = self.np.uniform(-width / 2, width / 2, size=(1, 1))
-                y = self.np.uniform(-length / 2, length / 2, size=(1, 1))
+                x, y = self._xy(width, length, prob_map)
                 th = self.np.uniform(-np.pi, np.pi, size=(1, 1))
                 v = self.np.uniform(-max_v, max_v, size=(1, 1))
                 thr = self.np.uniform(-1, 1, size=(1, 1))
@@ -274,15 +285,17 @@ class OraclePlanner:
         remain = None
         if self.run_type > 0 and self.init_main_path is not None:
             remain = self.remaining_reference_path()
+        pm = self.sampling_map()
         while self.goal_node is None and self.candidates < n_candidates:
             B = min(batch, n_candidates - self.candidates)
             if self.run_type == 0:
                 s, c = tape.draw_round(B, W, H, self.goal_state, goal_sample_rate=self.gsr,
-                                       goal_conditioning_bias=self.gcb)
+                                       goal_conditioning_bias=self.gcb, prob_map=pm)
             else:
                 s, c = np.zeros((B, 6)), np.zeros((B, 2))
                 for i in range(B):
-                    s[i], c[i] = tape.draw_candidate_ref(remain, W, H, self.goal_state, goal_sample_rate=self.gsr)
+                    s[i], c[i] = tape.draw_candidate_ref(remain, W, H, self.goal_state, goal_sample_rate=self.gsr,
+                                                         prob_map=pm)
             self.expand_round(s, c)
         reached = self.goal_node is not None
         if reached:
@@ -293,6 +306,20 @@ class OraclePlanner:
             node = self.fallback_node()
         path, actions = self.path_to(node) if node is not None else (None, None)
         return reached, path, actions
+
+    def sampling_map(self):
+        """car_env.py:100-137 + RRT.py:124-125: None for run_type < 2, the EDT prior for run_type 2, the prior
+        log-blended with the start -> goal Gaussian (cells as (col, row)) for run_type >= 3."""
+        if self.run_type < 2:
+            return None
+        from . import prob_maps as PM
+        prior = PM.edt_prior(np.asarray(self.maze, dtype=np.float64))
+        if self.run_type == 2:
+            return prior
+        start_rc = G.cell_xy_to_rowcol(cell_center_f32(self.start_state[:2], self.maze), self.maze)
+        goal_rc = G.cell_xy_to_rowcol(self.env_goal, self.maze)
+        gauss, _, _ = PM.gaussian_map(start_rc[::-1], goal_rc[::-1])
+        return PM.combine_log_blend(prior, gauss)
 
     def fallback_node(self):
         """RRT.py:233-254: nearest to the goal (+1e4 when an obstacle is ahead), or -- with a reference
@@ -345,8 +372,17 @@ class OracleCarEnv:
         self.done = False
         self.terminated = False
         self._state = np.zeros(6)
-        self.prob_map = np.zeros_like(self._maze_map)
         self.current_step = 0
+        # car_env.py:100-110 (the constructor passes (row, col) where the later updates pass (col, row))
+        from . import prob_maps as PM
+        self.prior = PM.edt_prior(self._maze_map)
+        if run_type < 2:
+            self.prob_map = np.zeros_like(self._maze_map.copy())
+        elif run_type == 2:
+            self.prob_map = self.prior
+        else:
+            g, _, _ = PM.gaussian_map(self.cell_xy_to_rowcol(self.state[:2]), self.cell_xy_to_rowcol(self.goal[:2]))
+            self.prob_map = PM.combine_log_blend(self.prior, g)
 
     @property
     def maze_map(self):
@@ -354,7 +390,20 @@ class OracleCarEnv:
 
     @maze_map.setter
     def maze_map(self, m):
+        """car_env.py:117-128."""
+        from . import prob_maps as PM
         self._maze_map = m
+        self.prior = PM.edt_prior(m)
+        if self.run_type == 2:
+            self.prob_map = self.prior
+        elif self.run_type >= 3:
+            self.update_prob_map_by_loc()
+
+    def update_prob_map_by_loc(self):
+        """car_env.py:130-137."""
+        from . import prob_maps as PM
+        g, _, _ = PM.gaussian_map(self.cell_xy_to_rowcol(self.state[:2])[::-1], self.cell_xy_to_rowcol(self.goal[:2])[::-1])
+        self.prob_map = PM.combine_log_blend(self.prior, g)
 
     @property
     def x_map_center(self):
@@ -369,13 +418,12 @@ class OracleCarEnv:
         return self._state.copy()
 
     def cell_rowcol_to_xy(self, rc):
-        return G.cell_rowcol_to_xy(rc, self._maze_map)
+        rc = np.asarray(rc)                       # car_env.py:189-194 indexes the FIRST axis ((2, 1) inputs occur)
+        xc, yc = G.map_center(self._maze_map)
+        return np.array([(rc[1] + 0.5) * 1.0 - xc, yc - (rc[0] + 0.5) * 1.0])
 
     def cell_xy_to_rowcol(self, xy, floor_enable=True):
         return G.cell_xy_to_rowcol(xy, self._maze_map, floor_enable=floor_enable)
-
-    def update_prob_map_by_loc(self):
-        pass
 
     def reset(self, *, seed=None, options=None, **kw):
         self._state = np.zeros(6, dtype=np.float32)

@@ -505,6 +505,75 @@ def gen_traces(out):
               f"{r['iterations']} chunk-iterations, oracle planner == reference planner")
 
 
+def gen_prob_maps(out):
+    """run_type >= 2 sampling-probability maps: prob_sampling_utils.gaussian_map / combine_log_blend and the EDT
+    prior of car_env.py:100-101, evaluated by the reference's own functions."""
+    import prob_sampling_utils as ref_psu
+    from scipy.ndimage import distance_transform_edt
+    from oracle import prob_maps as PM
+    maze = load_maze("boxes")
+    rng = np.random.default_rng(23)
+    pairs = np.floor(rng.uniform(1, 19, size=(24, 4)))
+    pairs[0, 2:] = pairs[0, :2]                       # robot == goal
+    pairs[1] = [3.0, 3.0, 18.0, 15.0]                 # the reference's own demo (prob_sampling_utils.py:181-183)
+    gauss, blend = [], []
+    mazes = [maze]
+    for k in range(3):
+        m = maze.copy()
+        rc = rng.integers(2, 18, size=(4, 2))
+        m[rc[:, 0], rc[:, 1]] = 1
+        mazes.append(m)
+    priors = []
+    for m in mazes:
+        pr = distance_transform_edt(1 - m)
+        pr = pr / np.sum(pr)
+        assert np.array_equal(pr, PM.edt_prior(m))
+        priors.append(pr)
+    for i, (rx, ry, gx, gy) in enumerate(pairs):
+        pdf, mean, sig = ref_psu.gaussian_map((rx, ry), (gx, gy))
+        opdf, omean, osig = PM.gaussian_map((rx, ry), (gx, gy))
+        assert np.array_equal(pdf, opdf) and np.array_equal(mean, omean) and np.array_equal(sig, osig), i
+        post = ref_psu.combine_log_blend(priors[i % len(priors)], pdf)
+        assert np.array_equal(post, PM.combine_log_blend(priors[i % len(priors)], opdf)), i
+        gauss.append(pdf)
+        blend.append(post)
+    out["probmap_pairs"] = pairs
+    out["probmap_mazes"] = np.array(mazes)
+    out["probmap_priors"] = np.array(priors)
+    out["probmap_gauss"] = np.array(gauss)
+    out["probmap_blend"] = np.array(blend)
+    print(f"probability maps: {len(pairs)} gaussian / log-blend maps on {len(mazes)} priors, oracle == reference")
+
+
+def gen_traces_run_type23(out):
+    """run_type 2 (EDT-prior cell sampling) and 3 (prior x start->goal Gaussian) planner traces: the reference
+    planner on the CarEnv restatement (base_planner.py:157-160,181-184, RRT.py:124-125)."""
+    maze = load_maze("boxes")
+    env0 = ORRT.OracleCarEnv(maze_map=maze)
+    start = np.array([*env0.cell_rowcol_to_xy(np.array([17, 2])), np.deg2rad(45.0), 0.0, 0.0, 0.0])
+    goal = np.array([*env0.cell_rowcol_to_xy(np.array([2, 17])), 0.0, 0.0, 0.0, 0.0])
+    for rt, seed, n in ((2, 31, 250), (3, 32, 250)):
+        counter = {"cand": 0}
+        planner, env = _ref_planner(maze.copy(), start, goal, seed, n, rt, counter)
+        planner.reset()
+        path, act = _plan_with_candidate_clock(planner, counter)
+        par, st = _tree_of(planner)
+        pl = ORRT.OraclePlanner(maze, start, goal, ActionTape(seed).sampler(), run_type=rt)
+        _, opath, oact = pl.plan(ORRT.RandomTape(42), n, batch=1)
+        assert not pl.sticky_triggered
+        assert np.array_equal(np.array(pl.tree.parents, dtype=np.int32), par), f"run_type {rt} parents"
+        assert np.array_equal(np.array(pl.tree.states), st)
+        assert (path is None) == (opath is None)
+        if path is not None:
+            assert np.array_equal(path, opath) and np.array_equal(act, oact)
+        out[f"rt{rt}_seed"], out[f"rt{rt}_budget"] = np.array(seed), np.array(n)
+        out[f"rt{rt}_parents"], out[f"rt{rt}_states"] = par, st
+        out[f"rt{rt}_prob_map"] = pl.sampling_map()
+        out[f"rt{rt}_path"] = np.zeros((0, 6), np.float32) if path is None else path
+        out[f"rt{rt}_actions"] = np.zeros((0, 2), np.float32) if act is None else act
+        print(f"run_type {rt}: {len(par)} nodes, path={'yes' if path is not None else 'none'}; oracle planner == reference planner")
+
+
 def _driver_functions(names):
     """Functions of run_scenarios_with_lidar_DiTree.py taken from its text: the script's top-level imports
     (playsound, minari, gymnasium, drone_env ...) are absent here, so it cannot be imported as a module."""
@@ -665,6 +734,10 @@ def gen_online(out):
 
 
 def main():
+    if sys.argv[1:] == ["probmaps"]:          # quick check of the run_type >= 2 pieces only (writes nothing)
+        gen_prob_maps({})
+        gen_traces_run_type23({})
+        return
     if sys.argv[1:] == ["online"]:
         online = {}
         gen_online(online)
@@ -681,6 +754,8 @@ def main():
     gen_unet(net)
     gen_traces(traces)
     gen_traces_run_type1(traces)
+    gen_traces_run_type23(traces)
+    gen_prob_maps(geo)
     np.savez_compressed(os.path.join(HERE, "geometry.npz"), **geo)
     np.savez_compressed(os.path.join(HERE, "network.npz"), **net)
     np.savez_compressed(os.path.join(HERE, "traces.npz"), **traces)

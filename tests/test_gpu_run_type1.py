@@ -43,9 +43,9 @@ def test_obstacle_ahead_bit_exact(ctx):
     assert ctx.obstacle_ahead(dev(np.zeros((0, 6)))).numel() == 0
 
 
-def _run(ctx, maze, start, goal, seed, budget, batch, init_main_path=None, remain=None):
+def _run(ctx, maze, start, goal, seed, budget, batch, init_main_path=None, remain=None, run_type=1, prob_map=None):
     from ditreeonlineplanner_amd.engine import ExpansionEngine
-    eng = ExpansionEngine(ctx, maze, start, goal, batch=batch, capacity=2048, run_type=1, early_exit=True)
+    eng = ExpansionEngine(ctx, maze, start, goal, batch=batch, capacity=2048, run_type=run_type, early_exit=True)
     eng.init_main_path = init_main_path
     rt, at = ORRT.RandomTape(42), ActionTape(seed)
     done = 0
@@ -53,7 +53,7 @@ def _run(ctx, maze, start, goal, seed, budget, batch, init_main_path=None, remai
         B = min(batch, budget - done)
         s, c = np.zeros((B, 6)), np.zeros((B, 2))
         for i in range(B):
-            s[i], c[i] = rt.draw_candidate_ref(remain, maze.shape[1], maze.shape[0], goal)
+            s[i], c[i] = rt.draw_candidate_ref(remain, maze.shape[1], maze.shape[0], goal, prob_map=prob_map)
         acts = np.stack([at.actions(np.arange(done, done + B), j) for j in range(eng.n_chunks)], axis=1)
         eng.expand_round(dev(s), dev(c), inject_actions=dev(acts))
         done += B
@@ -127,6 +127,22 @@ def test_run_type1_rounds_vs_oracle(ctx, batch):
             assert path.shape == opath.shape and np.abs(path - opath).max() < 1e-5 and np.array_equal(act, oact)
 
 
+@pytest.mark.parametrize("rt", [2, 3])
+def test_engine_reproduces_reference_run_type23_trace(ctx, rt):
+    """run_type 2 / 3: positions drawn from the sampling-probability map (host RNG order), everything else as
+    run_type 1 -- tree, path and actions equal the reference planner's."""
+    g = golden("traces")
+    maze = load_maze("boxes")
+    start, goal = g["rt1_start"], g["rt1_goal"]
+    eng = _run(ctx, maze, start, goal, int(g[f"rt{rt}_seed"]), int(g[f"rt{rt}_budget"]), 1, run_type=rt,
+               prob_map=g[f"rt{rt}_prob_map"])
+    _check_tree(eng, g[f"rt{rt}_parents"], g[f"rt{rt}_states"])
+    node = eng.goal_node if eng.goal_node is not None else eng.fallback_node()
+    path, act = eng.path_to(node)
+    assert path.shape == g[f"rt{rt}_path"].shape and np.abs(path - g[f"rt{rt}_path"]).max() < 1e-5
+    assert np.array_equal(act, g[f"rt{rt}_actions"])
+
+
 def test_fallback_none_when_every_node_has_an_obstacle_ahead(ctx):
     """RRT.py:227-232: np.all(has_obstacle_ahead) -> (None, None); also true for a tree holding only the start."""
     from ditreeonlineplanner_amd.engine import ExpansionEngine
@@ -193,5 +209,21 @@ def test_planner_facade_run_type1(ctx):
         assert n == 1 or flags.all()
     else:
         assert path.dtype == np.float32 and path.shape[1] == 6 and np.allclose(path[0], start.astype(np.float32))
-    with pytest.raises(NotImplementedError):
-        RRT_Planner(start, goal, env_id="carmaze", environment=env, sampler=smp, run_type=2)
+    # run_type 3: the facade's sampling order (map draw, then the uniform draws) equals the reference's
+    env3 = CarEnv(maze_map=load_maze("boxes"), collision_checking=False, run_type=3)
+    pl3 = RRT_Planner(start, goal, env_id="carmaze", environment=env3, sampler=smp, prediction_type="actions",
+                      action_horizon=8, local_map_size=20, local_map_scale=0.2, global_map_scale=1.0,
+                      prop_duration=[64], time_budget=120, batch=32, max_candidates=64, run_type=3)
+    pl3.reset()
+    env3.update_prob_map_by_loc()
+    assert np.array_equal(env3.prob_map, g["rt3_prob_map"])
+    random.seed(42)
+    np.random.seed(42)
+    s3, c3 = pl3.draw_round(48, None)
+    rt3 = ORRT.RandomTape(42)
+    for i in range(48):
+        es, ec = rt3.draw_candidate_ref(None, 20, 20, goal, prob_map=g["rt3_prob_map"])
+        assert np.array_equal(s3[i], es) and np.array_equal(c3[i], ec)
+    before = env3.prob_map.copy()
+    path3, _ = pl3.plan()
+    assert np.array_equal(env3.prob_map, before) and pl3.results["iterations"] > 0

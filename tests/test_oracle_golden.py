@@ -145,6 +145,63 @@ def test_run_type1_trace_matches_reference():
     assert not pl.sticky_triggered and not pl2.sticky_triggered
 
 
+def test_probability_maps_match_reference():
+    """run_type >= 2: EDT prior, gaussian_map, combine_log_blend (prob_sampling_utils.py:50-94,146-165) --
+    the oracle and the product's host module against the reference's outputs, bit for bit."""
+    from oracle import prob_maps as PM
+    from ditreeonlineplanner_amd import prob_sampling_utils as PSU
+    g = golden("geometry")
+    mazes, priors = g["probmap_mazes"], g["probmap_priors"]
+    for m, pr in zip(mazes, priors):
+        assert np.array_equal(PM.edt_prior(m), pr) and np.array_equal(PSU.edt_prior(m), pr)
+    for i, (rx, ry, gx, gy) in enumerate(g["probmap_pairs"]):
+        for mod in (PM, PSU):
+            pdf, _, _ = mod.gaussian_map((rx, ry), (gx, gy))
+            assert np.array_equal(pdf, g["probmap_gauss"][i]), (mod.__name__, i)
+            assert np.array_equal(mod.combine_log_blend(priors[i % len(priors)], pdf), g["probmap_blend"][i])
+    # degenerate blends fall back to the prior, then to uniform
+    z = np.zeros((20, 20))
+    for mod in (PM, PSU):
+        assert np.allclose(mod.combine_log_blend(z, g["probmap_gauss"][0]).sum(), 1.0)
+
+
+@pytest.mark.parametrize("rt", [2, 3])
+def test_run_type23_trace_matches_reference(rt):
+    g = golden("traces")
+    maze = load_maze("boxes")
+    start, goal = g["rt1_start"], g["rt1_goal"]
+    pl = ORRT.OraclePlanner(maze, start, goal, ActionTape(int(g[f"rt{rt}_seed"])).sampler(), run_type=rt)
+    assert np.array_equal(pl.sampling_map(), g[f"rt{rt}_prob_map"])
+    _, path, act = pl.plan(ORRT.RandomTape(42), int(g[f"rt{rt}_budget"]), batch=1)
+    assert np.array_equal(np.array(pl.tree.parents), g[f"rt{rt}_parents"])
+    assert np.array_equal(np.array(pl.tree.states), g[f"rt{rt}_states"])
+    assert np.array_equal(path, g[f"rt{rt}_path"]) and np.array_equal(act, g[f"rt{rt}_actions"])
+
+
+@pytest.mark.parametrize("rt", [2, 3])
+def test_car_env_sampling_map_wiring(rt):
+    """The product's CarEnv (host part only, no kernel call) keeps the reference's per-run_type map wiring
+    (car_env.py:100-137): equal to the CarEnv restatement the reference planner was run against."""
+    from ditreeonlineplanner_amd.car_env import CarEnv
+    g = golden("traces")
+    maze = load_maze("boxes")
+    start, goal = g["rt1_start"], g["rt1_goal"]
+    env, oenv = CarEnv(maze_map=maze.copy(), collision_checking=False, run_type=rt), ORRT.OracleCarEnv(maze.copy(), run_type=rt)
+    assert np.array_equal(env.prob_map, oenv.prob_map)
+    opts = {"reset_cell": env.cell_xy_to_rowcol(start[:2]), "reset_deg": np.rad2deg(start[2]),
+            "goal_cell": env.cell_xy_to_rowcol(goal[:2])}
+    env.reset(options=opts)
+    oenv.reset(options=opts)
+    if rt >= 3:
+        env.update_prob_map_by_loc()
+        oenv.update_prob_map_by_loc()
+    assert np.array_equal(env.prob_map, g[f"rt{rt}_prob_map"]) and np.array_equal(oenv.prob_map, env.prob_map)
+    m2 = g["rt1_maze2"]
+    env.maze_map = m2
+    oenv.maze_map = m2
+    assert np.array_equal(env.prob_map, oenv.prob_map) and not np.array_equal(env.prob_map, g[f"rt{rt}_prob_map"])
+
+
 @pytest.mark.parametrize("tag", ["visible", "free", "goal", "collision", "hidden", "track"])
 def test_online_loop_matches_reference(tag):
     """run_scenarios_with_lidar_DiTree.py:112-127,158-181,470-506 (oracle/online.py) vs the reference-driven loop."""
