@@ -97,6 +97,20 @@ def cpu_baseline(maze, nodes, goal, samples, cond, noise, state_dict, n_cand=512
                        f"oracle numpy geometry + torch-CPU fp32 denoiser, {dt:.1f} s")
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 +
+    WRITE_SIZE; profiles/run_profiles.sh + profiles/summarize.py).  Counters cannot be read inside a timed run, so
+    this is the recorded figure for the same command, or null when the summary is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"][kernel]
+        return {"traffic": k["hbm_bytes_per_launch"], "traffic_unit": "bytes per launch (L2-miss side: FETCH_SIZE*2 + WRITE_SIZE)",
+                "traffic_source": "profiles/r01_pmc_traffic.json"}
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,7 +251,7 @@ def main():
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12            # executed == algorithmic for this kernel (no padding)
             alg_total = 2.0 * MAC_PER_CALL * Bper * n_chunks * args.steps     # per rank, whole denoiser
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "kernel": name,
+                               "frac": ach / PEAK_BF16_TFLOPS, **pmc_traffic(name), "kernel": name,
                                "launches": d["launches"], "avg_launch_ms": d["ms"] / max(1, d["launches"]),
                                "algorithmic_gflop_per_launch": d["flops"] / max(1, d["launches"]) / 1e9,
                                "kernel_time_share": d["ms"] * 1e-3 / elapsed,
