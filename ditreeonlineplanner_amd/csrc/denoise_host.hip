@@ -539,7 +539,14 @@ void DenoiserState::build(int prec_, int Bmax_) {
           // candidate's result does not depend on which other candidates share its launch (bitwise).
           const int nk_total = tl.n * (Cin / 64);
           const int tiles = ((1024 * OH * OH + 255) / 256) * ((Cout + 255) / 256);
-          int sk = std::max(1, std::min(std::min(8, nk_total / 2), std::max(1, 160 / tiles)));
+          static int sk_target = -1, sk_cap = 8;          // A/B knobs: DITREE_SPLITK_TARGET (work-groups aimed at), DITREE_SPLITK_CAP
+          if (sk_target < 0) {
+            const char* e = getenv("DITREE_SPLITK_TARGET");
+            sk_target = (e && atoi(e) > 0) ? atoi(e) : 160;
+            const char* c = getenv("DITREE_SPLITK_CAP");
+            if (c && atoi(c) > 0) sk_cap = atoi(c);
+          }
+          int sk = std::max(1, std::min(std::min(sk_cap, nk_total / 2), std::max(1, sk_target / tiles)));
           while (sk > 1 && (size_t)sk * OH * OH * Cout > gout_per_sample) --sk;
           if (sk > 1) {                                   // every split must own at least one K-step
             const int per = (nk_total + sk - 1) / sk;

@@ -597,9 +597,27 @@ __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
     for (int j = 0; j < 4; ++j)
       bfr[set][j] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(wb + b_row_off + j * 4096 + psb));
   };
+  // DBG == 3 (timing experiment only, results are garbage): the same loop with two 16x16x32 MFMAs in place of
+  // each 32x32x16 (equal FLOPs, cycles and LDS bytes) to see which shape holds the higher clock in situ
+  f32x4_t acc16[2][4][4];
+  if constexpr (DBG == 3) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc16[mb][j][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  int flip = 0;
   auto mm = [&](int set, int mb, int j) {
-    acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][mb], bfr[set][j], acc[mb][j], 0, 0, 0);
+    if constexpr (DBG == 3) {
+      acc16[mb][j][flip] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[set][mb], bfr[set][j], acc16[mb][j][flip], 0, 0, 0);
+      acc16[mb][j][flip + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[set][mb], bfr[set][j], acc16[mb][j][flip + 1], 0, 0, 0);
+    } else {
+      acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][mb], bfr[set][j], acc[mb][j], 0, 0, 0);
+    }
   };
+  constexpr int MF = DBG == 3 ? 2 : 1;
   auto mm8 = [&](int set) {
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
@@ -628,11 +646,11 @@ __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
     // Pin the issue order the pipeline is built on (hipcc otherwise sinks every fragment read behind the
     // MFMAs that free its registers and then waits for LDS in front of each MFMA group):
     // ks0..ks2: the 6 reads of the next sub-step first, then the 8 MFMAs of the current one.
-    if constexpr (DBG == 0) {
+    if constexpr (DBG == 0 || DBG == 3) {
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
         __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * MF, 0);
       }
     }
     if constexpr (HAS_NEXT) {
@@ -655,12 +673,12 @@ __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
         if constexpr (ISSUE_A && DBG != 1) { if (i >= 3) issue_a(c + 2, i - 3); }
       }
     // after the barrier: the 6 reads of the next K-step first, then MFMA : LDS-DMA interleaved
-    if constexpr (DBG == 0) {
+    if constexpr (DBG == 0 || DBG == 3) {
       if constexpr (HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 6, 1);
       constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? 5 : 0);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, MF, 1);
         if (i < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
       }
       if constexpr (NV > 8) __builtin_amdgcn_sched_group_barrier(0x020, NV - 8, 1);
@@ -703,8 +721,369 @@ __global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
     step(I1{}, Tt{}, Ff{}, Ff{}, I0{}, c);
     step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, c);
   }
+  if constexpr (DBG == 3) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mb][j][i] = acc16[mb][j][i >> 2][i & 3];
+  }
   __syncthreads();
   gemm_epilogue<0>(p, acc, smem, tm, tn, tid, lane, r5, h, wm, wn);
+}
+
+// =================================================================================================
+// conv3_halo16_kernel: the halo kernel on v_mfma_f32_16x16x32_bf16.
+//
+// Same tile (256 x 256, 8 waves 4(M) x 2(N), wave tile 64 x 128), same LDS images, staging and
+// barrier protocol as conv3_halo_kernel; only the MFMA shape and with it the fragment / accumulator
+// geometry differ.  Measured in situ (same loop, two 16x16x32 per 32x32x16): the chip holds a higher
+// clock on this shape under load, -8.4 % kernel time at equal cycles, FLOPs and LDS bytes
+// (MI355X_MICROARCH.md "DVFS give-back" (7)).
+//   lane (r4 = lane & 15, h4 = lane >> 4); acc[mb][j][i]: tile row wm*64 + mb*16 + 4*h4 + i,
+//   tile channel wn*128 + 8*r4 + j  (W rows are permuted in LDS so a lane owns 8 consecutive channels:
+//   16-B stores, 256 B contiguous per row).
+//   A K-step (64 channels of one tap) is four phases of 16 MFMAs: (ks, j-half) = (0,0) (0,1) (1,0) (1,1);
+//   A fragments are double-buffered per 32-deep sub-step, B fragments per half (64 fragment VGPRs in all);
+//   phase n reads what phase n+1 needs; the barrier sits before the last phase, which carries the LDS-DMA issue.
+// =================================================================================================
+__device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t (&acc)[4][8], char* smem, int tm, int tn,
+                                                int tid, int lane, int r4, int h4, int wm, int wn) {
+  const int c_l = wn * 128 + 8 * r4;                          // lane's 8 consecutive channels in the tile
+  const int n0 = tn * 256 + c_l;
+  if (p.bias != nullptr) {
+    const f32x4_t b0 = *(const f32x4_t*)(p.bias + n0), b1 = *(const f32x4_t*)(p.bias + n0 + 4);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[mb][j] += b0[j]; acc[mb][4 + j] += b1[j]; }
+  }
+  // 16-row block mb of this wave: tile rows wm*64 + mb*16 .. +15 (inside one sample: 16 | L)
+  int blk_b[4], blk_l[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const int m0 = tm * 256 + wm * 64 + mb * 16;
+    const int b = m0 / p.L;
+    blk_b[mb] = b;
+    blk_l[mb] = m0 - b * p.L;
+  }
+  auto store_row = [&](int mb, int i, const float (&v)[8]) {
+    const int b = blk_b[mb], l = blk_l[mb] + 4 * h4 + i;
+    const long long orow = (long long)b * p.out_Lp + (long long)l * p.out_stride + p.out_off;
+    const long long oidx = orow * p.ldc + p.out_coff + n0;
+    short8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(v[j]);
+    *(short8_t*)((char*)p.Out + oidx * 2) = o;
+  };
+  if (p.mode < MODE_GN_MISH) {                                // plain store (not used by the U-Net's k=3 convs)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = acc[mb][j][i];
+        store_row(mb, i, v);
+      }
+    return;
+  }
+  float* s_sum = (float*)smem;                                // [16 slots][4 groups]
+  float* s_sq = s_sum + 64;
+  if (tid < 128) s_sum[tid] = 0.0f;
+  const f32x4_t gam0 = *(const f32x4_t*)(p.gamma + n0), gam1 = *(const f32x4_t*)(p.gamma + n0 + 4);
+  const f32x4_t bet0 = *(const f32x4_t*)(p.beta + n0), bet1 = *(const f32x4_t*)(p.beta + n0 + 4);
+  // FiLM rows (per sample) and residual rows are fetched two / one 16-row block ahead.  The two modes exclude
+  // each other, so both use the same 2 x 4 x 16-B prefetch registers:
+  //   FiLM: pre[blk & 1] = {scale lo, scale hi, bias lo, bias hi} (f32);  residual: pre[blk & 1][i] = 8 bf16 of row i
+  f32x4_t pre[2][4];
+  auto fetch_film = [&](int blk) {
+    const float* fr = p.film + (long long)blk_b[blk] * p.film_ld + p.film_off + n0;
+    pre[blk & 1][0] = *(const f32x4_t*)fr;
+    pre[blk & 1][1] = *(const f32x4_t*)(fr + 4);
+    pre[blk & 1][2] = *(const f32x4_t*)(fr + p.N);
+    pre[blk & 1][3] = *(const f32x4_t*)(fr + p.N + 4);
+  };
+  auto fetch_res = [&](int blk) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long rrow = (long long)blk_b[blk] * p.res_Lp + blk_l[blk] + 4 * h4 + i + p.res_off;
+      pre[blk & 1][i] = *(const f32x4_t*)((const char*)p.Res + (rrow * p.ldres + n0) * 2);
+    }
+  };
+  const bool has_film = p.mode == MODE_GN_MISH_FILM, has_res = p.mode == MODE_GN_MISH_RES;
+  if (has_film) { fetch_film(0); fetch_film(1); }
+  if (has_res) fetch_res(0);
+  __syncthreads();
+  const int spt = 256 / p.L;
+  const int gi = c_l / p.group_ch;
+  const bool wide = p.group_ch >= 128;
+  const float inv_cnt = 1.0f / (float)(p.group_ch * p.L);
+  int slot[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) slot[mb] = blk_b[mb] - tm * spt;
+  // one pass: sum and sum of squares (f32), var = E[x^2] - mean^2
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = acc[mb][j][i];
+        s += v;
+        q = fmaf(v, v, q);
+      }
+    s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
+    s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
+    s += __shfl_xor(s, 4); q += __shfl_xor(q, 4);
+    s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+    s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+    if (wide) { s += __shfl_xor(s, 8); q += __shfl_xor(q, 8); }
+    if (lane == 0 || (!wide && lane == 8)) {
+      atomicAdd(&s_sum[slot[mb] * 4 + gi], s);
+      atomicAdd(&s_sq[slot[mb] * 4 + gi], q);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const float mean = s_sum[slot[mb] * 4 + gi] * inv_cnt;
+    const float var = fmaxf(s_sq[slot[mb] * 4 + gi] * inv_cnt - mean * mean, 0.0f);
+    const float rstd = rsqrtf(var + p.eps);
+    if (has_res && mb < 3) fetch_res(mb + 1);
+    float ga[8], be[8], fs[8], fb[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ga[j] = gam0[j] * rstd; ga[4 + j] = gam1[j] * rstd;
+      be[j] = bet0[j] - mean * ga[j]; be[4 + j] = bet1[j] - mean * ga[4 + j];
+      fs[j] = fs[4 + j] = 1.f;
+      fb[j] = fb[4 + j] = 0.f;
+    }
+    if (has_film) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        fs[j] = pre[mb & 1][0][j]; fs[4 + j] = pre[mb & 1][1][j];
+        fb[j] = pre[mb & 1][2][j]; fb[4 + j] = pre[mb & 1][3][j];
+      }
+      if (mb < 2) fetch_film(mb + 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = mish_f<0>(acc[mb][j][i] * ga[j] + be[j]) * fs[j] + fb[j];
+      if (has_res) {
+        const short8_t rv = __builtin_bit_cast(short8_t, pre[mb & 1][i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += bf2f((unsigned short)rv[j]);
+      }
+      store_row(mb, i, v);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int A_BUF = 40960, W_BUF = 32768, W_BASE = 2 * A_BUF;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index: uniform, keeps every wave-level offset in SGPRs
+  const int r4 = lane & 15, h4 = lane >> 4;
+  const int wm = w >> 1, wn = w & 1;
+  const int ntn = (p.N + 255) >> 8;
+  const int ntm = (p.M + 255) >> 8;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int tm = tile / ntn, tn = tile - tm * ntn;
+  const int L = p.L, Lp = p.in_Lp, S = 256 / L;
+  const int a_rows = S * Lp;
+  const int nc = p.Cin >> 6;
+  const long long K = 3LL * p.Cin;
+
+  // ---- staging sources (buffer addressing, as conv3_halo_kernel) ------------------------------------
+  // pieces 0..3 of the A block differ by 64 rows (a wave-uniform byte offset, folded into the scalar offset);
+  // only piece 4 can run past the block and is clamped per lane
+  unsigned pa0, pa4, pbe, pbo;
+  const char* const a_base = (const char*)p.A + ((long long)tm * S * Lp + p.in_off) * p.lda * 2;
+  const char* const w_base = (const char*)p.W + ((long long)tn * 256) * K * 2;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
+  {
+    const int r = w * 8 + (lane >> 3);                               // LDS row of the A block, piece 0
+    const int slot = (lane & 7) ^ ((r >> 1) & 7);                    // (r + 64 i) >> 1 & 7 is the same for every piece
+    pa0 = (unsigned)((r * p.lda + slot * 8) * 2);
+    const int r4r = r + 256;
+    const int rs = r4r < a_rows ? r4r : a_rows - 1;
+    pa4 = (unsigned)((rs * p.lda + slot * 8) * 2);
+  }
+  const int a_piece = 64 * p.lda * 2;                                // bytes between pieces
+  // W tile: LDS row r = (w*4 + q)*8 + (lane >> 3) holds channel c(r) = (r & 128) + 8*(r & 15) + ((r >> 4) & 7)
+  // (row wn*128 + j*16 + r4 <- channel wn*128 + 8*r4 + j).  Per lane only 8*(lane >> 3) and the swizzled slot vary,
+  // and the slot depends on q through its parity alone: two lane offsets (q even / odd) + a wave-uniform row offset.
+  long long wq[4];
+  {
+    const int lr = lane >> 3;
+    const int slot0 = (lane & 7) ^ (lr >> 1);                        // q even: (r >> 1) & 7 = lr >> 1
+    const int slot1 = slot0 ^ 4;                                     // q odd:  (r >> 1) & 7 = 4 + (lr >> 1)
+    pbe = (unsigned)(((long long)(8 * lr) * K + slot0 * 8) * 2);
+    pbo = (unsigned)(((long long)(8 * lr) * K + slot1 * 8) * 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r0 = (w * 4 + q) * 8;                                // row with lane >> 3 = 0
+      const int cu = (r0 & 128) + 8 * (r0 & 8) + ((r0 >> 4) & 7);    // wave-uniform part of c(r)
+      wq[q] = (long long)cu * K * 2;
+    }
+  }
+  const int w_tap = p.Cin * 2;
+  auto issue_a = [&](int c, int i) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (LDS_AS void*)(smem + (c & 1) * A_BUF + (w + 8 * i) * 1024), 16,
+                                             i < 4 ? pa0 : pa4, c * 128 + (i < 4 ? i * a_piece : 0), 0, 0);
+  };
+  auto issue_w = [&](int c, int t, int q) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (LDS_AS void*)(smem + W_BASE + ((c + t) & 1) * W_BUF + (w * 4 + q) * 1024),
+                                             16, (q & 1) ? pbo : pbe, (int)wq[q] + c * 128 + t * w_tap, 0, 0);
+  };
+
+  // ---- fragment addressing ---------------------------------------------------------------------
+  // row of the A block of fragment row (wm*64 + mb*16 + r4): lrow0 + a wave-uniform step (16 rows per mb plus the
+  // two halo rows of every sample boundary crossed; 16 | L)
+  int lrow0;
+  {
+    const int ml = wm * 64 + r4;
+    const int sb = ml / L;
+    lrow0 = sb * Lp + (ml - sb * L);                                 // + tap
+  }
+  int lstep[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) lstep[mb] = 16 * mb + 2 * (((wm * 64 + 16 * mb) / L) - ((wm * 64) / L));
+  const int swl = (r4 >> 1) & 7;
+  const int b_row_off = (wn * 128 + r4) * 128;
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[mb][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8_t af[2][4], bq[2][4];
+  auto rdA = [&](int set, int c, int t, int ks) {
+    const char* ab = smem + (c & 1) * A_BUF;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int row = lrow0 + lstep[mb] + t;
+      const int ps = (((ks << 2) | h4) ^ ((row >> 1) & 7)) << 4;
+      af[set][mb] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(ab + row * 128 + ps));
+    }
+  };
+  auto rdB = [&](int set, int c, int t, int ks, int half) {
+    const char* wb = smem + W_BASE + ((c + t) & 1) * W_BUF + b_row_off + half * 8192;
+    const int psb = (((ks << 2) | h4) ^ swl) << 4;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) bq[set][jj] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(wb + jj * 2048 + psb));
+  };
+  auto mm = [&](int aset, int bset, int half, int mb, int jj) {
+    acc[mb][half * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[aset][mb], bq[bset][jj], acc[mb][half * 4 + jj], 0, 0, 0);
+  };
+  auto mm16 = [&](int aset, int bset, int half) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) mm(aset, bset, half, mb, jj);
+  };
+
+  // One K-step (chunk c, tap T); flags as in conv3_halo_kernel.  On entry af[0] = A(ks 0), bq[0] = B(ks 0, half 0).
+  auto step = [&](auto tT, auto tNext, auto tIW, auto tIA, auto tVM, int c) {
+    constexpr int T = decltype(tT)::value;
+    constexpr bool HAS_NEXT = decltype(tNext)::value, ISSUE_W = decltype(tIW)::value, ISSUE_A = decltype(tIA)::value;
+    constexpr int VM = decltype(tVM)::value;
+    asm volatile("" : "+v"(lrow0));    // keep the fragment-address arithmetic inside the step (hoisted it spills)
+    // Each phase is its own scheduling region (sched_barrier), inside it the fragment reads for the NEXT phase
+    // are issued first, then the 16 MFMAs: hipcc otherwise sinks the reads to the end of the phase and the next
+    // phase waits for LDS in front of every MFMA.
+    rdB(1, c, T, 0, 1);                 // phase (0,0)
+    mm16(0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    rdA(1, c, T, 1);                    // phase (0,1)
+    rdB(0, c, T, 1, 0);
+    mm16(0, 1, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    rdB(1, c, T, 1, 1);                 // phase (1,0)
+    mm16(1, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (HAS_NEXT) {
+      if constexpr (VM == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      constexpr int T1 = (T + 1) % 3;
+      rdA(0, c + (T + 1) / 3, T1, 0);
+      rdB(0, c + (T + 1) / 3, T1, 0, 0);
+    }
+    constexpr int T2 = (T + 2) % 3;
+    const int c2 = c + (T + 2) / 3;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)      // phase (1,1) + the LDS-DMA issue of step s+2 / chunk c+2
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        mm(1, 1, 1, mb, jj);
+        const int i = mb * 4 + jj;
+        if constexpr (ISSUE_W) { if (i < 4) issue_w(c2, T2, i); }
+        if constexpr (ISSUE_A) { if (i >= 4 && i < 9) issue_a(c + 2, i - 4); }
+      }
+    if constexpr (HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);
+    constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? 5 : 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+      if (i < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I5 = std::integral_constant<int, 5>;
+  using Tt = std::true_type;
+  using Ff = std::false_type;
+
+  // ---- prologue: A(0), W(0,0) -> visible; then W(0,1) and A(1) in flight ----------------------------
+#pragma unroll
+  for (int i = 0; i < 5; ++i) issue_a(0, i);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue_w(0, 0, q);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue_w(0, 1, q);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) issue_a(1, i);
+  rdA(0, 0, 0, 0);
+  rdB(0, 0, 0, 0, 0);
+
+  for (int c = 0; c < nc - 2; ++c) {
+    step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, c);          // waits W(c,1); A(c+1) may stay in flight
+    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, c);
+    step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, c);          // stages W(c+1,1) then A(c+2)
+  }
+  {
+    const int c = nc - 2;
+    step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, c);
+    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, c);
+    step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, c);
+  }
+  {
+    const int c = nc - 1;
+    step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, c);
+    step(I1{}, Tt{}, Ff{}, Ff{}, I0{}, c);
+    step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, c);
+  }
+  __syncthreads();
+  gemm_epilogue16(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
 }
 
 static bool halo_eligible(const ConvGemmParams& p, int prec) {
@@ -735,10 +1114,16 @@ void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s) {
       hipFuncSetAttribute((const void*)conv3_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
       hipFuncSetAttribute((const void*)conv3_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
       hipFuncSetAttribute((const void*)conv3_halo_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+      hipFuncSetAttribute((const void*)conv3_halo_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+      hipFuncSetAttribute((const void*)conv3_halo16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
       attr2 = true;
     }
+    static int shape16 = -1;               // DITREE_HALO_MFMA=32 selects the 32x32x16 kernel (A/B runs)
+    if (shape16 < 0) { const char* e = getenv("DITREE_HALO_MFMA"); shape16 = (e && atoi(e) == 32) ? 0 : 1; }
+    if (dbg == 0 && shape16) { hipLaunchKernelGGL(conv3_halo16_kernel, grid, block, 147456, s, p); return; }
     if (dbg == 1) hipLaunchKernelGGL(conv3_halo_kernel<1>, grid, block, 147456, s, p);
     else if (dbg == 2) hipLaunchKernelGGL(conv3_halo_kernel<2>, grid, block, 147456, s, p);
+    else if (dbg == 3) hipLaunchKernelGGL(conv3_halo_kernel<3>, grid, block, 147456, s, p);
     else hipLaunchKernelGGL(conv3_halo_kernel<0>, grid, block, 147456, s, p);
     return;
   }
@@ -869,9 +1254,27 @@ __global__ void __launch_bounds__(256) final_proj_flow_kernel(const void* __rest
   const int b = (int)(pos / P), l = (int)(pos - (long long)b * P);
   const long long row = (long long)b * Lp + l + 1;
   float s[2] = {0.f, 0.f};
-  for (int c = lane; c < C; c += 64) {
-    const float y = load_elem<PREC>(Y, row * C + c);
-    for (int d = 0; d < 2; ++d) s[d] += (d < D) ? y * W[(long long)d * C + c] : 0.f;
+  // a lane takes 8 consecutive channels per pass (16-B loads of bf16 rows; C is a multiple of 8)
+  for (int c = lane * 8; c < C; c += 512) {
+    float y[8];
+    if constexpr (PREC == 1) {
+      const f32x4_t y0 = *(const f32x4_t*)((const float*)Y + row * C + c), y1 = *(const f32x4_t*)((const float*)Y + row * C + c + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { y[j] = y0[j]; y[4 + j] = y1[j]; }
+    } else {
+      const short8_t yv = *(const short8_t*)((const unsigned short*)Y + row * C + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = bf2f((unsigned short)yv[j]);
+    }
+    for (int d = 0; d < 2; ++d) {
+      if (d < D) {
+        const f32x4_t w0 = *(const f32x4_t*)(W + (long long)d * C + c), w1 = *(const f32x4_t*)(W + (long long)d * C + c + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[d] = fmaf(y[j], w0[j], s[d]); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[d] = fmaf(y[4 + j], w1[j], s[d]); }
+      }
+    }
   }
   for (int d = 0; d < 2; ++d) {
 #pragma unroll
@@ -936,72 +1339,103 @@ void launch_im2col2d(const void* in, bool src_f32, void* out, int B, int H, int 
   }
 }
 
-// GroupNorm (C/16 groups, local_map_encoder.py:63-76) on the f32 GEMM output [B][HW][C],
-// optional residual add and ReLU (torchvision BasicBlock), writes the activation type.
+// GroupNorm (C/16 groups, local_map_encoder.py:63-76) on the f32 GEMM output [B][HW][C] (sum of the split-K
+// slabs), optional residual add and ReLU (torchvision BasicBlock), writes the activation type.
+// One 256-thread workgroup per sample: a thread owns 4 consecutive channels (16-B loads) of one position per
+// pass, T = C/4 threads span a position, 256/T positions per pass, <= GN2D_MAXP passes kept in registers;
+// a group is 4 adjacent threads x all positions: shuffle over the 4 threads, then 64 LDS partials
+// (positions-per-pass x groups) summed by every thread.  Mean first, then centred squares (two passes over
+// registers), as torch's GroupNorm.
+#define GN2D_MAXP 7
 template <int PREC>
-__global__ void __launch_bounds__(64) gn2d_kernel(const float* __restrict__ in, int nslab, long long slab_stride,
-                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  const void* __restrict__ res, int relu, void* __restrict__ out, int HW,
-                                                  int C, float eps) {
-  const int groups = C >> 4;
-  const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
-  const int lane = threadIdx.x;
-  const int n = HW * 16;
-  const long long base = (long long)b * HW * C + g * 16;
-  // each lane keeps its (up to 4) elements in registers: sum of the split-K partial slabs
-  float v[4];
+__global__ void __launch_bounds__(256) gn2d_kernel(const float* __restrict__ in, int nslab, long long slab_stride,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const void* __restrict__ res, int relu, void* __restrict__ out, int HW,
+                                                   int C, float eps) {
+  __shared__ float red[2][64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int T = C >> 2, PP = 256 / T, G = C >> 4;
+  const int tpos = tid / T, tc = tid - tpos * T, grp = tc >> 2;
+  const long long base = (long long)b * HW * C + 4 * tc;
+  f32x4_t v[GN2D_MAXP];
   float s = 0.f;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int e = lane + 64 * t;
-    float x = 0.f;
-    if (e < n) {
-      const long long idx = base + (long long)(e >> 4) * C + (e & 15);
-      for (int sl = 0; sl < nslab; ++sl) x += in[idx + sl * slab_stride];
+  for (int k = 0; k < GN2D_MAXP; ++k) {
+    const int pos = k * PP + tpos;
+    f32x4_t x = {0.f, 0.f, 0.f, 0.f};
+    if (pos < HW) {
+      const float* src = in + base + (long long)pos * C;
+      for (int sl = 0; sl < nslab; ++sl) {
+        const f32x4_t t = *(const f32x4_t*)(src + sl * slab_stride);
+        x += t;
+      }
+      s += (x[0] + x[1]) + (x[2] + x[3]);
     }
-    v[t] = x;
-    s += x;
+    v[k] = x;
   }
-  for (int e = lane + 256; e < n; e += 64) {                 // maps larger than 16 pixels (stem / layer1)
-    const long long idx = base + (long long)(e >> 4) * C + (e & 15);
-    float x = 0.f;
-    for (int sl = 0; sl < nslab; ++sl) x += in[idx + sl * slab_stride];
-    s += x;
-  }
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  if ((tc & 3) == 0) red[0][tpos * G + grp] = s;
+  __syncthreads();
+  float tot = 0.f;
+  for (int q = 0; q < PP; ++q) tot += red[0][q * G + grp];
+  const float inv_n = 1.0f / (float)(HW * 16);
+  const float mean = tot * inv_n;
+  float q2 = 0.f;
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-  const float mean = s / (float)n;
-  float q = 0.f;
+  for (int k = 0; k < GN2D_MAXP; ++k) {
+    if (k * PP + tpos < HW) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int e = lane + 64 * t;
-    if (e < n) { const float d = v[t] - mean; q += d * d; }
+      for (int j = 0; j < 4; ++j) { const float d = v[k][j] - mean; q2 = fmaf(d, d, q2); }
+    }
   }
-  for (int e = lane + 256; e < n; e += 64) {
-    const long long idx = base + (long long)(e >> 4) * C + (e & 15);
-    float x = 0.f;
-    for (int sl = 0; sl < nslab; ++sl) x += in[idx + sl * slab_stride];
-    const float d = x - mean;
-    q += d * d;
-  }
+  q2 += __shfl_xor(q2, 1);
+  q2 += __shfl_xor(q2, 2);
+  if ((tc & 3) == 0) red[1][tpos * G + grp] = q2;
+  __syncthreads();
+  float var = 0.f;
+  for (int q = 0; q < PP; ++q) var += red[1][q * G + grp];
+  const float rstd = rsqrtf(var * inv_n + eps);
+  const f32x4_t ga = *(const f32x4_t*)(gamma + 4 * tc), be = *(const f32x4_t*)(beta + 4 * tc);
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m);
-  const float rstd = rsqrtf(q / (float)n + eps);
-  for (int e = lane; e < n; e += 64) {
-    const long long idx = base + (long long)(e >> 4) * C + (e & 15);
-    const int c = g * 16 + (e & 15);
-    float x;
-    if (e < 256) x = v[e >> 6];
-    else { x = 0.f; for (int sl = 0; sl < nslab; ++sl) x += in[idx + sl * slab_stride]; }
-    float y = (x - mean) * rstd * gamma[c] + beta[c];
-    if (res != nullptr) y += load_elem<PREC>(res, idx);
-    if (relu) y = y > 0.f ? y : 0.f;
-    store_elem<PREC>(out, idx, y);
+  for (int k = 0; k < GN2D_MAXP; ++k) {
+    const int pos = k * PP + tpos;
+    if (pos >= HW) continue;
+    const long long idx = base + (long long)pos * C;
+    float y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = (v[k][j] - mean) * rstd * ga[j] + be[j];
+    if (res != nullptr) {
+      if constexpr (PREC == 1) {
+        const f32x4_t r = *(const f32x4_t*)((const float*)res + idx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] += r[j];
+      } else {
+        const short4_t r = *(const short4_t*)((const unsigned short*)res + idx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] += bf2f((unsigned short)r[j]);
+      }
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = y[j] > 0.f ? y[j] : 0.f;
+    }
+    if constexpr (PREC == 1) {
+      const f32x4_t o = {y[0], y[1], y[2], y[3]};
+      *(f32x4_t*)((float*)out + idx) = o;
+    } else {
+      short4_t o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (short)f2bf(y[j]);
+      *(short4_t*)((unsigned short*)out + idx) = o;
+    }
   }
 }
 void launch_gn2d(const float* in, int nslab, long long slab_stride, const float* gamma, const float* beta, const void* res,
                  int relu, void* out, int B, int HW, int C, float eps, int prec, hipStream_t s) {
-  dim3 grid((unsigned)(B * (C >> 4))), block(64);
+  // host-side shape contract of the kernel (ResNet-18 stages on maps up to 10 x 10)
+  if (C < 64 || C > 1024 || (C & (C - 1)) != 0 || (HW + 256 / (C >> 2) - 1) / (256 / (C >> 2)) > GN2D_MAXP) abort();
+  dim3 grid((unsigned)B), block(256);
   if (prec == 0) hipLaunchKernelGGL(gn2d_kernel<0>, grid, block, 0, s, in, nslab, slab_stride, gamma, beta, res, relu, out, HW, C, eps);
   else hipLaunchKernelGGL(gn2d_kernel<1>, grid, block, 0, s, in, nslab, slab_stride, gamma, beta, res, relu, out, HW, C, eps);
 }
