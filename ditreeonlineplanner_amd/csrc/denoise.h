@@ -46,6 +46,7 @@ struct ConvGemmParams {
 };
 
 void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s);
+bool conv2d_small_eligible(int prec);                   // implicit Conv2d layers run on the 64 x 64-tile kernel (no split-K)
 int conv_gemm_kind(const ConvGemmParams& p, int prec);   // 0 halo kernel, 1 generic, 2 implicit Conv2d
 void launch_prep_sample(const float* x, void* A0, int B, int P, int D, int prec, hipStream_t s);
 void launch_time_embed(float t, const float* W1, const float* b1, const float* W2, const float* b2, float* out,

@@ -542,7 +542,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
           static int sk_target = -1, sk_cap = 8;          // A/B knobs: DITREE_SPLITK_TARGET (work-groups aimed at), DITREE_SPLITK_CAP
           if (sk_target < 0) {
             const char* e = getenv("DITREE_SPLITK_TARGET");
-            sk_target = (e && atoi(e) > 0) ? atoi(e) : 160;
+            sk_target = (e && atoi(e) > 0) ? atoi(e) : 256;      // one work-group per CU
             const char* c = getenv("DITREE_SPLITK_CAP");
             if (c && atoi(c) > 0) sk_cap = atoi(c);
           }
@@ -555,6 +555,18 @@ void DenoiserState::build(int prec_, int Bmax_) {
           // measured on MI355X at B = 1024: 28.2 ms per round with split-K vs 29.6 without; DITREE_SPLITK=0 disables
           static int use_split = -1;
           if (use_split < 0) { const char* e = getenv("DITREE_SPLITK"); use_split = (e && !atoi(e)) ? 0 : 1; }
+          if (conv2d_small_eligible(prec)) {
+            // 64 x 64 tiles, three work-groups per CU: split only the layers that cannot fill those slots
+            static int small_target = -1;
+            if (small_target < 0) { const char* e = getenv("DITREE_C2D_TARGET"); small_target = (e && atoi(e) > 0) ? atoi(e) : 768; }
+            const int tiles64 = ((1024 * OH * OH + 63) / 64) * (Cout / 64);
+            sk = std::max(1, std::min(std::min(8, nk_total / 2), small_target / tiles64));
+            while (sk > 1 && (size_t)sk * OH * OH * Cout > gout_per_sample) --sk;
+            if (sk > 1) {
+              const int per = (nk_total + sk - 1) / sk;
+              sk = (nk_total + per - 1) / per;
+            }
+          }
           if (!use_split) sk = 1;
           p.splitk = sk;
           p.slab_stride = (long long)M * Cout;

@@ -884,6 +884,7 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
   }
 }
 
+template <bool SNAKE>
 __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int A_BUF = 40960, W_BUF = 32768, W_BASE = 2 * A_BUF;
@@ -984,11 +985,12 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
   auto mm = [&](int aset, int bset, int half, int mb, int jj) {
     acc[mb][half * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[aset][mb], bq[bset][jj], acc[mb][half * 4 + jj], 0, 0, 0);
   };
+  // snake order: consecutive MFMAs always share one operand (A along a row of the 4 x 4 block, B at the turn)
   auto mm16 = [&](int aset, int bset, int half) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) mm(aset, bset, half, mb, jj);
+      for (int jj = 0; jj < 4; ++jj) mm(aset, bset, half, mb, SNAKE ? ((mb & 1) ? 3 - jj : jj) : jj);
   };
 
   // One K-step (chunk c, tap T); flags as in conv3_halo_kernel.  On entry af[0] = A(ks 0), bq[0] = B(ks 0, half 0).
@@ -1030,7 +1032,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
     for (int mb = 0; mb < 4; ++mb)      // phase (1,1) + the LDS-DMA issue of step s+2 / chunk c+2
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
-        mm(1, 1, 1, mb, jj);
+        mm(1, 1, 1, mb, SNAKE ? ((mb & 1) ? 3 - jj : jj) : jj);
         const int i = mb * 4 + jj;
         if constexpr (ISSUE_W) { if (i < 4) issue_w(c2, T2, i); }
         if constexpr (ISSUE_A) { if (i >= 4 && i < 9) issue_a(c + 2, i - 4); }
@@ -1086,6 +1088,117 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
   gemm_epilogue16(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
 }
 
+// =================================================================================================
+// conv2d_small_kernel: implicit-GEMM Conv2d for the local-map encoder (bf16), 64 x 64 tiles.
+//
+// The encoder's GEMMs are small (M = B*OH*OW <= 25 600 rows, N = 64..512 channels, K = live taps x Cin) and,
+// on 256 x 256 tiles, leave most CUs idle behind long latency-bound K loops (one work-group per CU, 128 KB of
+// LDS, split-K slabs to be reduced afterwards).  Here a work-group is 4 waves on a 64 x 64 tile (one 32 x 32
+// accumulator per wave), 3 LDS stages of 16 KB (two K-steps in flight), so 3 work-groups share a CU and
+// every layer launches 128..400 of them: latency is hidden by occupancy, no split-K, no slabs.
+//   GEMM row m = (b, oh, ow); K-step = (live tap, 64-channel chunk); a tap outside the map reads `zero`.
+//   LDS stage: A 64 rows x 128 B + W 64 rows x 128 B, 16-B slots XOR-swizzled on the source address
+//   (slot ^ (row >> 1) & 7), staged by LDS-DMA: 16 one-KiB pieces per stage, 4 per wave.
+//   Output f32 [M][N] (the GroupNorm kernel follows), rows >= M masked.
+// =================================================================================================
+__global__ void __launch_bounds__(256) conv2d_small_kernel(ConvGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 16384;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r5 = lane & 31, h = lane >> 5;
+  const int wm = w >> 1, wn = w & 1;
+  const int ntn = p.N >> 6;
+  const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;      // N-tiles of one M-block are neighbours (A reuse in L2)
+  const int kpt = p.Cin >> 6;                                       // K-steps per tap
+  const long long K = (long long)p.taps * p.Cin;
+  // split-K over blockIdx.y (layers with few tiles and long K): a contiguous range of K-steps per block, partial
+  // tiles go to Out + y * slab_stride and are summed, in slab order, by the GroupNorm kernel
+  int k0 = 0, nk = p.taps * kpt;
+  long long out_extra = 0;
+  if (p.splitk > 1) {
+    const int per = (nk + p.splitk - 1) / p.splitk;
+    k0 = blockIdx.y * per;
+    nk = min(nk - k0, per);
+    out_extra = (long long)blockIdx.y * p.slab_stride;
+  }
+
+  // ---- staging: wave w stages A pieces {2w, 2w+1} (rows 8*piece + (lane >> 3)) and the same W pieces
+  const char* a_base[2];
+  int ih0[2], iw0[2];
+  const char* w_src[2];
+  int slot_b[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = (2 * w + q) * 8 + (lane >> 3);                     // tile row 0..63
+    slot_b[q] = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+    int m = tm * 64 + r;
+    m = m < p.M ? m : p.M - 1;
+    const int b = m / p.c2_OHW, rem = m - b * p.c2_OHW;
+    const int oh = rem / p.c2_OW, ow = rem - oh * p.c2_OW;
+    a_base[q] = (const char*)p.A + (long long)b * p.c2_H * p.c2_W * p.Cin * 2;
+    ih0[q] = oh * p.c2_stride - p.c2_pad;
+    iw0[q] = ow * p.c2_stride - p.c2_pad;
+    w_src[q] = (const char*)p.W + ((long long)(tn * 64 + r) * K) * 2 + slot_b[q];
+  }
+  auto issue = [&](int kl) {                                         // local K-step kl -> ring slot kl % 3
+    const int k = k0 + kl;
+    const int tap = k / kpt, kin = k - tap * kpt;
+    const int kh = p.c2_kh[tap], kw = p.c2_kw[tap];
+    char* st = smem + (kl % 3) * STAGE;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int ih = ih0[q] + kh, iw = iw0[q] + kw;
+      const bool ok = ih >= 0 && ih < p.c2_H && iw >= 0 && iw < p.c2_W;
+      const char* src = ok ? a_base[q] + ((long long)(ih * p.c2_W + iw) * p.Cin + kin * 64) * 2 : (const char*)p.zero;
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + slot_b[q]), (LDS_AS void*)(st + (2 * w + q) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(w_src[q] + (long long)k * 128),
+                                       (LDS_AS void*)(st + 8192 + (2 * w + q) * 1024), 16, 0, 0);
+  };
+
+  f32x16_t acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  const int a_row = wm * 32 + r5, b_row = wn * 32 + r5;
+  const int a_off = a_row * 128, b_off = 8192 + b_row * 128;
+  const int sa = (a_row >> 1) & 7, sb = (b_row >> 1) & 7;
+
+  issue(0);
+  if (nk > 1) issue(1);
+  for (int k = 0; k < nk; ++k) {
+    // stage k landed (the 4 pieces of stage k+1 may stay in flight), every wave is done with stage k-1
+    if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (k + 2 < nk) issue(k + 2);                                    // into the slot read at step k-1
+    const char* st = smem + (k % 3) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(st + a_off + ((((ks << 1) | h) ^ sa) << 4)));
+      const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(st + b_off + ((((ks << 1) | h) ^ sb) << 4)));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's reads of stage k are complete
+  }
+
+  // ---- store: acc[i] = C[row (i & 3) + 8 (i >> 2) + 4 h][col r5]
+  const int n = tn * 64 + wn * 32 + r5;
+  float bias = (p.bias != nullptr && k0 == 0) ? p.bias[n] : 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int m = tm * 64 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (m < p.M) ((float*)p.Out)[out_extra + (long long)m * p.ldc + p.out_coff + n] = acc[i] + bias;
+  }
+}
+bool conv2d_small_eligible(int prec) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("DITREE_C2D_SMALL"); on = (e && !atoi(e)) ? 0 : 1; }
+  return on && prec == 0;
+}
+
 static bool halo_eligible(const ConvGemmParams& p, int prec) {
   static int halo = -1;
   if (halo < 0) { const char* e = getenv("DITREE_NO_HALO"); halo = (e && atoi(e)) ? 0 : 1; }
@@ -1115,16 +1228,28 @@ void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s) {
       hipFuncSetAttribute((const void*)conv3_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
       hipFuncSetAttribute((const void*)conv3_halo_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
       hipFuncSetAttribute((const void*)conv3_halo_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
-      hipFuncSetAttribute((const void*)conv3_halo16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+      hipFuncSetAttribute((const void*)conv3_halo16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+      hipFuncSetAttribute((const void*)conv3_halo16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
       attr2 = true;
     }
     static int shape16 = -1;               // DITREE_HALO_MFMA=32 selects the 32x32x16 kernel (A/B runs)
     if (shape16 < 0) { const char* e = getenv("DITREE_HALO_MFMA"); shape16 = (e && atoi(e) == 32) ? 0 : 1; }
-    if (dbg == 0 && shape16) { hipLaunchKernelGGL(conv3_halo16_kernel, grid, block, 147456, s, p); return; }
+    if (dbg == 0 && shape16) {
+      static int snake = -1;
+      if (snake < 0) { const char* e = getenv("DITREE_HALO_SNAKE"); snake = (e && !atoi(e)) ? 0 : 1; }
+      if (snake) hipLaunchKernelGGL(conv3_halo16_kernel<true>, grid, block, 147456, s, p);
+      else hipLaunchKernelGGL(conv3_halo16_kernel<false>, grid, block, 147456, s, p);
+      return;
+    }
     if (dbg == 1) hipLaunchKernelGGL(conv3_halo_kernel<1>, grid, block, 147456, s, p);
     else if (dbg == 2) hipLaunchKernelGGL(conv3_halo_kernel<2>, grid, block, 147456, s, p);
     else if (dbg == 3) hipLaunchKernelGGL(conv3_halo_kernel<3>, grid, block, 147456, s, p);
     else hipLaunchKernelGGL(conv3_halo_kernel<0>, grid, block, 147456, s, p);
+    return;
+  }
+  if (p.c2d && conv2d_small_eligible(prec) && (p.N & 63) == 0 && (p.Cin & 63) == 0 && p.out_f32 && p.mode == MODE_BIAS) {
+    hipLaunchKernelGGL(conv2d_small_kernel, dim3(((p.M + 63) >> 6) * (p.N >> 6), p.splitk > 1 ? p.splitk : 1), dim3(256),
+                       3 * 16384, s, p);
     return;
   }
   if (p.c2d) {
