@@ -78,26 +78,53 @@ struct DenoiserState {
   long long last_slab[4] = {0, 0, 0, 0};
   // optional per-launch timing of the dominant kernel (hipEvents on the launch stream)
   bool prof_on = false;
+  int prof_mode = 0;             // 1: every MFMA launch, 2: only runs of the dominant (halo) kernel, one event pair per run
   std::vector<hipEvent_t> prof_ev;
   size_t prof_used = 0;
   // per kernel kind: 0 = conv3_halo_kernel, 1 = conv_gemm_kernel, 2 = conv_gemm_kernel (implicit Conv2d)
   double prof_ms_done[3] = {0, 0, 0};
   int64_t prof_launches_done[3] = {0, 0, 0};
   double prof_flops_done[3] = {0, 0, 0};
-  struct ProfRec { size_t a, b; int kind; double flops; };
+  struct ProfRec { size_t a, b; int kind; double flops; int launches; };
+  bool run_open = false;         // mode 2: a run of back-to-back halo launches whose end event is still to be recorded
+  size_t run_end = 0;
+  void close_run() {
+    if (run_open) { hipEventRecord(prof_ev[run_end], prof_last_stream); run_open = false; }
+  }
   // Profiling brackets every GEMM launch with events on its stream.  Back-to-back GEMM launches on
   // one stream share an event (the end of one is the start of the next), which halves the marker
   // packets; `prof_chain` is broken by note_other() whenever another kernel is enqueued in between.
   hipStream_t prof_last_stream = nullptr;
   bool prof_chain = false;
   std::vector<ProfRec> prof_pairs;                           // (start event, end event, kind, flops) per launch
-  void note_other() { prof_chain = false; }
+  void note_other() { close_run(); prof_chain = false; }     // call BEFORE enqueueing the other kernel
   void run_gemm(const ConvGemmParams& p, hipStream_t s) {
     if (!prof_on) { launch_conv_gemm(p, prec, s); return; }
     if (prof_used + 2 > prof_ev.size()) {
       const size_t old = prof_ev.size();
       prof_ev.resize(old + 4096);
       for (size_t i = old; i < prof_ev.size(); ++i) hipEventCreate(&prof_ev[i]);
+    }
+    const double fl = 2.0 * (double)p.M * (double)p.N * (double)p.taps * (double)p.Cin;
+    if (prof_mode == 2) {
+      // dominant kernel only: one (start, end) pair around each run of back-to-back halo launches, so the timed
+      // region carries ~20 marker packets per denoiser call instead of ~120
+      if (conv_gemm_kind(p, prec) != 0) { close_run(); launch_conv_gemm(p, prec, s); return; }
+      if (run_open && prof_last_stream == s) {
+        launch_conv_gemm(p, prec, s);
+        prof_pairs.back().flops += fl;
+        prof_pairs.back().launches += 1;
+        return;
+      }
+      close_run();
+      const size_t st = prof_used++;
+      run_end = prof_used++;
+      hipEventRecord(prof_ev[st], s);
+      launch_conv_gemm(p, prec, s);
+      prof_pairs.push_back(ProfRec{st, run_end, 0, fl, 1});
+      run_open = true;
+      prof_last_stream = s;
+      return;
     }
     size_t start;
     if (prof_chain && prof_last_stream == s && prof_used > 0) {
@@ -109,17 +136,18 @@ struct DenoiserState {
     launch_conv_gemm(p, prec, s);
     const size_t end = prof_used++;
     hipEventRecord(prof_ev[end], s);
-    prof_pairs.push_back(ProfRec{start, end, conv_gemm_kind(p, prec), 2.0 * (double)p.M * (double)p.N * (double)p.taps * (double)p.Cin});
+    prof_pairs.push_back(ProfRec{start, end, conv_gemm_kind(p, prec), fl, 1});
     prof_chain = true;
     prof_last_stream = s;
   }
   void prof_collect() {
+    close_run();
     if (prof_used == 0) return;
     hipDeviceSynchronize();                                  // events live on several streams
     for (auto& pr : prof_pairs) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, prof_ev[pr.a], prof_ev[pr.b]) == hipSuccess) prof_ms_done[pr.kind] += ms;
-      ++prof_launches_done[pr.kind];
+      prof_launches_done[pr.kind] += pr.launches;
       prof_flops_done[pr.kind] += pr.flops;
     }
     prof_pairs.clear();
@@ -861,6 +889,7 @@ int32_t ditree_profile(ditree_ctx* ctx, int32_t enable) {
   if (!st) return set_err(ctx, DITREE_E_STATE, "profile: weights not loaded");
   st->prof_collect();
   st->prof_on = enable != 0;
+  st->prof_mode = enable;
   if (enable) for (int k = 0; k < 3; ++k) { st->prof_ms_done[k] = 0.0; st->prof_launches_done[k] = 0; st->prof_flops_done[k] = 0.0; }
   return DITREE_OK;
 }

@@ -257,7 +257,9 @@ Context.debug_read = _ctx_debug_read
 
 
 def _ctx_profile(self, enable=True):
-    check(self._h, lib().ditree_profile(self._h, int(bool(enable))), "profile")
+    """False / 0: off; True / 1: bracket every MFMA launch with events; 2: only runs of the dominant (halo) kernel,
+    one event pair per run of back-to-back launches (what a timed region can carry without slowing down)."""
+    check(self._h, lib().ditree_profile(self._h, int(enable)), "profile")
 
 
 PROFILE_KINDS = ("conv3_halo16_kernel", "conv_gemm_kernel", "conv2d_small_kernel")

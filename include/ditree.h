@@ -228,11 +228,12 @@ int32_t ditree_denoise(ditree_ctx* ctx, const float* noise, const float* local_m
                        const float* cond, int32_t B, int32_t K, const float* t0, const float* dt,
                        const double* act_norm, double* actions, float* x_out, void* stream);
 
-/* Measurement support: when enabled, every launch of the MFMA kernels is bracketed by hipEvents on
- * its launch stream (back-to-back launches share an event); ditree_profile_read waits for them and
- * returns, per kernel kind k = 0 conv3_halo_kernel, 1 conv_gemm_kernel, 2 conv_gemm_kernel in
- * implicit-Conv2d mode: summed kernel time ms3[k], launches3[k] and executed FLOPs flops3[k]
- * (2*M*N*K of every launch) since the last enable. */
+/* Measurement support.  enable = 1: every launch of the MFMA kernels is bracketed by hipEvents on its launch
+ * stream (back-to-back launches share an event; ~120 marker packets per denoiser call, which costs a timed
+ * region ~6 %); enable = 2: only the dominant kernel, one event pair around each run of back-to-back halo
+ * launches (~20 packets per call); 0: off.  ditree_profile_read waits for the events and returns, per kernel
+ * kind k = 0 conv3_halo16_kernel, 1 conv_gemm_kernel, 2 conv2d_small_kernel: summed kernel time ms3[k],
+ * launches3[k] and executed FLOPs flops3[k] (2*M*N*K of every launch) since the last enable. */
 int32_t ditree_profile(ditree_ctx* ctx, int32_t enable);
 int32_t ditree_profile_read(ditree_ctx* ctx, double* ms3, int64_t* launches3, double* flops3);
 
