@@ -1,22 +1,24 @@
-"""Flow-matching step schedule (mirror of the reference's common/fm_utils.py:4-17).
-
-Host-side and tiny (K values); evaluated with torch float32 exactly like the reference
-so that t0/dt are bit-identical to what the reference sampler would use.
+"""Flow-matching step schedule: start times ``t0`` and step sizes ``dt`` of the K Euler steps
+(reference behaviour: common/fm_utils.py:4-17).  Host side, K values, evaluated in torch float32 so that
+t0 / dt carry the same bits the reference sampler would use (checked against tests/golden/timesteps.json).
 """
 import torch
 
+_WEIGHTS = {
+    # un-normalised step weights on the grid s_i = i / K, i < K
+    "cosine": lambda s, scale: torch.cos(s * torch.pi) + 1,
+    "exp": lambda s, scale: torch.exp(-s * scale),
+}
+
 
 def get_timesteps(schedule: str, k_steps: int, exp_scale: float = 1.0):
-    t = torch.linspace(0, 1, k_steps + 1)[:-1]
+    grid = torch.linspace(0, 1, k_steps + 1)[:-1]
     if schedule == "linear":
-        dt = torch.full((k_steps,), 1.0) / k_steps
-    elif schedule == "cosine":
-        dt = torch.cos(t * torch.pi) + 1
-        dt = dt / dt.sum()
-    elif schedule == "exp":
-        dt = torch.exp(-t * exp_scale)
-        dt = dt / dt.sum()
+        steps = torch.ones(k_steps) / k_steps
+    elif schedule in _WEIGHTS:
+        weights = _WEIGHTS[schedule](grid, exp_scale)
+        steps = weights / torch.sum(weights)
     else:
         raise ValueError(f"Invalid schedule: {schedule}")
-    t0 = torch.cat((torch.zeros(1), torch.cumsum(dt, dim=0)[:-1]))
-    return t0, dt
+    starts = torch.cat((torch.zeros(1), torch.cumsum(steps, dim=0)[:-1]))
+    return starts, steps
