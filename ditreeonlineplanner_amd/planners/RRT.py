@@ -21,7 +21,7 @@ import time
 import numpy as np
 import torch
 
-from ..engine import CNT_ITERS, ExpansionEngine
+from ..engine import CNT_GOAL, CNT_ITERS, ExpansionEngine
 from .base_planner import BasePlanner, Node
 
 
@@ -52,6 +52,8 @@ class RRT_Planner(BasePlanner):
             emulate_sticky_done=kwargs.get("emulate_sticky_done", True), early_exit=kwargs.get("early_exit", True),
             run_type=self.run_type)
         self._engine.env_goal = np.asarray(self.env.goal, dtype=np.float64)
+        from concurrent.futures import ThreadPoolExecutor
+        self._draw_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ditree-draw")
 
     # ------------------------------------------------------------------ reference surface
     def reset(self, start_state=None, goal_state=None, reset_main_path=False):
@@ -166,18 +168,34 @@ class RRT_Planner(BasePlanner):
         if self.run_type > 0 and self.init_main_path is not None:
             remain = self.extract_path_after_obstacle()
         eng.init_main_path = self.init_main_path if self.run_type > 0 else None
+        # The samples of round r+1 are drawn (host RNGs, reference call order) by a helper thread while round r runs
+        # on the GPU: the C-ABI call releases the GIL, and the draws do not depend on the tree.  With batch = 1
+        # nothing is drawn ahead, so the RNG streams advance exactly as in the reference.
+        def round_size(already):
+            return self.batch if self.max_candidates is None else min(self.batch, self.max_candidates - already)
+
+        ahead = self.batch > 1
+        pool = self._draw_pool if ahead else None
+        pending = None
+        cnt = None
         while (time.time() - start_time) < self.time_budget:
             if self.max_candidates is not None and drawn >= self.max_candidates:
                 break
-            B = self.batch if self.max_candidates is None else min(self.batch, self.max_candidates - drawn)
-            s, c = self.draw_round(B, remain)
+            B = round_size(drawn)
+            s, c = pending.result() if pending is not None else self.draw_round(B, remain)
+            pending = None
+            nxt = drawn + B
+            if ahead and (self.max_candidates is None or nxt < self.max_candidates):
+                pending = pool.submit(self.draw_round, round_size(nxt), remain)
             noise = torch.randn((B, eng.n_chunks, eng.P, 2), device=dev)
             cnt = eng.expand_round(torch.as_tensor(s, device=dev), torch.as_tensor(c, device=dev), noise=noise)
             drawn += B
-            goal = eng.goal_node
+            goal = int(cnt[CNT_GOAL]) if int(cnt[CNT_GOAL]) >= 0 else None
             if goal is not None:
                 break
-        iters = int(eng.tree.counters[CNT_ITERS].item())
+        if pending is not None:
+            pending.result()                     # never leave the helper running on the global RNGs
+        iters = int(cnt[CNT_ITERS]) if cnt is not None else 0
         self.env.prob_map = orig_prob_map
         if goal is not None:
             self.env.done = True
