@@ -637,9 +637,32 @@ void DenoiserState::build(int prec_, int Bmax_) {
     const int H1 = osz(H0, 7, 2, 3);                  // 10
     const int H2 = osz(H1, 3, 2, 1);                  // 5
     Act c1 = ebuf("enc.c1", H1 * H1, 64);
+    Act pool = ebuf("enc.pool", H2 * H2, 64);
+    static int fused_stem = -1;                     // DITREE_FUSED_STEM=0: the layered im2col / GEMM / GroupNorm / pool path
+    if (fused_stem < 0) { const char* e = getenv("DITREE_FUSED_STEM"); fused_stem = (e && !atoi(e)) ? 0 : 1; }
+    if (fused_stem && H0 == 20) {
+      // one launch: conv 7x7/2 (input channels folded) + GroupNorm + ReLU + max-pool
+      const HostParam& w = P_(R + "conv1.weight");
+      const int Cw = (int)w.dims[1];
+      std::vector<float> wf(64 * 49);
+      for (int n = 0; n < 64; ++n)
+        for (int t = 0; t < 49; ++t) {
+          float sacc = 0.f;
+          for (int cc = 0; cc < Cw; ++cc) sacc += w.data[((size_t)n * Cw + cc) * 49 + t];
+          wf[t * 64 + n] = sacc;                       // tap-major: lanes (channels) read consecutive floats
+        }
+      float* wdev = upload_f32(R + "conv1.weight#folded", wf.data(), 64 * 49);
+      float* ga = vec(R + "bn1.weight");
+      float* be = vec(R + "bn1.bias");
+      char* op = (char*)pool.p;
+      const float** lm_slot = &lm_ptr;
+      enc_ops.push_back([=, this](int b0, int Bn, int, hipStream_t s) {
+        note_other();
+        launch_encoder_stem(*lm_slot + (size_t)b0 * 400, wdev, ga, be, op + (size_t)b0 * 25 * 64 * E_, Bn, 1e-5f, pr, s);
+      });
+    } else {
     conv2d(R + "conv1", nullptr, H0, 1, 64, 7, 2, 3, H1, true);
     gn(R + "bn1", c1, nullptr, true);
-    Act pool = ebuf("enc.pool", H2 * H2, 64);
     {
       const char* ip = (const char*)c1.p; char* op = (char*)pool.p;
       const int a = H1, b2 = H2;
@@ -647,6 +670,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
         note_other();
         launch_maxpool2d(ip + (size_t)b0 * a * a * 64 * E_, op + (size_t)b0 * b2 * b2 * 64 * E_, Bn, a, a, 64, b2, b2, pr, s);
       });
+    }
     }
     Act cur = pool;
     int Hc = H2, Cc = 64;

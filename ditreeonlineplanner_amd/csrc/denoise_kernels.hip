@@ -1284,6 +1284,86 @@ __device__ __forceinline__ float load_elem(const void* base, long long idx) {
 
 // x (B, P, D) f32 -> A0 rows (b, l): [x[l-1,:], x[l,:], x[l+1,:], 0 ...] (K padded to 64): the
 // im2col of the first Conv1d(D -> C, 3) (conditional_unet1d.py:214-218 with dim_in = input_dim).
+// Encoder stem in one launch: Conv2d(1 -> 64, 7x7, stride 2, pad 3; the three identical input channels of
+// x.repeat(1,3,1,1) are folded into the weights) + GroupNorm(4 groups of 16 channels) + ReLU + MaxPool(3, 2, 1)
+// (local_map_encoder.py:101-122 through torchvision's resnet18 stem).  One 256-thread work-group per sample:
+// the padded 26 x 26 map and the 64 x 49 f32 weights sit in LDS / registers, thread (c = tid & 63, q = tid >> 6)
+// computes channel c at positions q, q+4, ... (25 of the 100), f32 FMA in (kh, kw) order; group statistics in two
+// passes over registers; the normalised 10 x 10 x 64 map goes through LDS to the 5 x 5 max-pool.
+// Replaces im2col + GEMM + GroupNorm + max-pool launches (and their 26 MB of intermediates per 1024 samples).
+template <int PREC>
+__global__ void __launch_bounds__(256) encoder_stem_kernel(const float* __restrict__ lm /*[B][20][20]*/,
+                                                           const float* __restrict__ W /*[49][64]: tap-major, coalesced per lane*/,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           void* __restrict__ out /*[B][25][64]*/, float eps) {
+  __shared__ float s_map[26 * 26];
+  __shared__ float s_act[100 * 64];
+  __shared__ float s_red[2][4][4];                    // [pass][position quarter][group]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int c = tid & 63, q = tid >> 6, g = c >> 4;
+  for (int i = tid; i < 26 * 26; i += 256) {
+    const int r = i / 26 - 3, cc = i % 26 - 3;
+    s_map[i] = (r >= 0 && r < 20 && cc >= 0 && cc < 20) ? lm[(size_t)b * 400 + r * 20 + cc] : 0.0f;
+  }
+  float w[49];
+#pragma unroll
+  for (int k = 0; k < 49; ++k) w[k] = W[k * 64 + c];
+  __syncthreads();
+  float v[25];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < 25; ++j) {
+    const int p = q + 4 * j, oh = p / 10, ow = p - oh * 10;
+    const float* m0 = s_map + (oh * 2) * 26 + ow * 2;
+    float a = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 7; ++kw) a = fmaf(w[kh * 7 + kw], m0[kh * 26 + kw], a);
+    v[j] = a;
+    sum += a;
+  }
+  // the 16 channels of a group are 16 adjacent lanes; the 4 position quarters are the 4 waves
+  sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+  if ((c & 15) == 0) s_red[0][q][g] = sum;
+  __syncthreads();
+  const float mean = ((s_red[0][0][g] + s_red[0][1][g]) + (s_red[0][2][g] + s_red[0][3][g])) * (1.0f / 1600.0f);
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < 25; ++j) { const float d = v[j] - mean; sq = fmaf(d, d, sq); }
+  sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4); sq += __shfl_xor(sq, 8);
+  if ((c & 15) == 0) s_red[1][q][g] = sq;
+  __syncthreads();
+  const float var = ((s_red[1][0][g] + s_red[1][1][g]) + (s_red[1][2][g] + s_red[1][3][g])) * (1.0f / 1600.0f);
+  const float rstd = rsqrtf(var + eps);
+  const float ga = gamma[c] * rstd, be = beta[c] - mean * ga;
+#pragma unroll
+  for (int j = 0; j < 25; ++j) {
+    float y = fmaf(v[j], ga, be);
+    y = y > 0.f ? y : 0.f;
+    if constexpr (PREC == 0) y = bf2f(f2bf(y));      // the activation is stored as bf16 before the pool in the layered path
+    s_act[(q + 4 * j) * 64 + c] = y;
+  }
+  __syncthreads();
+  for (int o = tid; o < 25 * 64; o += 256) {
+    const int oc = o & 63, op = o >> 6, oh = op / 5, ow = op - oh * 5;
+    float best = -__builtin_huge_valf();
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ih = oh * 2 + kh - 1, iw = ow * 2 + kw - 1;
+        if (ih >= 0 && ih < 10 && iw >= 0 && iw < 10) best = fmaxf(best, s_act[(ih * 10 + iw) * 64 + oc]);
+      }
+    store_elem<PREC>(out, (long long)b * 1600 + o, best);
+  }
+}
+void launch_encoder_stem(const float* lm, const float* W, const float* gamma, const float* beta, void* out, int B, float eps,
+                         int prec, hipStream_t s) {
+  if (prec == 0) hipLaunchKernelGGL(encoder_stem_kernel<0>, dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps);
+  else hipLaunchKernelGGL(encoder_stem_kernel<1>, dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps);
+}
+
 template <int PREC>
 __global__ void prep_sample_kernel(const float* __restrict__ x, void* __restrict__ A0, int B, int P, int D) {
   const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
