@@ -625,6 +625,11 @@ void DenoiserState::build(int prec_, int Bmax_) {
       const char* rp = res ? (const char*)res->p : nullptr;
       char* op = (char*)out.p;
       const int HW = out.L, C = out.C;
+      {                                                  // shape contract of gn2d_kernel, checked when the plan is built
+        const int pp = (C >= 64 && C <= 1024 && (C & (C - 1)) == 0) ? 256 / (C >> 2) : 0;
+        if (pp == 0 || (HW + pp - 1) / pp > 7)
+          throw std::runtime_error("encoder GroupNorm: unsupported map (" + std::to_string(HW) + " pixels x " + std::to_string(C) + " channels)");
+      }
       enc_ops.push_back([=, this](int b0, int Bn, int reg, hipStream_t s) {
         note_other();
         const size_t off = (size_t)b0 * HW * C * E_;
