@@ -71,6 +71,7 @@ SIGNATURES = {
     "ditree_load_weights": (_i32, [_vp, _vp, _i64, C.c_char_p, _vp]),
     "ditree_denoise_reserve": (_i32, [_vp, _i32, _i32]),
     "ditree_denoise": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _pf, _pf, _pd, _vp, _vp, _vp]),
+    "ditree_denoise_eval": (_i32, [_vp, _vp, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp]),
     "ditree_profile": (_i32, [_vp, _i32]),
     "ditree_profile_read": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ditree_denoise_debug_read": (_i32, [_vp, C.c_char_p, _i32, _vp, _i64, C.POINTER(_i32), _vp]),

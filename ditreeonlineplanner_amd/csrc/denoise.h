@@ -54,7 +54,7 @@ void launch_time_embed(float t, const float* W1, const float* b1, const float* W
 void launch_prep_cond(const float* temb, const float* map_emb, int E, const float* cond, int G, void* out, int B,
                       int Kpad, int prec, hipStream_t s);
 void launch_final_proj_flow(const void* Y, int C, int Lp, const float* W, const float* bias, int D, float* x, float dt,
-                            const double* act_norm, double* actions, int B, int P, int prec, hipStream_t s);
+                            const double* act_norm, double* actions, int B, int P, int prec, hipStream_t s, int raw = 0);
 struct TapList {          // live (kh, kw) taps of a Conv2d on a small map
   int n;
   signed char kh[49], kw[49];

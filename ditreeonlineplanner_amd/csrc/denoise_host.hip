@@ -761,9 +761,25 @@ static int parse_manifest(DenoiserState* st, const char* manifest, int64_t n_flo
   return 0;
 }
 
+static int denoise_core(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const int32_t* noise_idx,
+                        const float* local_map, const float* cond, int B, int K, const float* t0, const float* dt,
+                        const double* act_norm, double* actions, float* x_out, hipStream_t s, float t_scale, int raw,
+                        int reuse_encoder);
+
 int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const int32_t* noise_idx, const float* local_map,
                 const float* cond, int B, int K, const float* t0, const float* dt, const double* act_norm, double* actions,
                 float* x_out, hipStream_t s) {
+  return denoise_core(ctx, noise, noise_stride, noise_idx, local_map, cond, B, K, t0, dt, act_norm, actions, x_out, s,
+                      20.0f /* pos_emb_scale, fm_policy.py:187 */, 0, 0);
+}
+
+// t_scale: factor on t0[k] before the sinusoidal embedding (20 for the flow sampler, 1 for a raw evaluation);
+// raw: the last projection writes the network output instead of the Euler update; reuse_encoder: keep the map
+// embedding of the previous call (same local maps: the steps of a DDPM loop).
+static int denoise_core(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const int32_t* noise_idx,
+                        const float* local_map, const float* cond, int B, int K, const float* t0, const float* dt,
+                        const double* act_norm, double* actions, float* x_out, hipStream_t s, float t_scale, int raw,
+                        int reuse_encoder) {
   DenoiserState* st = ctx->dn;
   if (!st || !st->loaded) return set_err(ctx, DITREE_E_STATE, "denoise: weights not loaded");
   if (st->prec < 0) return set_err(ctx, DITREE_E_STATE, "denoise: call ditree_denoise_reserve first");
@@ -782,7 +798,7 @@ int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const
                                     hipMemcpyDeviceToDevice, s));
   }
   st->lm_ptr = local_map;
-  {
+  if (!reuse_encoder) {
     // encoder: up to ENC_SUBS sub-batches on separate streams (fork/join with events on `s`)
     // measured on MI355X (B = 1024): 4 concurrent sub-batches cost more in extra launches than the
     // concurrency returns (34.9 vs 31.6 ms per round); default is one sub-batch, DITREE_ENC_SUBS overrides
@@ -811,7 +827,7 @@ int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const
     }
   }
   for (int k = 0; k < K; ++k) {
-    const float t = t0[k] * 20.0f;                                      // pos_emb_scale, fm_policy.py:187
+    const float t = t0[k] * t_scale;
     if (t != st->temb_t) {                                              // batch-invariant: K = 1 computes it once
       launch_time_embed(t, st->dev_f["unet.diffusion_step_encoder.1.weight"], st->dev_f["unet.diffusion_step_encoder.1.bias"],
                         st->dev_f["unet.diffusion_step_encoder.3.weight"], st->dev_f["unet.diffusion_step_encoder.3.bias"],
@@ -828,7 +844,7 @@ int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const
     st->note_other();
     launch_final_proj_flow(st->final_h.p, st->final_h.C, st->final_h.Lp(), st->dev_f["unet.final_conv.1.weight"],
                            st->dev_f["unet.final_conv.1.bias"], st->D, st->x_cur, dt[k], act_norm,
-                           (last && actions) ? actions : nullptr, B, st->P, pr, s);
+                           (last && actions) ? actions : nullptr, B, st->P, pr, s, raw);
   }
   if (x_out) HIP_TRY(ctx, hipMemcpyAsync(x_out, st->x_cur, (size_t)B * st->P * st->D * 4, hipMemcpyDeviceToDevice, s));
   HIP_TRY(ctx, hipGetLastError());
@@ -910,6 +926,17 @@ int32_t ditree_denoise(ditree_ctx* ctx, const float* noise, const float* local_m
   if (!ctx->dn) return set_err(ctx, DITREE_E_STATE, "denoise: weights not loaded");
   return denoise_run(ctx, noise, (int64_t)ctx->dn->P * ctx->dn->D, nullptr, local_map, cond, B, K, t0, dt, act_norm, actions, x_out,
                      (hipStream_t)stream);
+}
+
+int32_t ditree_denoise_eval(ditree_ctx* ctx, const float* sample, const float* local_map, const float* cond, int32_t B,
+                            float timestep, int32_t reuse_encoder, float* out, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!ctx->dn) return set_err(ctx, DITREE_E_STATE, "denoise_eval: weights not loaded");
+  if (!out) return set_err(ctx, DITREE_E_ARG, "denoise_eval: bad argument");
+  const float one = 1.0f;
+  const double unit[4] = {0.0, 0.0, 1.0, 1.0};
+  return denoise_core(ctx, sample, (int64_t)ctx->dn->P * ctx->dn->D, nullptr, local_map, cond, B, 1, &timestep, &one, unit,
+                      nullptr, out, (hipStream_t)stream, 1.0f, 1, reuse_encoder);
 }
 
 int32_t ditree_profile(ditree_ctx* ctx, int32_t enable) {

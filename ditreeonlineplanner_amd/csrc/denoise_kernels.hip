@@ -1452,7 +1452,7 @@ __global__ void __launch_bounds__(256) final_proj_flow_kernel(const void* __rest
                                                               const float* __restrict__ bias, int D,
                                                               float* __restrict__ x /*[B][P][D] in/out*/, float dt,
                                                               double mu0, double mu1, double sg0, double sg1,
-                                                              double* __restrict__ actions, int B, int P) {
+                                                              double* __restrict__ actions, int B, int P, int raw) {
   const long long pos = blockIdx.x * 4LL + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (pos >= (long long)B * P) return;
@@ -1488,7 +1488,7 @@ __global__ void __launch_bounds__(256) final_proj_flow_kernel(const void* __rest
   if (lane < D && lane < 2) {
     const float v = s[lane] + bias[lane];
     const long long xi = pos * D + lane;
-    const float xn = x[xi] + v * dt;                        // naction + vel_pred * dt[k]
+    const float xn = raw ? v : x[xi] + v * dt;              // naction + vel_pred * dt[k]; raw: the network output itself
     x[xi] = xn;
     if (actions != nullptr) {
       const double sg = lane == 0 ? sg0 : sg1, mu = lane == 0 ? mu0 : mu1;
@@ -1497,15 +1497,15 @@ __global__ void __launch_bounds__(256) final_proj_flow_kernel(const void* __rest
   }
 }
 void launch_final_proj_flow(const void* Y, int C, int Lp, const float* W, const float* bias, int D, float* x, float dt,
-                            const double* act_norm, double* actions, int B, int P, int prec, hipStream_t s) {
+                            const double* act_norm, double* actions, int B, int P, int prec, hipStream_t s, int raw) {
   long long pos = (long long)B * P;
   dim3 grid((unsigned)((pos + 3) / 4)), block(256);
   if (prec == 0)
     hipLaunchKernelGGL(final_proj_flow_kernel<0>, grid, block, 0, s, Y, C, Lp, W, bias, D, x, dt, act_norm[0],
-                       act_norm[1], act_norm[2], act_norm[3], actions, B, P);
+                       act_norm[1], act_norm[2], act_norm[3], actions, B, P, raw);
   else
     hipLaunchKernelGGL(final_proj_flow_kernel<1>, grid, block, 0, s, Y, C, Lp, W, bias, D, x, dt, act_norm[0],
-                       act_norm[1], act_norm[2], act_norm[3], actions, B, P);
+                       act_norm[1], act_norm[2], act_norm[3], actions, B, P, raw);
 }
 
 // ------------------------------------------------------------------------------- encoder helpers

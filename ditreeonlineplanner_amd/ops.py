@@ -241,6 +241,18 @@ def _ctx_denoise(self, noise, local_map, cond, t0=None, dt=None, act_norm=None, 
     return actions if want_actions else xout
 
 
+def _ctx_denoise_eval(self, sample, local_map, cond, timestep, reuse_encoder=False):
+    """One raw network evaluation net(sample, map, timestep, cond) -> (B,P,D) f32 (the DDPM branch's model call)."""
+    dev = self.device
+    _chk(sample, torch.float32, "sample", dev)
+    _chk(local_map, torch.float32, "local_map", dev)
+    _chk(cond, torch.float32, "cond", dev)
+    out = torch.empty_like(sample)
+    check(self._h, lib().ditree_denoise_eval(self._h, _ptr(sample), _ptr(local_map), _ptr(cond), sample.shape[0],
+                                             float(timestep), int(bool(reuse_encoder)), _ptr(out), self.stream), "denoise_eval")
+    return out
+
+
 def _ctx_debug_read(self, name, B, capacity=1 << 26):
     out = torch.empty(capacity, dtype=torch.float32, device=self.device)
     dims = (C.c_int32 * 3)()
@@ -253,6 +265,7 @@ def _ctx_debug_read(self, name, B, capacity=1 << 26):
 Context.load_weights = _ctx_load_weights
 Context.denoise_reserve = _ctx_denoise_reserve
 Context.denoise = _ctx_denoise
+Context.denoise_eval = _ctx_denoise_eval
 Context.debug_read = _ctx_debug_read
 
 

@@ -48,8 +48,10 @@ class DiffusionSampler(nn.Module):
                  position_conditioned=False, goal_conditioned=True, local_map_conditioned=True, local_map_size=16,
                  metadata=None, ctx=None, precision=_lib.PREC_BF16):
         super().__init__()
-        if "car" not in env_id.lower() or policy != "flow_matching" or prediction_type != "actions":
-            raise NotImplementedError("this round covers carmaze + flow_matching + action prediction")
+        if "car" not in env_id.lower() or policy not in ("flow_matching", "diffusion") or prediction_type != "actions":
+            raise NotImplementedError("covered: carmaze, flow_matching / diffusion, action prediction")
+        if policy == "diffusion" and noise_scheduler is None:
+            raise ValueError("policy='diffusion' needs a noise scheduler (set_timesteps / timesteps / step)")
         if obs_history != 1 or action_history != 1 or position_conditioned or not goal_conditioned:
             raise NotImplementedError("car config: obs_history = action_history = 1, goal conditioned")
         self.metadata = metadata if metadata is not None else load_metadata(env_id)
@@ -115,5 +117,16 @@ class DiffusionSampler(nn.Module):
         lm = (lm * 2 - 1).contiguous()                             # fm_policy.py:152
         noise = torch.randn((B, self.pred_horizon, self.action_dim), device=dev)     # :158-159
         self.ensure_bound(B)
+        if self.policy == "diffusion":
+            # fm_policy.py:164-182: the caller's scheduler (e.g. diffusers' DDPMScheduler) drives the loop; every
+            # model call is one raw network evaluation on the device, the map embedding is computed once
+            self.noise_scheduler.set_timesteps(self.num_diffusion_iters)
+            naction = noise
+            for i, k in enumerate(self.noise_scheduler.timesteps):
+                noise_pred = ctx.denoise_eval(naction.contiguous(), lm, cond, float(k), reuse_encoder=i > 0)
+                naction = self.noise_scheduler.step(model_output=noise_pred, timestep=k, sample=naction).prev_sample
+                naction = naction.to(torch.float32)
+            x = naction.detach().to("cpu").numpy()
+            return x * self.metadata["Actions_std"] + self.metadata["Actions_mean"]          # :201-203
         actions = ctx.denoise(noise, lm, cond, t0=self.t0, dt=self.dt, act_norm=self.norm[12:16], want_actions=True)
         return actions.cpu().numpy()

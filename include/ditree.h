@@ -228,6 +228,15 @@ int32_t ditree_denoise(ditree_ctx* ctx, const float* noise, const float* local_m
                        const float* cond, int32_t B, int32_t K, const float* t0, const float* dt,
                        const double* act_norm, double* actions, float* x_out, void* stream);
 
+/* One raw evaluation of the noise-prediction network, out = net(sample, map, timestep, cond)
+ * (model/diffusion/conditional_unet1d.py:268-347 behind local_map_encoder.py:101-109): the building block of the
+ * sampler's policy = 'diffusion' branch (policies/fm_policy.py:164-182), whose scheduler step stays with the caller.
+ *   sample [dev] (B, P, 2) f32; timestep: the value the sinusoidal embedding sees (the scheduler's k);
+ *   reuse_encoder != 0 keeps the map embedding of the previous call (same local maps, later steps of one loop);
+ *   out [dev] (B, P, 2) f32. */
+int32_t ditree_denoise_eval(ditree_ctx* ctx, const float* sample, const float* local_map, const float* cond,
+                            int32_t B, float timestep, int32_t reuse_encoder, float* out, void* stream);
+
 /* Measurement support.  enable = 1: every launch of the MFMA kernels is bracketed by hipEvents on its launch
  * stream (back-to-back launches share an event; ~120 marker packets per denoiser call, which costs a timed
  * region ~6 %); enable = 2: only the dominant kernel, one event pair around each run of back-to-back halo
