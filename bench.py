@@ -129,6 +129,11 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # Rehearsal of the N > 1 path on a one-GPU box (tests only, never a measurement): every rank uses device 0 and the
+    # candidate records travel through gloo (RCCL refuses two ranks on one device).
+    rehearse = os.environ.get("DITREE_REHEARSE_ONE_GPU", "0") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     pg = None
     force_dist = world == 1 and os.environ.get("DITREE_FORCE_DIST", "0") == "1"     # RCCL path on a single GPU
@@ -137,7 +142,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("NCCL_DEBUG", "WARN")          # keep RCCL's banner off stdout: rank 0 prints one JSON line
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from ditreeonlineplanner_amd import _lib
     from ditreeonlineplanner_amd.engine import CNT_GOAL, CNT_LATCH, CNT_NODES, ExpansionEngine
@@ -193,7 +201,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        et = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        et = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         elapsed = float(et.item())
     prof = prof_all = None
@@ -228,7 +236,7 @@ def main():
             dist.barrier()
         e2 = time.perf_counter() - t1
         if world > 1:
-            et = torch.tensor([e2], device=dev, dtype=torch.float64)
+            et = torch.tensor([e2], device="cpu" if rehearse else dev, dtype=torch.float64)
             dist.all_reduce(et, op=dist.ReduceOp.MAX)
             e2 = float(et.item())
         run = eng.rb.chunks_run[:Btot].float().mean().item()
@@ -244,7 +252,7 @@ def main():
             "metric": "candidate tree-expansions/sec (carmaze, H=32)", "value": value,
             "unit": "candidate expansions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic" + (" (one-GPU rehearsal of N ranks over gloo: not a measurement)" if rehearse else ""),
             "config": {"workload": f"cfgs/carmaze.yaml + fm_policy flow sampler (K=1), batch={Bper} candidates per GPU, "
                                    f"H=32 (4 chunks x 8 steps), boxes.csv 20x20, {N0}-node tree snapshot, seeded random weights",
                        "batch_per_gpu": Bper, "global_batch": Btot, "edge_length": H, "action_horizon": A,
