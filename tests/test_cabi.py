@@ -35,3 +35,29 @@ def test_product_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(_lib.DitreeLibraryError):
         Context()
+
+
+def test_halo_kernel_loop_has_no_scratch_traffic(tmp_path):
+    """The 16x16x32 halo kernel waits for its LDS-DMA stages with a *counted* s_waitcnt vmcnt(5) inside the K loop.
+    That is only sound while the loop body issues no other vector-memory operation: a register spill reloaded or stored
+    there (scratch_* counts in vmcnt) would change what the count means.  Guard the generated code, not the source."""
+    import re
+    import subprocess
+    src = os.path.join(REPO, "ditreeonlineplanner_amd", "csrc", "denoise_kernels.hip")
+    out = tmp_path / "dk.s"
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc, "-S", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", src, "-o", str(out)],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    start = text.index("_Z19conv3_halo16_kernelILb1EEv14ConvGemmParams:")
+    body = text[start:text.index(".Lfunc_end", start)].splitlines()
+    headers = [n for n, l in enumerate(body) if "Loop Header" in l]
+    assert len(headers) == 1, "expected exactly one loop (the chunk loop) in the halo kernel"
+    label = body[headers[0]].split(":")[0].strip()
+    back = [n for n, l in enumerate(body) if re.search(r"s_cbranch\w+\s+" + re.escape(label) + r"\b", l)]
+    assert back, "no backward branch to the chunk loop"
+    loop = body[headers[0]:back[-1] + 1]
+    assert sum("v_mfma_f32_16x16x32_bf16" in l for l in loop) == 192          # 3 K-steps x 64 MFMAs
+    assert any("vmcnt(5)" in l for l in loop)
+    offenders = [l.strip() for l in loop if "scratch_" in l or re.search(r"\b(global|flat)_(load|store)", l)]
+    assert not offenders, offenders
