@@ -1088,7 +1088,25 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
     step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, c);
   }
   __syncthreads();
+#ifdef HALO16_NO_EPILOGUE     // timing experiment: plain scaled bf16 store instead of GroupNorm / Mish / FiLM (data stays O(1))
+  {
+    const float sc = rsqrtf((float)K);
+    const int c_l = wn * 128 + 8 * r4, n0 = tn * 256 + c_l;
+    for (int mb = 0; mb < 4; ++mb) {
+      const int m0 = tm * 256 + wm * 64 + mb * 16;
+      const int b = m0 / p.L, l0 = m0 - b * p.L;
+      for (int i = 0; i < 4; ++i) {
+        const int l = l0 + 4 * h4 + i;
+        const long long orow = (long long)b * p.out_Lp + (long long)l * p.out_stride + p.out_off;
+        short8_t o;
+        for (int jx = 0; jx < 8; ++jx) o[jx] = (short)f2bf(acc[mb][jx][i] * sc);
+        *(short8_t*)((char*)p.Out + (orow * p.ldc + p.out_coff + n0) * 2) = o;
+      }
+    }
+  }
+#else
   gemm_epilogue16(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
+#endif
 }
 
 // =================================================================================================
