@@ -59,6 +59,9 @@ struct TapList {          // live (kh, kw) taps of a Conv2d on a small map
   int n;
   signed char kh[49], kw[49];
 };
+void launch_gn1d(void* x, int ld, int Lp, int row_off, int coff, int L, int C, const float* gamma, const float* beta, float eps,
+                 int mode, const float* film, int film_ld, int film_off, const void* res, int ldres, int res_Lp, int res_off,
+                 int B, int prec, hipStream_t s);
 void launch_encoder_stem(const float* lm, const float* W /*[49][64] f32 (tap-major), input channels folded*/, const float* gamma,
                          const float* beta, void* out /*[B][25][64]*/, int B, float eps, int prec, hipStream_t s);
 void launch_im2col2d(const void* in, bool src_f32, void* out, int B, int H, int W, int C, const TapList& taps, int stride,

@@ -262,10 +262,37 @@ struct DenoiserState {
     if (mode == MODE_GN_MISH_RES) {
       p.Res = aptr(*res); p.ldres = res->ld; p.res_Lp = res->Lp(); p.res_off = res->padded ? 1 : 0;
     }
-    const int L = in.L, pr = prec;
-    ops.push_back([this, p, L](int, int Bp, hipStream_t s) mutable {
-      p.M = Bp * L;
-      run_gemm(p, s);
+    emit_block(ops, p, out, in.L);
+  }
+  // A GEMM whose epilogue is GroupNorm(8) + Mish (+ FiLM | + residual).  The fused epilogue needs whole GroupNorm
+  // groups inside a 256-channel tile: 64, 128 or 256 channels per group (C_out 512 / 1024 / 2048, the `large`
+  // denoiser).  Other sizes run conv + bias in the GEMM and the normalisation / Mish / FiLM / residual in gn1d_kernel.
+  void emit_block(std::vector<std::function<void(int, int, hipStream_t)>>& ops, const ConvGemmParams& p, const Act& out, int L) {
+    const int Cout = p.N, mode = p.mode, pr = prec;
+    const int gch = Cout / 8;
+    const bool fused = mode < MODE_GN_MISH || ((Cout & 255) == 0 && (gch == 64 || gch == 128 || gch == 256));
+    if (!fused) {
+      ConvGemmParams q = p;
+      q.mode = MODE_BIAS;
+      const float* film_p = p.film;
+      const int film_ld_ = p.film_ld, film_off_ = p.film_off, ldres = p.ldres, res_Lp = p.res_Lp, res_off = p.res_off;
+      const void* resp = p.Res;
+      const float *ga = p.gamma, *be = p.beta;
+      void* xo = (void*)out.p;
+      const int ld = out.ld, oLp = out.Lp(), ocoff = out.coff;
+      ops.push_back([=, this](int, int Bp, hipStream_t s) mutable {
+        q.M = Bp * L;
+        run_gemm(q, s);
+        note_other();
+        launch_gn1d(xo, ld, oLp, 1, ocoff, L, Cout, ga, be, 1e-5f, mode, film_p, film_ld_, film_off_, resp, ldres, res_Lp,
+                    res_off, Bp, pr, s);
+      });
+      return;
+    }
+    ConvGemmParams q = p;
+    ops.push_back([this, q, L](int, int Bp, hipStream_t s) mutable {
+      q.M = Bp * L;
+      run_gemm(q, s);
     });
   }
   // Conv1d(k = 1) residual projection.
@@ -426,8 +453,8 @@ void DenoiserState::build(int prec_, int Bmax_) {
     p.L = L0; p.N = C0; p.bias = vec(pre + ".blocks.0.block.0.bias"); p.mode = MODE_GN_MISH_FILM; p.eps = 1e-5f;
     p.gamma = vec(pre + ".blocks.0.block.1.weight"); p.beta = vec(pre + ".blocks.0.block.1.bias"); p.group_ch = C0 / 8;
     p.film = film; p.film_ld = film_cols; p.film_off = film_offs[0];
-    const int pr = prec, L = L0;
-    unet_ops.push_back([this, p, L](int, int Bp, hipStream_t s) mutable { p.M = Bp * L; run_gemm(p, s); });
+    const int L = L0;
+    emit_block(unet_ops, p, h, L0);
     // residual Conv1d(D, C0, 1): centre-tap columns of the same rows
     const HostParam& wr = P_(pre + ".residual_conv.weight");
     const float* wrd = wr.data;
@@ -890,7 +917,7 @@ int32_t ditree_load_weights(ditree_ctx* ctx, const float* blob, int64_t n_floats
     if (st->G < 0 || 3 * st->D > 64 || st->D > 2) throw std::runtime_error("unsupported dimensions (car config: action_dim 2)");
     if (st->P_("unet.diffusion_step_encoder.1.weight").dims[1] != 256) throw std::runtime_error("diffusion_step_embed_dim must be 256");
     for (int i = 0; i < 3; ++i)
-      if (st->dims[i] % 512 != 0 || st->dims[i] > 2048) throw std::runtime_error("down_dims must be multiples of 512, <= 2048");
+      if (st->dims[i] % 64 != 0 || st->dims[i] > 4096) throw std::runtime_error("down_dims must be multiples of 64, <= 4096");
   } catch (const std::exception& e) {
     delete st;
     return set_err(ctx, DITREE_E_ARG, std::string("load_weights: ") + e.what());

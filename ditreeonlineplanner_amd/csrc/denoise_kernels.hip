@@ -1224,7 +1224,7 @@ static bool halo_eligible(const ConvGemmParams& p, int prec) {
   static int halo = -1;
   if (halo < 0) { const char* e = getenv("DITREE_NO_HALO"); halo = (e && atoi(e)) ? 0 : 1; }
   return prec == 0 && halo && !p.c2d && p.taps == 3 && p.in_stride == 1 && p.in_Lp == p.L + 2 && (256 % p.L) == 0 &&
-         p.L >= 16 && (p.M & 255) == 0 && (p.Cin & 63) == 0 && p.Cin >= 192;
+         p.L >= 16 && (p.M & 255) == 0 && (p.N & 255) == 0 && (p.Cin & 63) == 0 && p.Cin >= 192;
 }
 int conv_gemm_kind(const ConvGemmParams& p, int prec) { return halo_eligible(p, prec) ? 0 : (p.c2d ? 2 : 1); }
 
@@ -1305,6 +1305,79 @@ __device__ __forceinline__ float load_elem(const void* base, long long idx) {
 
 // x (B, P, D) f32 -> A0 rows (b, l): [x[l-1,:], x[l,:], x[l+1,:], 0 ...] (K padded to 64): the
 // im2col of the first Conv1d(D -> C, 3) (conditional_unet1d.py:214-218 with dim_in = input_dim).
+// GroupNorm(8 groups) + Mish (+ FiLM | + residual) in place on a padded channels-last activation: the unfused form
+// of the GEMM epilogue, for channel counts whose groups do not map onto the 256-channel GEMM tiles (the reference's
+// denoiser sizes other than `large`: C/8 < 64 or > 256 channels per group).  conv1d_components.py:23-40,
+// conditional_unet1d.py:110-141.  One 256-thread work-group per (sample, group); a thread walks 8-channel vectors;
+// mean, then centred squares, then the update: three passes over at most 16 KB that stay in L2.
+template <int PREC>
+__global__ void __launch_bounds__(256) gn1d_kernel(void* __restrict__ x, int ld, int Lp, int row_off, int coff, int L, int C,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                   int mode, const float* __restrict__ film, int film_ld, int film_off,
+                                                   const void* __restrict__ res, int ldres, int res_Lp, int res_off) {
+  __shared__ float red[8];
+  const int b = blockIdx.x >> 3, g = blockIdx.x & 7;
+  const int gc = C >> 3, vpr = gc >> 3, nvec = L * vpr;          // channels per group, 8-channel vectors per row
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  auto at = [&](int v, int& l, int& c) { l = v / vpr; c = g * gc + (v - l * vpr) * 8; };
+  auto load8 = [&](int l, int c, float (&o)[8]) {
+    const long long idx = ((long long)b * Lp + l + row_off) * ld + coff + c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = load_elem<PREC>(x, idx + j);
+  };
+  auto wg_sum = [&](float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  float s = 0.f;
+  for (int v = tid; v < nvec; v += 256) {
+    int l, c; at(v, l, c);
+    float o[8]; load8(l, c, o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += o[j];
+  }
+  const float inv_n = 1.0f / (float)(L * gc);
+  const float mean = wg_sum(s) * inv_n;
+  float q = 0.f;
+  for (int v = tid; v < nvec; v += 256) {
+    int l, c; at(v, l, c);
+    float o[8]; load8(l, c, o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = o[j] - mean; q = fmaf(d, d, q); }
+  }
+  const float rstd = rsqrtf(wg_sum(q) * inv_n + eps);
+  for (int v = tid; v < nvec; v += 256) {
+    int l, c; at(v, l, c);
+    float o[8]; load8(l, c, o);
+    const long long idx = ((long long)b * Lp + l + row_off) * ld + coff + c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float y = mish_f<PREC>((o[j] - mean) * rstd * gamma[c + j] + beta[c + j]);
+      if (mode == MODE_GN_MISH_FILM) {
+        const float* fr = film + (long long)b * film_ld + film_off + c + j;
+        y = y * fr[0] + fr[C];
+      } else if (mode == MODE_GN_MISH_RES) {
+        y += load_elem<PREC>(res, ((long long)b * res_Lp + l + res_off) * ldres + c + j);
+      }
+      store_elem<PREC>(x, idx + j, y);
+    }
+  }
+}
+void launch_gn1d(void* x, int ld, int Lp, int row_off, int coff, int L, int C, const float* gamma, const float* beta, float eps,
+                 int mode, const float* film, int film_ld, int film_off, const void* res, int ldres, int res_Lp, int res_off,
+                 int B, int prec, hipStream_t s) {
+  if (prec == 0)
+    hipLaunchKernelGGL(gn1d_kernel<0>, dim3(B * 8), dim3(256), 0, s, x, ld, Lp, row_off, coff, L, C, gamma, beta, eps, mode, film,
+                       film_ld, film_off, res, ldres, res_Lp, res_off);
+  else
+    hipLaunchKernelGGL(gn1d_kernel<1>, dim3(B * 8), dim3(256), 0, s, x, ld, Lp, row_off, coff, L, C, gamma, beta, eps, mode, film,
+                       film_ld, film_off, res, ldres, res_Lp, res_off);
+}
+
 // Encoder stem in one launch: Conv2d(1 -> 64, 7x7, stride 2, pad 3; the three identical input channels of
 // x.repeat(1,3,1,1) are folded into the weights) + GroupNorm(4 groups of 16 channels) + ReLU + MaxPool(3, 2, 1)
 // (local_map_encoder.py:101-122 through torchvision's resnet18 stem).  One 256-thread work-group per sample:

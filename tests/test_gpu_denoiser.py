@@ -212,3 +212,27 @@ def test_raw_network_evaluation_and_diffusion_loop(ctx, oracle_net, inputs, prec
     assert a.shape == (B, 64, 2) and a.dtype == np.float64 and np.isfinite(a).all()
     with pytest.raises(ValueError):
         DiffusionSampler(net, None, "carmaze", policy="diffusion", pred_horizon=64, action_dim=2)
+
+
+@pytest.mark.parametrize("size,dims", [("small", (64, 128, 256)), ("medium", (256, 512, 1024)), ("xlarge", (1024, 2048, 4096))])
+@pytest.mark.parametrize("prec,tol", [(1, 1e-4), (0, 4e-2)])
+def test_other_denoiser_sizes(ctx, inputs, size, dims, prec, tol):
+    """The reference's `denoiser_size` small / medium / xlarge (run_scenarios.py:92-97): channel counts whose GroupNorm groups do
+    not fit the fused 256-channel epilogue run conv + bias in the GEMM and GroupNorm / Mish / FiLM / residual in
+    gn1d_kernel; one flow step and the actions against the oracle network of the same size."""
+    from ditreeonlineplanner_amd.model import NoisePredNet
+    noise, lm, cond = inputs
+    B = 8
+    torch.manual_seed(3)
+    onet = OD.init_noise_pred_net(down_dims=dims).eval()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, p in onet.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.2 * torch.randn(p.shape, generator=g))
+    net = NoisePredNet(down_dims=dims)
+    net.load_state_dict(onet.state_dict())
+    net.bind(ctx, precision=prec, max_batch=B)
+    x_ref = OS.flow_sample(onet, noise[:B], lm[:B], cond[:B], k_steps=1)
+    x = ctx.denoise(noise[:B].cuda().contiguous(), lm[:B].cuda().contiguous(), cond[:B].cuda().contiguous(), want_actions=False)
+    assert rel(x.cpu().numpy(), x_ref) < tol, (size, prec, rel(x.cpu().numpy(), x_ref))
