@@ -153,6 +153,22 @@ def test_denoiser_batch_1024_rows_independent(ctx):
         assert torch.equal(part, full[lo:lo + 16])
 
 
+@pytest.mark.parametrize("B", [1000, 513, 100, 31])
+def test_denoiser_ragged_batches_equal_full_batch_rows(ctx, B):
+    """Partially filled GEMM tiles, ragged encoder tiles and padded sample rows: the first B rows of a ragged batch are
+    bit-identical to the same rows of the 1024-candidate batch (what early-exit compaction relies on)."""
+    from ditreeonlineplanner_amd.model import NoisePredNet
+    net = NoisePredNet(seed=3)
+    net.bind(ctx, precision=0, max_batch=1024)
+    g = torch.Generator().manual_seed(9)
+    noise = torch.randn(1024, 64, 2, generator=g).cuda()
+    lm = (torch.rand(1024, 20, 20, generator=g) > 0.7).float().cuda() * 2 - 1
+    cond = (torch.randn(1024, 7, generator=g) * 0.5).cuda()
+    full = ctx.denoise(noise, lm, cond, want_actions=False)
+    part = ctx.denoise(noise[:B].contiguous(), lm[:B].contiguous(), cond[:B].contiguous(), want_actions=False)
+    assert torch.isfinite(part).all() and torch.equal(part, full[:B])
+
+
 def test_early_exit_round_is_bit_identical(ctx):
     """Compacting the alive candidates after every chunk (the reference abandons a collided edge,
     RRT.py:179-184) must not change any result: denoiser rows are independent of the batch composition."""
