@@ -777,7 +777,7 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
     for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(v[j]);
     *(short8_t*)((char*)p.Out + oidx * 2) = o;
   };
-  if (p.mode < MODE_GN_MISH) {                                // plain store (not used by the U-Net's k=3 convs)
+  if (p.mode < MODE_GN_MISH) {                                // plain store: bf16 activations, or f32 (the FiLM table)
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -785,7 +785,15 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = acc[mb][j][i];
-        store_row(mb, i, v);
+        if (p.out_f32) {
+          const int b = blk_b[mb], l = blk_l[mb] + 4 * h4 + i;
+          const long long orow = (long long)b * p.out_Lp + (long long)l * p.out_stride + p.out_off;
+          float* o = (float*)p.Out + orow * p.ldc + p.out_coff + n0;
+          *(f32x4_t*)o = f32x4_t{v[0], v[1], v[2], v[3]};
+          *(f32x4_t*)(o + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+        } else {
+          store_row(mb, i, v);
+        }
       }
     return;
   }
@@ -1220,6 +1228,168 @@ bool conv2d_small_eligible(int prec) {
   return on && prec == 0;
 }
 
+// =================================================================================================
+// gemm16_kernel: the other dense bf16 layers of the U-Net on the halo kernel's machinery -- stride-2 down
+// convs, the two 2-tap halves of a transposed conv, 1x1 residual convs, the first conv (K padded to 64) and the
+// batched FiLM linears.  Same tile, wave and fragment geometry, 16x16x32 MFMAs in snake order, four 16-MFMA phases per
+// K-step with the next phase's ds_reads issued first, epilogue16; what differs is the K walk: K-step k = (tap k / nc,
+// 64-channel chunk k % nc) stages BOTH a 256-row activation tile and a 256-row weight tile (2 x 32 KB each,
+// double-buffered), two K-steps in flight, one barrier per K-step with a plain vmcnt(0).
+//   Activation row of tile row m = (b, l):  b*in_Lp + l*in_stride + in_off + tap.  An 8-row staging piece never leaves
+//   a sample (8 | L), so its source offset is wave-uniform + 8 lane-dependent rows: two lane offsets (the XOR swizzle
+//   depends on the piece parity) + scalar offsets, as for the weights.
+// =================================================================================================
+__global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BUF = 32768, W_BASE = 2 * BUF;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r4 = lane & 15, h4 = lane >> 4;
+  const int wm = w >> 1, wn = w & 1;
+  const int ntn = p.N >> 8, ntm = p.M >> 8;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int tm = tile / ntn, tn = tile - tm * ntn;
+  const int nc = p.Cin >> 6, nk = p.taps * nc;
+  const long long K = (long long)p.taps * p.Cin;
+
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.W + ((long long)tn * 256) * K * 2), 0, 0x7fffffff, 0x00020000);
+  unsigned pae, pao, pbe, pbo;
+  int aq[4], wq[4];
+  {
+    const int lr = lane >> 3;
+    const int slot0 = (lane & 7) ^ (lr >> 1), slot1 = slot0 ^ 4;     // piece parity 0 / 1: (r >> 1) & 7 = (lr >> 1) (+ 4)
+    pae = (unsigned)((lr * p.in_stride * p.lda + slot0 * 8) * 2);
+    pao = (unsigned)((lr * p.in_stride * p.lda + slot1 * 8) * 2);
+    pbe = (unsigned)(((long long)(8 * lr) * K + slot0 * 8) * 2);
+    pbo = (unsigned)(((long long)(8 * lr) * K + slot1 * 8) * 2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r0 = (w * 4 + q) * 8;                                // tile row of the piece's first lane row
+      const int m = tm * 256 + r0;
+      const int b = m / p.L, l = m - b * p.L;
+      aq[q] = (int)((((long long)b * p.in_Lp + (long long)l * p.in_stride + p.in_off) * p.lda) * 2);
+      const int cu = (r0 & 128) + 8 * (r0 & 8) + ((r0 >> 4) & 7);    // W: LDS row wn*128 + j*16 + r4 <- channel wn*128 + 8*r4 + j
+      wq[q] = (int)((long long)cu * K * 2);
+    }
+  }
+  const int tap_bytes = p.lda * 2;                                   // one activation row further per tap
+  auto issue = [&](int k) {                                          // K-step k -> buffers k & 1
+    const int t = k / nc, c = k - t * nc;
+    char* ab = smem + (k & 1) * BUF;
+    char* wb = smem + W_BASE + (k & 1) * BUF;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (LDS_AS void*)(ab + (w * 4 + q) * 1024), 16, (q & 1) ? pao : pae,
+                                               aq[q] + t * tap_bytes + c * 128, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (LDS_AS void*)(wb + (w * 4 + q) * 1024), 16, (q & 1) ? pbo : pbe,
+                                               wq[q] + k * 128, 0, 0);
+  };
+
+  const int a_row = wm * 64 + r4;                                    // + 16 mb
+  const int swa = (a_row >> 1) & 7;                                  // (a_row + 16 mb) >> 1 & 7 is the same for every mb
+  const int a_off = a_row * 128, b_off = (wn * 128 + r4) * 128;
+  const int swb = (r4 >> 1) & 7;
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[mb][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t af[2][4], bq[2][4];
+  auto rdA = [&](int set, int k, int ks) {
+    const char* ab = smem + (k & 1) * BUF + a_off + ((((ks << 2) | h4) ^ swa) << 4);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) af[set][mb] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(ab + mb * 2048));
+  };
+  auto rdB = [&](int set, int k, int ks, int half) {
+    const char* wb = smem + W_BASE + (k & 1) * BUF + b_off + half * 8192 + ((((ks << 2) | h4) ^ swb) << 4);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) bq[set][jj] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(wb + jj * 2048));
+  };
+  auto mm = [&](int aset, int bset, int half, int mb, int jj) {
+    acc[mb][half * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[aset][mb], bq[bset][jj], acc[mb][half * 4 + jj], 0, 0, 0);
+  };
+  auto mm16 = [&](int aset, int bset, int half) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) mm(aset, bset, half, mb, (mb & 1) ? 3 - jj : jj);
+  };
+  // One K-step.  On entry af[0] = A(ks 0), bq[0] = B(ks 0, half 0) of step k.
+  auto step = [&](auto tNext, auto tIssue, int k) {
+    constexpr bool HAS_NEXT = decltype(tNext)::value, ISSUE = decltype(tIssue)::value;
+    rdB(1, k, 0, 1);                    // phase (0,0)
+    mm16(0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    rdA(1, k, 1);                       // phase (0,1)
+    rdB(0, k, 1, 0);
+    mm16(0, 1, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    rdB(1, k, 1, 1);                    // phase (1,0)
+    mm16(1, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (HAS_NEXT) {
+      // stage k+1 (requested one K-step ago) has landed; every wave is done reading stage k
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      rdA(0, k + 1, 0);
+      rdB(0, k + 1, 0, 0);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)      // phase (1,1) + the 8 LDS-DMA pieces of step k+2 into the buffers just released
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        mm(1, 1, 1, mb, (mb & 1) ? 3 - jj : jj);
+        if constexpr (ISSUE) {
+          const int i = mb * 4 + jj, t2 = (k + 2) / nc, c2 = (k + 2) - t2 * nc;
+          if (i < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (LDS_AS void*)(smem + (k & 1) * BUF + (w * 4 + i) * 1024), 16,
+                                                     (i & 1) ? pao : pae, aq[i] + t2 * tap_bytes + c2 * 128, 0, 0);
+          else if (i < 8)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (LDS_AS void*)(smem + W_BASE + (k & 1) * BUF + (w * 4 + i - 4) * 1024),
+                                                     16, ((i - 4) & 1) ? pbo : pbe, wq[i - 4] + (k + 2) * 128, 0, 0);
+        }
+      }
+    if constexpr (HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+      if (ISSUE && i < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using Tt = std::true_type;
+  using Ff = std::false_type;
+
+  issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (nk > 1) issue(1);
+  rdA(0, 0, 0);
+  rdB(0, 0, 0, 0);
+  for (int k = 0; k < nk - 2; ++k) step(Tt{}, Tt{}, k);
+  if (nk >= 2) step(Tt{}, Ff{}, nk - 2);
+  step(Ff{}, Ff{}, nk - 1);
+  __syncthreads();
+  gemm_epilogue16(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
+}
+static bool gemm16_eligible(const ConvGemmParams& p, int prec) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("DITREE_GEMM16"); on = (e && !atoi(e)) ? 0 : 1; }
+  return on && prec == 0 && !p.c2d && (!p.out_f32 || p.mode == MODE_BIAS) && p.taps >= 1 && p.taps <= 3 && (p.M & 255) == 0 && (p.N & 255) == 0 &&
+         (p.Cin & 63) == 0 && (p.L & 15) == 0 && p.M > 0 && (p.mode == MODE_BIAS || (256 % p.L) == 0);
+}
+
 static bool halo_eligible(const ConvGemmParams& p, int prec) {
   static int halo = -1;
   if (halo < 0) { const char* e = getenv("DITREE_NO_HALO"); halo = (e && atoi(e)) ? 0 : 1; }
@@ -1266,6 +1436,15 @@ void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s) {
     else if (dbg == 2) hipLaunchKernelGGL(conv3_halo_kernel<2>, grid, block, 147456, s, p);
     else if (dbg == 3) hipLaunchKernelGGL(conv3_halo_kernel<3>, grid, block, 147456, s, p);
     else hipLaunchKernelGGL(conv3_halo_kernel<0>, grid, block, 147456, s, p);
+    return;
+  }
+  if (!halo_ok && gemm16_eligible(p, prec)) {
+    static bool attr4 = false;
+    if (!attr4) {
+      hipFuncSetAttribute((const void*)gemm16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      attr4 = true;
+    }
+    hipLaunchKernelGGL(gemm16_kernel, grid, block, 131072, s, p);
     return;
   }
   if (p.c2d && conv2d_small_eligible(prec) && (p.N & 63) == 0 && (p.Cin & 63) == 0 && p.out_f32 && p.mode == MODE_BIAS) {
