@@ -241,7 +241,7 @@ int32_t ditree_denoise_eval(ditree_ctx* ctx, const float* sample, const float* l
  * stream (back-to-back launches share an event; ~120 marker packets per denoiser call, which costs a timed
  * region ~6 %); enable = 2: only the dominant kernel, one event pair around each run of back-to-back halo
  * launches (~20 packets per call); 0: off.  ditree_profile_read waits for the events and returns, per kernel
- * kind k = 0 conv3_halo16_kernel, 1 conv_gemm_kernel, 2 conv2d_small_kernel: summed kernel time ms3[k],
+ * kind k = 0 conv3_halo16_kernel, 1 gemm16_kernel / conv_gemm_kernel, 2 conv2d_small_kernel: summed kernel time ms3[k],
  * launches3[k] and executed FLOPs flops3[k] (2*M*N*K of every launch) since the last enable. */
 int32_t ditree_profile(ditree_ctx* ctx, int32_t enable);
 int32_t ditree_profile_read(ditree_ctx* ctx, double* ms3, int64_t* launches3, double* flops3);

@@ -32,7 +32,7 @@ def counter_rows(path, counter):
 
 
 def short(name):
-    for k in ("conv3_halo16_kernel", "conv3_halo_kernel", "conv_gemm_kernel<0, 0, true>", "conv_gemm_kernel<0, 0, false>", "gn2d_kernel",
+    for k in ("conv3_halo16_kernel", "conv3_halo_kernel", "gemm16_kernel", "conv_gemm_kernel<0, 0, true>", "conv_gemm_kernel<0, 0, false>", "gn2d_kernel",
               "final_proj_flow_kernel", "car_rollout_kernel", "im2col2d_kernel", "maxpool2d_kernel"):
         if k in name:
             return k
