@@ -892,6 +892,12 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
   }
 }
 
+#ifdef HALO16_STAMP   // diagnostic build only: in-kernel clock of the K loop (MI355X_MICROARCH.md, DVFS give-back (6))
+__device__ unsigned long long g_halo_stamp[8];
+extern "C" int ditree_debug_halo_stamp(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_stamp), sizeof(g_halo_stamp));
+}
+#endif
 template <bool SNAKE>
 __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1075,11 +1081,21 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
   rdA(0, 0, 0, 0);
   rdB(0, 0, 0, 0, 0);
 
+#ifdef HALO16_STAMP
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int c = 0; c < nc - 2; ++c) {
     step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, c);          // waits W(c,1); A(c+1) may stay in flight
     step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, c);
     step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, c);          // stages W(c+1,1) then A(c+2)
   }
+#ifdef HALO16_STAMP
+  if (blockIdx.x == 100 && tid == 0 && nc >= 32) {
+    g_halo_stamp[0] = __builtin_amdgcn_s_memtime() - st0;
+    g_halo_stamp[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    g_halo_stamp[2] = (unsigned long long)(nc - 2) * 3;
+  }
+#endif
   // The counted wait (vmcnt(5)) is only used inside the loop above, whose body holds no other vector-memory
   // operation.  The two tail chunks wait for everything: register spills the compiler may place here (scratch
   // accesses count in vmcnt) must not take part in a counted wait.
