@@ -1048,15 +1048,20 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
       for (int jj = 0; jj < 4; ++jj) {
         mm(1, 1, 1, mb, SNAKE ? ((mb & 1) ? 3 - jj : jj) : jj);
         const int i = mb * 4 + jj;
-        if constexpr (ISSUE_W) { if (i < 4) issue_w(c2, T2, i); }
-        if constexpr (ISSUE_A) { if (i >= 4 && i < 9) issue_a(c + 2, i - 4); }
+        // An LDS-DMA issue holds the wave's instruction stream for 60-180 cycles and both waves of a SIMD run this
+        // phase together: one issue behind every second MFMA (the ninth behind the last) instead of nine in a row
+        // leaves the partner wave MFMAs to issue in between (-1.7 % kernel time).
+        const int d = (i & 1) ? -1 : (i >> 1);
+        if constexpr (ISSUE_W) { if (d >= 0 && d < 4) issue_w(c2, T2, d); }
+        if constexpr (ISSUE_A) { if (d >= 4 && d < 8) issue_a(c + 2, d - 4); if (i == 15) issue_a(c + 2, 4); }
       }
     if constexpr (HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);
     constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? 5 : 0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-      if (i < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+      if (!(i & 1) && (i >> 1) < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+      if (i == 15 && NV == 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -1367,11 +1372,12 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
       for (int jj = 0; jj < 4; ++jj) {
         mm(1, 1, 1, mb, (mb & 1) ? 3 - jj : jj);
         if constexpr (ISSUE) {
-          const int i = mb * 4 + jj, t2 = (k + 2) / nc, c2 = (k + 2) - t2 * nc;
-          if (i < 4)
+          // one LDS-DMA issue behind every second MFMA (see conv3_halo16_kernel)
+          const int m = mb * 4 + jj, i = (m & 1) ? -1 : (m >> 1), t2 = (k + 2) / nc, c2 = (k + 2) - t2 * nc;
+          if (i >= 0 && i < 4)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (LDS_AS void*)(smem + (k & 1) * BUF + (w * 4 + i) * 1024), 16,
                                                      (i & 1) ? pao : pae, aq[i] + t2 * tap_bytes + c2 * 128, 0, 0);
-          else if (i < 8)
+          else if (i >= 4 && i < 8)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (LDS_AS void*)(smem + W_BASE + (k & 1) * BUF + (w * 4 + i - 4) * 1024),
                                                      16, ((i - 4) & 1) ? pbo : pbe, wq[i - 4] + (k + 2) * 128, 0, 0);
         }
@@ -1380,7 +1386,7 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-      if (ISSUE && i < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+      if (ISSUE && !(i & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
