@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="candidates per GPU per round")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"], help="denoiser instantiation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch event timing")
     ap.add_argument("--no-early-exit-line", action="store_true",
@@ -158,7 +159,7 @@ def main():
     nodes, goal, samples, cond, noise = synth_inputs(maze, Btot)
     ctx = Context(local)
     net = NoisePredNet(seed=0)
-    net.bind(ctx, precision=_lib.PREC_BF16, max_batch=Bper)
+    net.bind(ctx, precision={'bf16': _lib.PREC_BF16, 'f32': _lib.PREC_F32}[args.precision], max_batch=Bper)
     eng = ExpansionEngine(ctx, maze, nodes[0], goal, edge_length=H, action_horizon=A, pred_horizon=P, batch=Btot,
                           capacity=N0 + Btot, rank=rank, world_size=world, emulate_sticky_done=False)
     eng.force_allgather = force_dist
@@ -252,7 +253,7 @@ def main():
             "metric": "candidate tree-expansions/sec (carmaze, H=32)", "value": value,
             "unit": "candidate expansions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic" + (" (one-GPU rehearsal of N ranks over gloo: not a measurement)" if rehearse else ""),
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic" + (" (one-GPU rehearsal of N ranks over gloo: not a measurement)" if rehearse else ""),
             "config": {"workload": f"cfgs/carmaze.yaml + fm_policy flow sampler (K=1), batch={Bper} candidates per GPU, "
                                    f"H=32 (4 chunks x 8 steps), boxes.csv 20x20, {N0}-node tree snapshot, seeded random weights",
                        "batch_per_gpu": Bper, "global_batch": Btot, "edge_length": H, "action_horizon": A,
@@ -263,8 +264,9 @@ def main():
             name = max(prof, key=lambda k: prof[k]["ms"])
             d = prof[name]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12            # executed == algorithmic for this kernel (no padding)
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_BF16_TFLOPS, **pmc_traffic(name), "kernel": name,
+            peak = 157.3 if args.precision == "f32" else PEAK_BF16_TFLOPS
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, **pmc_traffic(name), "kernel": name,
                                "launches": d["launches"], "avg_launch_ms": d["ms"] / max(1, d["launches"]),
                                "algorithmic_gflop_per_launch": d["flops"] / max(1, d["launches"]) / 1e9,
                                "kernel_time_share": d["ms"] * 1e-3 / elapsed}

@@ -109,7 +109,8 @@ struct DenoiserState {
     if (prof_mode == 2) {
       // dominant kernel only: one (start, end) pair around each run of back-to-back halo launches, so the timed
       // region carries ~20 marker packets per denoiser call instead of ~120
-      if (conv_gemm_kind(p, prec) != 0) { close_run(); launch_conv_gemm(p, prec, s); return; }
+      const int dom = prec == 1 ? 1 : 0;                     // f32 instantiation: everything runs on conv_gemm_kernel
+      if (conv_gemm_kind(p, prec) != dom) { close_run(); launch_conv_gemm(p, prec, s); return; }
       if (run_open && prof_last_stream == s) {
         launch_conv_gemm(p, prec, s);
         prof_pairs.back().flops += fl;
@@ -121,7 +122,7 @@ struct DenoiserState {
       run_end = prof_used++;
       hipEventRecord(prof_ev[st], s);
       launch_conv_gemm(p, prec, s);
-      prof_pairs.push_back(ProfRec{st, run_end, 0, fl, 1});
+      prof_pairs.push_back(ProfRec{st, run_end, dom, fl, 1});
       run_open = true;
       prof_last_stream = s;
       return;

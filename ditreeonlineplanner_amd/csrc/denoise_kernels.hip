@@ -10,7 +10,7 @@
 //    into LDS with `global_load_lds` (16 B per lane) and per-lane source addresses;
 //  * GEMM orientation: M = positions (B*L), N = output channels, K = taps*C_in;
 //    256 x 256 x (128 bytes of K) tiles, 8 waves as 4(M) x 2(N), each wave 64 x 128 with
-//    v_mfma_f32_32x32x16_bf16 (PREC 0) or v_mfma_f32_32x32x2_f32 (PREC 1, parity path);
+//    v_mfma_f32_32x32x16_bf16 / _f16 (PREC 0 / 2) or v_mfma_f32_32x32x2_f32 (PREC 1, parity path);
 //  * LDS rows are 128 B; the 16-B slot index is XOR-swizzled with (row>>1)&7 on the
 //    *source* address and on the ds_read_b128 address (conflict-free fragment reads);
 //  * the weight rows of a tile are permuted in LDS so that lane r of a wave owns output
@@ -25,6 +25,7 @@
 #include "denoise.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
 typedef __attribute__((ext_vector_type(8))) short short8_t;
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -40,6 +41,33 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 __device__ __forceinline__ float bf2f(unsigned short u) {
   unsigned int x = ((unsigned int)u) << 16;
   return __builtin_bit_cast(float, x);
+}
+__device__ __forceinline__ unsigned short f2h(float f) {
+  // f16 has no headroom above 65504: saturate instead of producing inf (a NaN stays a NaN through v_med3)
+  _Float16 b = (_Float16)__builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f);
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float h2f(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
+
+// 16-bit element types of the MFMA operands.  ET 0: bf16 (8 significand bits, f32 range), ET 1: f16 (11 bits, +-65504).
+// SPLIT instantiations carry every operand as two 16-bit planes hi + lo (lo = rnd(x - hi)) and form a product from
+// three MFMAs hi*hi + hi*lo + lo*hi with f32 accumulation: 16 (bf16) / 22 (f16) significand bits per operand at a
+// third of the 16-bit MFMA rate -- the f32-input MFMA runs at a sixteenth of it (MI355X_MICROARCH.md, Matrix cores).
+template <int ET> __device__ __forceinline__ unsigned short f2e(float f) { if constexpr (ET == 0) return f2bf(f); else return f2h(f); }
+template <int ET> __device__ __forceinline__ float e2f(unsigned short u) { if constexpr (ET == 0) return bf2f(u); else return h2f(u); }
+template <int ET>
+__device__ __forceinline__ f32x4_t mfma16(const short8_t& a, const short8_t& b, const f32x4_t& c) {
+  if constexpr (ET == 0)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+}
+template <int ET>
+__device__ __forceinline__ f32x16_t mfma32(const short8_t& a, const short8_t& b, const f32x16_t& c) {
+  if constexpr (ET == 0)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
 }
 
 template <int PREC>
@@ -70,12 +98,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // ---- shared epilogue: bias, GroupNorm + Mish (+ FiLM | + residual), store ------------------------
 // acc[mb][j][i] of lane (r5, h), wave (wm, wn) holds tile row wm*64 + mb*32 + (i&3) + 8*(i>>2) + 4*h,
 // tile channel wn*128 + 4*r5 + j.  `smem` must be free for reuse (callers barrier first).
+// PREC 0: bf16 storage, 1: f32 (parity instantiation, two-pass statistics, exact Mish), 2: f16 storage.
 template <int PREC>
 __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t (&acc)[2][4], char* smem, int tm, int tn,
                                               int tid, int lane, int r5, int h, int wm, int wn,
                                               long long out_extra_bytes = 0) {
 
-  // ---- epilogue ---------------------------------------------------------------------------
+  constexpr int ET = PREC == 2 ? 1 : 0;
   const int c_l = wn * 128 + 4 * r5;                          // lane's 4 consecutive channels in the tile
   const int n0 = tn * 256 + c_l;
   const bool n_ok = n0 < p.N;
@@ -90,7 +119,10 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mb][j][i] += bias4[j];
+      for (int i = 0; i < 16; ++i) {
+        if constexpr (PREC == 2) acc[mb][j][i] = fmaf(acc[mb][j][i], p.w_scale, bias4[j]);   // f16 weights are stored scaled
+        else acc[mb][j][i] += bias4[j];
+      }
 
   // 16-row blocks of this lane: blk = mb*2 + hf covers tile rows wm*64 + mb*32 + hf*16 .. +15
   int blk_b[4], blk_l[4];
@@ -128,7 +160,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
         dst[i] = *(const short4_t*)((const char*)p.Res + (rrow * p.ldres + n0) * 2);
       }
     };
-    const bool res_bf16 = (PREC == 0) && p.mode == MODE_GN_MISH_RES;
+    const bool res_bf16 = (PREC != 1) && p.mode == MODE_GN_MISH_RES;
     if (res_bf16) fetch_res(0, resv[0]);
     __syncthreads();
     const int spt = 256 / p.L;                                // sample slots per tile
@@ -139,7 +171,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
     for (int blk = 0; blk < 4; ++blk) slot[blk] = blk_b[blk] - tm * spt;
     const float inv_cnt = 1.0f / (float)(p.group_ch * p.L);
     float mean[4], rstd[4];
-    if constexpr (PREC == 0) {
+    if constexpr (PREC != 1) {
       // one pass: sum and sum of squares (f32), var = E[x^2] - mean^2
 #pragma unroll
       for (int blk = 0; blk < 4; ++blk) {
@@ -236,12 +268,12 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
         const int b = blk_b[blk], l = blk_l[blk] + rofs;
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = mish_f<PREC>(acc[blk >> 1][j][ii] * ga[j] + be[j]) * fs[j] + fb[j];
+        for (int j = 0; j < 4; ++j) v[j] = mish_f<PREC == 1 ? 1 : 0>(acc[blk >> 1][j][ii] * ga[j] + be[j]) * fs[j] + fb[j];
         if (p.mode == MODE_GN_MISH_RES) {
-          if constexpr (PREC == 0) {
+          if constexpr (PREC != 1) {
             const short4_t rv = resv[blk & 1][i];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += bf2f((unsigned short)rv[j]);
+            for (int j = 0; j < 4; ++j) v[j] += e2f<ET>((unsigned short)rv[j]);
           } else {
             const long long rrow = (long long)b * p.res_Lp + l + p.res_off;
             const f32x4_t rv = *(const f32x4_t*)((const char*)p.Res + (rrow * p.ldres + n0) * 4);
@@ -257,7 +289,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
         } else {
           short4_t o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (short)f2bf(v[j]);
+          for (int j = 0; j < 4; ++j) o[j] = (short)f2e<ET>(v[j]);
           *(short4_t*)((char*)p.Out + out_extra_bytes + oidx * 2) = o;
         }
       }
@@ -283,16 +315,17 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
       } else {
         short4_t o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (short)f2bf(acc[blk >> 1][j][ii]);
+        for (int j = 0; j < 4; ++j) o[j] = (short)f2e<ET>(acc[blk >> 1][j][ii]);
         *(short4_t*)((char*)p.Out + out_extra_bytes + oidx * 2) = o;
       }
     }
   }
 }
 
-template <int PREC, int DBG = 0, bool C2D = false>
+template <int PREC, bool C2D = false>
 __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
-  constexpr int ES = (PREC == 0) ? 2 : 4;          // element bytes
+  constexpr int ES = (PREC == 1) ? 4 : 2;          // element bytes
+  constexpr int ET = PREC == 2 ? 1 : 0;
   constexpr int EK = 128 / ES;                     // elements of K per step
   constexpr int EPS = 16 / ES;                     // elements per 16-B slot
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -419,16 +452,16 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
   // an MFMA it is hidden, in front of the first ds_read it is not).
   auto kstep = [&](const char* sb, auto stage_tag, char* snext) {
     constexpr bool STAGE = decltype(stage_tag)::value;
-    if constexpr (PREC == 0) {
-      bf16x8_t af[2][2], bfr[2][4];
+    if constexpr (PREC != 1) {
+      short8_t af[2][2], bfr[2][4];
       auto rd = [&](int ks, int slot) {
         const int ps = (((ks << 1) | h) ^ swl) << 4;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
-          af[slot][mb] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(sb + a_row_off + mb * 4096 + ps));
+          af[slot][mb] = *(const short8_t*)(sb + a_row_off + mb * 4096 + ps);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          bfr[slot][j] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(sb + b_row_off + j * 4096 + ps));
+          bfr[slot][j] = *(const short8_t*)(sb + b_row_off + j * 4096 + ps);
       };
       if constexpr (STAGE) {
 #pragma unroll
@@ -442,7 +475,7 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][mb], bfr[ks & 1][j], acc[mb][j], 0, 0, 0);
+            acc[mb][j] = mfma32<ET>(af[ks & 1][mb], bfr[ks & 1][j], acc[mb][j]);
       }
       // pin the order: the next tile's LDS-DMA first (it has the whole step to land), then for every
       // sub-step the reads of the following one ahead of its own 8 MFMAs (true fragment double buffering;
@@ -486,11 +519,7 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
   for (int kt = 0; kt < nk - 1; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if constexpr (DBG == 1) kstep(smem + (kt & 1) * 65536, std::false_type{}, nullptr);
-    else if constexpr (DBG == 2) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) stage_piece(q, smem + ((kt + 1) & 1) * 65536);
-    } else kstep(smem + (kt & 1) * 65536, std::true_type{}, smem + ((kt + 1) & 1) * 65536);
+    kstep(smem + (kt & 1) * 65536, std::true_type{}, smem + ((kt + 1) & 1) * 65536);
     advance();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -498,239 +527,6 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
   kstep(smem + ((nk - 1) & 1) * 65536, std::false_type{}, nullptr);
   __syncthreads();                                            // all fragment reads done: LDS reusable
   gemm_epilogue<PREC>(p, acc, smem, tm, tn, tid, lane, r5, h, wm, wn, out_extra);
-}
-
-// =================================================================================================
-// conv3_halo_kernel: Conv1d(k = 3, stride 1, pad 1) on padded channels-last bf16 activations.
-//
-// Same tile / wave / epilogue geometry as conv_gemm_kernel, different K loop: K is walked
-// channel-chunk major, tap minor.  For one 64-channel chunk the activation block of the tile --
-// (256/L) samples x (L+2) padded rows, i.e. the 256 output rows plus their halos -- is staged
-// into LDS ONCE and serves all three taps (the tap only shifts the fragment row), so every
-// activation byte crosses L2->LDS once per tile instead of three times; only the weights are
-// re-staged per tap.  Per chunk: 36 KB (A) + 96 KB (W) instead of 192 KB.
-//   LDS: A[2] x 40 KB (40 one-KiB pieces, 5 per wave, rows beyond the block clamp) + W[2] x 32 KB.
-//   Pipeline: fragments are read one 16-wide sub-step ahead, also across K-steps; the single
-//   barrier of a K-step sits between its third and fourth MFMA group, where 8 MFMAs are queued;
-//   W(s+2) is issued right after the barrier of step s, A(c+2) after the last barrier of chunk c,
-//   waited with a counted vmcnt (activations stay in flight for three K-steps).
-// =================================================================================================
-template <int DBG>
-__global__ void __launch_bounds__(512, 2) conv3_halo_kernel(ConvGemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int A_BUF = 40960, W_BUF = 32768, W_BASE = 2 * A_BUF;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int r5 = lane & 31, h = lane >> 5;
-  const int wm = w >> 1, wn = w & 1;
-  const int ntn = (p.N + 255) >> 8;
-  const int ntm = (p.M + 255) >> 8;
-  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
-  const int tm = tile / ntn, tn = tile - tm * ntn;
-  const int L = p.L, Lp = p.in_Lp, S = 256 / L;
-  const int a_rows = S * Lp;
-  const int nc = p.Cin >> 6;
-  const long long K = 3LL * p.Cin;
-
-  // ---- staging sources: buffer addressing -- a wave-uniform descriptor per operand (SGPRs), a 32-bit
-  // per-lane byte offset (9 VGPRs in all) and a wave-uniform scalar offset per K-step; no 64-bit
-  // vector pointers are kept live across the loop
-  unsigned pa[5], pb[4];
-  const char* const a_base = (const char*)p.A + ((long long)tm * S * Lp + p.in_off) * p.lda * 2;
-  const char* const w_base = (const char*)p.W + ((long long)tn * 256) * K * 2;
-  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int r = (w + 8 * i) * 8 + (lane >> 3);                     // LDS row of the A block
-    const int rs = r < a_rows ? r : a_rows - 1;
-    const int slot = (lane & 7) ^ ((r >> 1) & 7);
-    pa[i] = (unsigned)((rs * p.lda + slot * 8) * 2);
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int r = (w * 4 + q) * 8 + (lane >> 3);
-    const int slot = (lane & 7) ^ ((r >> 1) & 7);
-    const int c = (r & 128) + 4 * (r & 31) + ((r >> 5) & 3);
-    pb[q] = (unsigned)(((long long)c * K + slot * 8) * 2);
-  }
-  const int w_tap = p.Cin * 2;                                       // bytes between taps in a weight row
-  auto issue_a = [&](int c, int i) {                                 // piece i of chunk c
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (LDS_AS void*)(smem + (c & 1) * A_BUF + (w + 8 * i) * 1024), 16,
-                                             pa[i], c * 128, 0, 0);
-  };
-  auto issue_w = [&](int c, int t, int q) {                          // piece q of step (c, t)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (LDS_AS void*)(smem + W_BASE + ((c + t) & 1) * W_BUF + (w * 4 + q) * 1024),
-                                             16, pb[q], c * 128 + t * w_tap, 0, 0);
-  };
-
-  // ---- fragment addressing ---------------------------------------------------------------------
-  int lrow[2];
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const int ml = wm * 64 + mb * 32 + r5;
-    const int sb = ml / L;
-    lrow[mb] = sb * Lp + (ml - sb * L);                              // + tap
-  }
-  const int swl = (r5 >> 1) & 7;
-  const int b_row_off = (wn * 128 + r5) * 128;
-
-  f32x16_t acc[2][4];
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mb][j][i] = 0.0f;
-
-  bf16x8_t af[2][2], bfr[2][4];
-  auto rd = [&](int set, int c, int t, int ks) {
-    const char* ab = smem + (c & 1) * A_BUF;
-    const char* wb = smem + W_BASE + ((c + t) & 1) * W_BUF;
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      const int row = lrow[mb] + t;
-      const int ps = (((ks << 1) | h) ^ ((row >> 1) & 7)) << 4;
-      af[set][mb] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(ab + row * 128 + ps));
-    }
-    const int psb = (((ks << 1) | h) ^ swl) << 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      bfr[set][j] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(wb + b_row_off + j * 4096 + psb));
-  };
-  // DBG == 3 (timing experiment only, results are garbage): the same loop with two 16x16x32 MFMAs in place of
-  // each 32x32x16 (equal FLOPs, cycles and LDS bytes) to see which shape holds the higher clock in situ
-  f32x4_t acc16[2][4][4];
-  if constexpr (DBG == 3) {
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc16[mb][j][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  }
-  int flip = 0;
-  auto mm = [&](int set, int mb, int j) {
-    if constexpr (DBG == 3) {
-      acc16[mb][j][flip] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[set][mb], bfr[set][j], acc16[mb][j][flip], 0, 0, 0);
-      acc16[mb][j][flip + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[set][mb], bfr[set][j], acc16[mb][j][flip + 1], 0, 0, 0);
-    } else {
-      acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[set][mb], bfr[set][j], acc[mb][j], 0, 0, 0);
-    }
-  };
-  constexpr int MF = DBG == 3 ? 2 : 1;
-  auto mm8 = [&](int set) {
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) mm(set, mb, j);
-  };
-
-  // One K-step (chunk c, tap T).  HAS_NEXT: another step follows (barrier + read-ahead);
-  // ISSUE_W: stage W of step s+2; ISSUE_A: stage A of chunk c+2; VM: LDS-DMA pieces that may
-  // stay in flight across this step's barrier (the A pieces issued after the W pieces it waits for).
-  auto step = [&](auto tT, auto tNext, auto tIW, auto tIA, auto tVM, int c) {
-    constexpr int T = decltype(tT)::value;
-    constexpr bool HAS_NEXT = decltype(tNext)::value, ISSUE_W = decltype(tIW)::value, ISSUE_A = decltype(tIA)::value;
-    constexpr int VM = decltype(tVM)::value;
-    // keep the fragment-address arithmetic inside the step (hoisted out of the chunk loop it
-    // costs ~30 VGPRs of precomputed addresses and spills)
-    asm volatile("" : "+v"(lrow[0]), "+v"(lrow[1]));
-    if constexpr (DBG != 2) {
-      rd(1, c, T, 1);
-      mm8(0);
-      rd(0, c, T, 2);
-      mm8(1);
-      rd(1, c, T, 3);
-      mm8(0);
-    }
-    // Pin the issue order the pipeline is built on (hipcc otherwise sinks every fragment read behind the
-    // MFMAs that free its registers and then waits for LDS in front of each MFMA group):
-    // ks0..ks2: the 6 reads of the next sub-step first, then the 8 MFMAs of the current one.
-    if constexpr (DBG == 0 || DBG == 3) {
-#pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 8 * MF, 0);
-      }
-    }
-    if constexpr (HAS_NEXT) {
-      // this wave's reads of W(s) / A(c) are complete, the DMA of step s+1 has landed
-      if constexpr (VM == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      constexpr int T1 = (T + 1) % 3;
-      if constexpr (DBG != 2) rd(0, c + (T + 1) / 3, T1, 0);
-    }
-    constexpr int T2 = (T + 2) % 3;
-    const int c2 = c + (T + 2) / 3;
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if constexpr (DBG != 2) mm(1, mb, j);
-        const int i = mb * 4 + j;
-        if constexpr (ISSUE_W && DBG != 1) { if (i < 4) issue_w(c2, T2, i); }
-        if constexpr (ISSUE_A && DBG != 1) { if (i >= 3) issue_a(c + 2, i - 3); }
-      }
-    // after the barrier: the 6 reads of the next K-step first, then MFMA : LDS-DMA interleaved
-    if constexpr (DBG == 0 || DBG == 3) {
-      if constexpr (HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 6, 1);
-      constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? 5 : 0);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, MF, 1);
-        if (i < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
-      }
-      if constexpr (NV > 8) __builtin_amdgcn_sched_group_barrier(0x020, NV - 8, 1);
-    }
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  using I5 = std::integral_constant<int, 5>;
-  using Tt = std::true_type;
-  using Ff = std::false_type;
-
-  // ---- prologue: A(0), W(0,0) -> visible; then W(0,1) and A(1) in flight ----------------------------
-#pragma unroll
-  for (int i = 0; i < 5; ++i) issue_a(0, i);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) issue_w(0, 0, q);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) issue_w(0, 1, q);
-#pragma unroll
-  for (int i = 0; i < 5; ++i) issue_a(1, i);
-  rd(0, 0, 0, 0);
-
-  for (int c = 0; c < nc - 2; ++c) {
-    step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, c);          // waits W(c,1); A(c+1) may stay in flight
-    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, c);
-    step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, c);          // stages W(c+1,1) then A(c+2)
-  }
-  {
-    const int c = nc - 2;                           // last chunk but one: no A left to stage
-    step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, c);
-    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, c);
-    step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, c);
-  }
-  {
-    const int c = nc - 1;                           // last chunk
-    step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, c);
-    step(I1{}, Tt{}, Ff{}, Ff{}, I0{}, c);
-    step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, c);
-  }
-  if constexpr (DBG == 3) {
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[mb][j][i] = acc16[mb][j][i >> 2][i & 3];
-  }
-  __syncthreads();
-  gemm_epilogue<0>(p, acc, smem, tm, tn, tid, lane, r5, h, wm, wn);
 }
 
 // =================================================================================================
@@ -1117,25 +913,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
     step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, c);
   }
   __syncthreads();
-#ifdef HALO16_NO_EPILOGUE     // timing experiment: plain scaled bf16 store instead of GroupNorm / Mish / FiLM (data stays O(1))
-  {
-    const float sc = rsqrtf((float)K);
-    const int c_l = wn * 128 + 8 * r4, n0 = tn * 256 + c_l;
-    for (int mb = 0; mb < 4; ++mb) {
-      const int m0 = tm * 256 + wm * 64 + mb * 16;
-      const int b = m0 / p.L, l0 = m0 - b * p.L;
-      for (int i = 0; i < 4; ++i) {
-        const int l = l0 + 4 * h4 + i;
-        const long long orow = (long long)b * p.out_Lp + (long long)l * p.out_stride + p.out_off;
-        short8_t o;
-        for (int jx = 0; jx < 8; ++jx) o[jx] = (short)f2bf(acc[mb][jx][i] * sc);
-        *(short8_t*)((char*)p.Out + (orow * p.ldc + p.out_coff + n0) * 2) = o;
-      }
-    }
-  }
-#else
   gemm_epilogue16(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
-#endif
 }
 
 // =================================================================================================
