@@ -117,7 +117,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="candidates per GPU per round")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"], help="denoiser instantiation")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "f16x3", "bf16x3", "f16"],
+                    help="denoiser instantiation (include/ditree.h DITREE_PREC_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch event timing")
     ap.add_argument("--no-early-exit-line", action="store_true",
@@ -159,7 +160,7 @@ def main():
     nodes, goal, samples, cond, noise = synth_inputs(maze, Btot)
     ctx = Context(local)
     net = NoisePredNet(seed=0)
-    net.bind(ctx, precision={'bf16': _lib.PREC_BF16, 'f32': _lib.PREC_F32}[args.precision], max_batch=Bper)
+    net.bind(ctx, precision=_lib.PREC_NAMES[args.precision], max_batch=Bper)
     eng = ExpansionEngine(ctx, maze, nodes[0], goal, edge_length=H, action_horizon=A, pred_horizon=P, batch=Btot,
                           capacity=N0 + Btot, rank=rank, world_size=world, emulate_sticky_done=False)
     eng.force_allgather = force_dist
@@ -264,7 +265,9 @@ def main():
             name = max(prof, key=lambda k: prof[k]["ms"])
             d = prof[name]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12            # executed == algorithmic for this kernel (no padding)
-            peak = 157.3 if args.precision == "f32" else PEAK_BF16_TFLOPS
+            # governing MFMA roofline of the instantiation (MI355X_MICROARCH.md): 16-bit dense 2.5 PFLOP/s; the split
+            # instantiations issue 3 MFMAs per algorithmic product, so their ceiling in ALGORITHMIC FLOP/s is a third of it
+            peak = {"f32": 157.3, "f16x3": PEAK_BF16_TFLOPS / 3, "bf16x3": PEAK_BF16_TFLOPS / 3}.get(args.precision, PEAK_BF16_TFLOPS)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                "frac": ach / peak, **pmc_traffic(name), "kernel": name,
                                "launches": d["launches"], "avg_launch_ms": d["ms"] / max(1, d["launches"]),

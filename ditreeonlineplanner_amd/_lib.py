@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(HERE, "libditree_hip.so")
 
 ST_NOT_RUN, ST_OK, ST_GOAL, ST_COLLIDED = -1, 0, 1, 2
 ST_FLAG_GOAL_AT_COLLISION = 0x100
-PREC_BF16, PREC_F32 = 0, 1
+PREC_BF16, PREC_F32, PREC_F16X3, PREC_BF16X3, PREC_F16 = 0, 1, 2, 3, 4
+PREC_NAMES = {"bf16": PREC_BF16, "f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3, "f16": PREC_F16}
 
 
 class DitreeLibraryError(RuntimeError):
@@ -72,6 +73,7 @@ SIGNATURES = {
     "ditree_denoise_reserve": (_i32, [_vp, _i32, _i32]),
     "ditree_denoise": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _pf, _pf, _pd, _vp, _vp, _vp]),
     "ditree_denoise_eval": (_i32, [_vp, _vp, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp]),
+    "ditree_denoise_dims": (_i32, [_vp, C.POINTER(_i32)]),
     "ditree_profile": (_i32, [_vp, _i32]),
     "ditree_profile_read": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ditree_denoise_debug_read": (_i32, [_vp, C.c_char_p, _i32, _vp, _i64, C.POINTER(_i32), _vp]),

@@ -5,6 +5,15 @@
 
 enum { MODE_BIAS = 0, MODE_GN_MISH = 1, MODE_GN_MISH_FILM = 2, MODE_GN_MISH_RES = 3 };
 
+// Numeric format of an activation buffer / a GEMM: storage type | split << 2.
+//   storage: bf16, f32, f16.  split (16-bit storage only): the buffer holds two planes, hi = rnd16(x) and
+//   lo = rnd16(x - hi), `plane` bytes apart; a split GEMM forms hi*hi + hi*lo + lo*hi on the 16-bit MFMA pipeline.
+enum { ST_BF16 = 0, ST_F32 = 1, ST_F16 = 2 };
+static inline int fmt_make(int st, bool split) { return st | (split ? 4 : 0); }
+static inline __host__ __device__ int fmt_st(int f) { return f & 3; }
+static inline __host__ __device__ bool fmt_split(int f) { return (f & 4) != 0; }
+static inline int fmt_es(int f) { return fmt_st(f) == ST_F32 ? 4 : 2; }
+
 // One implicit-GEMM launch (see denoise_kernels.hip).  All counts are in elements of the
 // activation type (bf16 or f32); pointers are device pointers.
 struct ConvGemmParams {
@@ -39,36 +48,42 @@ struct ConvGemmParams {
   int c2d, c2_H, c2_W, c2_OW, c2_OHW, c2_stride, c2_pad;
   signed char c2_kh[12], c2_kw[12];
   const void* zero;
+  // split formats: bytes from the hi plane to the lo plane of each operand; f16 weights are stored multiplied by a power
+  // of two (the range of f16 is narrow) and `w_scale` = its reciprocal is applied to the accumulator
+  long long a_plane, w_plane, out_plane, res_plane;
+  float w_scale;
   // split-K (implicit Conv2d mode only): gridDim.y = splitk blocks share a tile, block y handles a
   // contiguous range of K-steps and writes its partial f32 tile to Out + y * slab_stride elements
   int splitk;
   long long slab_stride;
 };
 
-void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s);
-bool conv2d_small_eligible(int prec);                   // implicit Conv2d layers run on the 64 x 64-tile kernel (no split-K)
-int conv_gemm_kind(const ConvGemmParams& p, int prec);   // 0 halo kernel, 1 generic, 2 implicit Conv2d
-void launch_prep_sample(const float* x, void* A0, int B, int P, int D, int prec, hipStream_t s);
+void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s);
+bool conv2d_small_eligible(int fmt);                    // implicit Conv2d layers run on the 64 x 64-tile kernel
+int conv_gemm_kind(const ConvGemmParams& p, int fmt);   // 0 halo kernel, 1 gemm16 / generic, 2 implicit Conv2d
+bool conv_gemm_supported(const ConvGemmParams& p, int fmt);   // split formats: only shapes of the halo / gemm16 tiles
+void launch_prep_sample(const float* x, void* A0, int B, int P, int D, int fmt, long long plane, hipStream_t s);
 void launch_time_embed(float t, const float* W1, const float* b1, const float* W2, const float* b2, float* out,
                        hipStream_t s);
 void launch_prep_cond(const float* temb, const float* map_emb, int E, const float* cond, int G, void* out, int B,
-                      int Kpad, int prec, hipStream_t s);
-void launch_final_proj_flow(const void* Y, int C, int Lp, const float* W, const float* bias, int D, float* x, float dt,
-                            const double* act_norm, double* actions, int B, int P, int prec, hipStream_t s, int raw = 0);
+                      int Kpad, int fmt, long long plane, hipStream_t s);
+void launch_final_proj_flow(const void* Y, int C, int Lp, long long plane, const float* W, const float* bias, int D, float* x,
+                            float dt, const double* act_norm /*[mu[D], sigma[D]]*/, double* actions, int B, int P, int fmt,
+                            hipStream_t s, int raw = 0);
 struct TapList {          // live (kh, kw) taps of a Conv2d on a small map
   int n;
   signed char kh[49], kw[49];
 };
 void launch_gn1d(void* x, int ld, int Lp, int row_off, int coff, int L, int C, const float* gamma, const float* beta, float eps,
                  int mode, const float* film, int film_ld, int film_off, const void* res, int ldres, int res_Lp, int res_off,
-                 int B, int prec, hipStream_t s);
+                 int B, int fmt, long long x_plane, long long res_plane, hipStream_t s);
 void launch_encoder_stem(const float* lm, const float* W /*[49][64] f32 (tap-major), input channels folded*/, const float* gamma,
-                         const float* beta, void* out /*[B][25][64]*/, int B, float eps, int prec, hipStream_t s);
+                         const float* beta, void* out /*[B][25][64]*/, int B, float eps, int fmt, hipStream_t s);
 void launch_im2col2d(const void* in, bool src_f32, void* out, int B, int H, int W, int C, const TapList& taps, int stride,
-                     int pad, int OH, int OW, int Kpad, int prec, hipStream_t s);
+                     int pad, int OH, int OW, int Kpad, int fmt, hipStream_t s);
 void launch_gn2d(const float* in, int nslab, long long slab_stride, const float* gamma, const float* beta, const void* res,
-                 int relu, void* out, int B, int HW, int C, float eps, int prec, hipStream_t s);
-void launch_maxpool2d(const void* in, void* out, int B, int H, int W, int C, int OH, int OW, int prec, hipStream_t s);
-void launch_avgpool2d(const void* in, void* out, int B, int HW, int C, int prec, hipStream_t s);
-void launch_unpack_act(const void* in, int ld, int coff, int Lp, int roff, float* out, int B, int L, int C, int prec,
-                       hipStream_t s);
+                 int relu, void* out, int B, int HW, int C, float eps, int fmt, hipStream_t s);
+void launch_maxpool2d(const void* in, void* out, int B, int H, int W, int C, int OH, int OW, int fmt, hipStream_t s);
+void launch_avgpool2d(const void* in, void* out, int B, int HW, int C, int fmt, hipStream_t s);
+void launch_unpack_act(const void* in, int ld, int coff, int Lp, int roff, float* out, int B, int L, int C, int fmt,
+                       long long plane, hipStream_t s);

@@ -29,7 +29,15 @@ struct Act {             // channels-last activation view
   int L = 0, C = 0;      // positions per sample, channels of this view
   int ld = 0, coff = 0;  // row stride (elements), channel offset of the view
   bool padded = true;    // rows per sample = L + 2 (one zero row each side)
+  long long plane = 0;   // split formats: bytes from the hi plane to the lo plane (same layout)
+  int fmt = 0;           // numeric format of the buffer (denoise.h)
   int Lp() const { return padded ? L + 2 : L; }
+};
+
+struct Packed {          // a GEMM weight in the MFMA layout
+  void* p = nullptr;
+  long long plane = 0;   // split formats: bytes to the lo plane
+  float scale = 1.0f;    // f16: the stored values are w / scale (scale a power of two)
 };
 
 inline uint16_t f2bf_host(float f) {
@@ -39,6 +47,14 @@ inline uint16_t f2bf_host(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+inline float bf2f_host(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+inline uint16_t f2h_host(float f) { _Float16 h = (_Float16)f; uint16_t u; std::memcpy(&u, &h, 2); return u; }   // RNE
+inline float h2f_host(uint16_t u) { _Float16 h; std::memcpy(&h, &u, 2); return (float)h; }
 
 }  // namespace
 
@@ -51,10 +67,11 @@ struct DenoiserState {
   int dims[3] = {512, 1024, 2048};
   bool loaded = false;
   // workspace
-  int prec = -1, Bmax = 0;
+  int prec = -1, Bmax = 0;     // prec: the DITREE_PREC_* the workspace was built for
+  int ufmt = 0, efmt = 0;      // formats (denoise.h) of the U-Net activations / GEMMs and of the encoder
   std::vector<void*> allocs;
   std::map<std::string, Act> named;
-  std::map<std::string, void*> dev_w;       // packed GEMM weights by name
+  std::map<std::string, Packed> dev_w;      // packed GEMM weights by name
   std::map<std::string, float*> dev_f;      // f32 vectors (bias, gamma, beta, small matrices)
   std::vector<std::function<void(int, int, hipStream_t)>> unet_ops;            // (B, Bp, stream)
   std::vector<std::function<void(int, int, int, hipStream_t)>> enc_ops;        // (b0, Bn, scratch region, stream)
@@ -69,7 +86,8 @@ struct DenoiserState {
   float temb_t = -1.0f;          // timestep the cached embedding was computed for (< 0: none)
   float* map_emb = nullptr;      // (Bmax, E) f32
   float* film = nullptr;         // (Bp, film_cols) f32
-  void* condA = nullptr;         // (Bp, condK)
+  void* condA = nullptr;         // (Brows, condK) [x planes]
+  long long cond_plane = 0;
   int condK = 0, film_cols = 0;
   Act final_h;                   // input of the final 1x1 projection
   const float* lm_ptr = nullptr; // caller's scaled local map of the current call
@@ -98,8 +116,8 @@ struct DenoiserState {
   bool prof_chain = false;
   std::vector<ProfRec> prof_pairs;                           // (start event, end event, kind, flops) per launch
   void note_other() { close_run(); prof_chain = false; }     // call BEFORE enqueueing the other kernel
-  void run_gemm(const ConvGemmParams& p, hipStream_t s) {
-    if (!prof_on) { launch_conv_gemm(p, prec, s); return; }
+  void run_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
+    if (!prof_on) { launch_conv_gemm(p, fmt, s); return; }
     if (prof_used + 2 > prof_ev.size()) {
       const size_t old = prof_ev.size();
       prof_ev.resize(old + 4096);
@@ -109,10 +127,10 @@ struct DenoiserState {
     if (prof_mode == 2) {
       // dominant kernel only: one (start, end) pair around each run of back-to-back halo launches, so the timed
       // region carries ~20 marker packets per denoiser call instead of ~120
-      const int dom = prec == 1 ? 1 : 0;                     // f32 instantiation: everything runs on conv_gemm_kernel
-      if (conv_gemm_kind(p, prec) != dom) { close_run(); launch_conv_gemm(p, prec, s); return; }
+      const int dom = fmt_st(ufmt) == ST_F32 ? 1 : 0;        // f32 instantiation: everything runs on conv_gemm_kernel
+      if (conv_gemm_kind(p, fmt) != dom || fmt != ufmt) { close_run(); launch_conv_gemm(p, fmt, s); return; }
       if (run_open && prof_last_stream == s) {
-        launch_conv_gemm(p, prec, s);
+        launch_conv_gemm(p, fmt, s);
         prof_pairs.back().flops += fl;
         prof_pairs.back().launches += 1;
         return;
@@ -121,7 +139,7 @@ struct DenoiserState {
       const size_t st = prof_used++;
       run_end = prof_used++;
       hipEventRecord(prof_ev[st], s);
-      launch_conv_gemm(p, prec, s);
+      launch_conv_gemm(p, fmt, s);
       prof_pairs.push_back(ProfRec{st, run_end, dom, fl, 1});
       run_open = true;
       prof_last_stream = s;
@@ -134,10 +152,10 @@ struct DenoiserState {
       start = prof_used++;
       hipEventRecord(prof_ev[start], s);
     }
-    launch_conv_gemm(p, prec, s);
+    launch_conv_gemm(p, fmt, s);
     const size_t end = prof_used++;
     hipEventRecord(prof_ev[end], s);
-    prof_pairs.push_back(ProfRec{start, end, conv_gemm_kind(p, prec), fl, 1});
+    prof_pairs.push_back(ProfRec{start, end, conv_gemm_kind(p, fmt), fl, 1});
     prof_chain = true;
     prof_last_stream = s;
   }
@@ -155,7 +173,9 @@ struct DenoiserState {
     prof_used = 0;
     prof_chain = false;
   }
-  int es() const { return prec == 0 ? 2 : 4; }
+  int es() const { return fmt_es(ufmt); }                   // element bytes of a U-Net activation plane
+  int ees() const { return fmt_es(efmt); }                  // ... of an encoder activation
+  int planes() const { return fmt_split(ufmt) ? 2 : 1; }
 
   const HostParam& P_(const std::string& name) const {
     auto it = params.find(name);
@@ -198,43 +218,83 @@ struct DenoiserState {
     return upload_f32(name, hp.data, hp.n);
   }
 
-  // Pack a GEMM weight [Npad][T*Cin_pad] in the activation type from get(n, t, ci).
+  // Pack a GEMM weight [Npad][T*Cin_pad] in format `fmt` from get(n, t, ci): f32, or 16-bit elements -- for a split
+  // format two planes hi = rnd16(w) and lo = rnd16(w - hi).  f16 has a narrow range: the matrix is stored multiplied by a
+  // power of two that puts its largest magnitude in [2^13, 2^14); the kernels multiply the accumulator by 1 / that.
   template <class F>
-  void* pack(const std::string& key, int N, int T, int Cin_pad, F get) {
+  Packed pack(const std::string& key, int fmt, int N, int T, int Cin_pad, F get) {
     auto it = dev_w.find(key);
     if (it != dev_w.end()) return it->second;
     const int Npad = (N + 255) / 256 * 256;
     const size_t K = (size_t)T * Cin_pad, total = (size_t)Npad * K;
-    std::vector<uint8_t> host(total * es(), 0);
+    const int st = fmt_st(fmt), e = fmt_es(fmt), npl = fmt_split(fmt) ? 2 : 1;
+    std::vector<uint8_t> host(total * e * npl, 0);
     const int nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    float mul = 1.0f;
+    if (st == ST_F16) {
+      std::vector<float> mx(nthreads, 0.0f);
+      std::vector<std::thread> th;
+      for (int ti = 0; ti < nthreads; ++ti)
+        th.emplace_back([&, ti]() {
+          float m = 0.f;
+          for (int n = ti; n < N; n += nthreads)
+            for (int t = 0; t < T; ++t)
+              for (int ci = 0; ci < Cin_pad; ++ci) m = std::max(m, std::fabs(get(n, t, ci)));
+          mx[ti] = m;
+        });
+      for (auto& t : th) t.join();
+      const float m = *std::max_element(mx.begin(), mx.end());
+      if (m > 0.f && std::isfinite(m)) {
+        int ex;
+        std::frexp(m, &ex);                      // m = f * 2^ex, f in [0.5, 1)
+        mul = std::ldexp(1.0f, 14 - ex);         // m * mul in [2^13, 2^14)
+      }
+    }
     std::vector<std::thread> th;
     for (int ti = 0; ti < nthreads; ++ti) {
       th.emplace_back([&, ti]() {
         for (int n = ti; n < N; n += nthreads) {
           for (int t = 0; t < T; ++t)
             for (int ci = 0; ci < Cin_pad; ++ci) {
-              const float v = get(n, t, ci);
+              const float v = get(n, t, ci) * mul;
               const size_t idx = (size_t)n * K + (size_t)t * Cin_pad + ci;
-              if (prec == 0) ((uint16_t*)host.data())[idx] = f2bf_host(v);
-              else ((float*)host.data())[idx] = v;
+              if (st == ST_F32) { ((float*)host.data())[idx] = v; continue; }
+              uint16_t* hi = (uint16_t*)host.data();
+              uint16_t* lo = hi + total;
+              if (st == ST_BF16) {
+                hi[idx] = f2bf_host(v);
+                if (npl == 2) lo[idx] = f2bf_host(v - bf2f_host(hi[idx]));
+              } else {
+                hi[idx] = f2h_host(v);
+                if (npl == 2) lo[idx] = f2h_host(v - h2f_host(hi[idx]));
+              }
             }
         }
       });
     }
     for (auto& t : th) t.join();
-    void* d = dalloc(total * es(), false);
-    if (hipMemcpy(d, host.data(), total * es(), hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("memcpy");
-    dev_w[key] = d;
-    return d;
+    Packed pk;
+    pk.p = dalloc(total * e * npl, false);
+    pk.plane = npl == 2 ? (long long)(total * e) : 0;
+    pk.scale = 1.0f / mul;
+    if (hipMemcpy(pk.p, host.data(), total * e * npl, hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("memcpy");
+    dev_w[key] = pk;
+    return pk;
   }
+  static void set_w(ConvGemmParams& p, const Packed& pk) { p.W = pk.p; p.w_plane = pk.plane; p.w_scale = pk.scale; }
 
   Act make_act(const std::string& name, int L, int C, bool padded = true) {
     Act a;
-    a.L = L; a.C = C; a.ld = C; a.coff = 0; a.padded = padded;
-    a.p = dalloc((size_t)Bmax * a.Lp() * C * es());
+    a.L = L; a.C = C; a.ld = C; a.coff = 0; a.padded = padded; a.fmt = ufmt;
+    const size_t bytes = (size_t)Bmax * a.Lp() * C * es();
+    a.plane = planes() == 2 ? (long long)bytes : 0;
+    if (bytes >= (1ull << 30)) throw std::runtime_error("activation plane of 1 GiB or more: lower the reserved batch");   // 32-bit buffer offsets
+    a.p = dalloc(bytes * planes());
     named[name] = a;
     return a;
   }
+  static void set_in(ConvGemmParams& p, const Act& in) { p.a_plane = in.plane; }
+  static void set_out(ConvGemmParams& p, const Act& out) { p.out_plane = out.plane; }
   static Act view(const Act& base, int coff, int C, const char* = nullptr) {
     Act v = base;
     v.coff = coff;
@@ -250,10 +310,10 @@ struct DenoiserState {
     const HostParam& w = P_(wname + ".weight");
     const int Cout = (int)w.dims[0], Cin = (int)w.dims[1];
     const float* wd = w.data;
-    void* wp = pack(wname, Cout, 3, Cin, [=](int n, int t, int ci) { return wd[((size_t)n * Cin + ci) * 3 + t]; });
+    const Packed wp = pack(wname, ufmt, Cout, 3, Cin, [=](int n, int t, int ci) { return wd[((size_t)n * Cin + ci) * 3 + t]; });
     ConvGemmParams p{};
     p.A = aptr(in); p.lda = in.ld; p.in_Lp = in.Lp(); p.in_stride = 1; p.in_off = 0; p.taps = 3; p.Cin = Cin;
-    p.W = wp;
+    set_w(p, wp); set_in(p, in); set_out(p, out);
     p.Out = (void*)aptr(out); p.ldc = out.ld; p.out_Lp = out.Lp(); p.out_stride = 1; p.out_off = 1; p.out_coff = 0;
     p.L = in.L; p.N = Cout; p.bias = vec(wname + ".bias"); p.mode = mode; p.eps = 1e-5f;
     if (mode >= MODE_GN_MISH) {
@@ -261,7 +321,7 @@ struct DenoiserState {
     }
     if (mode == MODE_GN_MISH_FILM) { p.film = film; p.film_ld = film_cols; p.film_off = film_off; }
     if (mode == MODE_GN_MISH_RES) {
-      p.Res = aptr(*res); p.ldres = res->ld; p.res_Lp = res->Lp(); p.res_off = res->padded ? 1 : 0;
+      p.Res = aptr(*res); p.ldres = res->ld; p.res_Lp = res->Lp(); p.res_off = res->padded ? 1 : 0; p.res_plane = res->plane;
     }
     emit_block(ops, p, out, in.L);
   }
@@ -269,9 +329,10 @@ struct DenoiserState {
   // groups inside a 256-channel tile: 64, 128 or 256 channels per group (C_out 512 / 1024 / 2048, the `large`
   // denoiser).  Other sizes run conv + bias in the GEMM and the normalisation / Mish / FiLM / residual in gn1d_kernel.
   void emit_block(std::vector<std::function<void(int, int, hipStream_t)>>& ops, const ConvGemmParams& p, const Act& out, int L) {
-    const int Cout = p.N, mode = p.mode, pr = prec;
+    const int Cout = p.N, mode = p.mode, uf = ufmt;
     const int gch = Cout / 8;
-    const bool fused = mode < MODE_GN_MISH || ((Cout & 255) == 0 && (gch == 64 || gch == 128 || gch == 256));
+    // ... and whole 16-row blocks inside a sample (the ant config runs L = 8 and 4: unfused)
+    const bool fused = mode < MODE_GN_MISH || ((Cout & 255) == 0 && (gch == 64 || gch == 128 || gch == 256) && (L & 15) == 0);
     if (!fused) {
       ConvGemmParams q = p;
       q.mode = MODE_BIAS;
@@ -281,19 +342,20 @@ struct DenoiserState {
       const float *ga = p.gamma, *be = p.beta;
       void* xo = (void*)out.p;
       const int ld = out.ld, oLp = out.Lp(), ocoff = out.coff;
+      const long long xpl = out.plane, rpl = p.res_plane;
       ops.push_back([=, this](int, int Bp, hipStream_t s) mutable {
         q.M = Bp * L;
-        run_gemm(q, s);
+        run_gemm(q, uf, s);
         note_other();
         launch_gn1d(xo, ld, oLp, 1, ocoff, L, Cout, ga, be, 1e-5f, mode, film_p, film_ld_, film_off_, resp, ldres, res_Lp,
-                    res_off, Bp, pr, s);
+                    res_off, Bp, uf, xpl, rpl, s);
       });
       return;
     }
     ConvGemmParams q = p;
-    ops.push_back([this, q, L](int, int Bp, hipStream_t s) mutable {
+    ops.push_back([this, q, L, uf](int, int Bp, hipStream_t s) mutable {
       q.M = Bp * L;
-      run_gemm(q, s);
+      run_gemm(q, uf, s);
     });
   }
   // Conv1d(k = 1) residual projection.
@@ -302,16 +364,16 @@ struct DenoiserState {
     const HostParam& w = P_(wname + ".weight");
     const int Cout = (int)w.dims[0], Cin = (int)w.dims[1];
     const float* wd = w.data;
-    void* wp = pack(wname, Cout, 1, Cin, [=](int n, int, int ci) { return wd[(size_t)n * Cin + ci]; });
+    const Packed wp = pack(wname, ufmt, Cout, 1, Cin, [=](int n, int, int ci) { return wd[(size_t)n * Cin + ci]; });
     ConvGemmParams p{};
     p.A = aptr(in); p.lda = in.ld; p.in_Lp = in.Lp(); p.in_stride = 1; p.in_off = 1; p.taps = 1; p.Cin = Cin;
-    p.W = wp;
+    set_w(p, wp); set_in(p, in); set_out(p, out);
     p.Out = (void*)aptr(out); p.ldc = out.ld; p.out_Lp = out.Lp(); p.out_stride = 1; p.out_off = 1;
     p.L = in.L; p.N = Cout; p.bias = vec(wname + ".bias"); p.mode = MODE_BIAS;
-    const int L = in.L, pr = prec;
-    ops.push_back([this, p, L](int, int Bp, hipStream_t s) mutable {
+    const int L = in.L, uf = ufmt;
+    ops.push_back([this, p, L, uf](int, int Bp, hipStream_t s) mutable {
       p.M = Bp * L;
-      run_gemm(p, s);
+      run_gemm(p, uf, s);
     });
   }
   // Downsample1d: Conv1d(C, C, 3, stride 2, pad 1)  (conv1d_components.py:7-13)
@@ -320,16 +382,16 @@ struct DenoiserState {
     const HostParam& w = P_(wname + ".weight");
     const int Cout = (int)w.dims[0], Cin = (int)w.dims[1];
     const float* wd = w.data;
-    void* wp = pack(wname, Cout, 3, Cin, [=](int n, int t, int ci) { return wd[((size_t)n * Cin + ci) * 3 + t]; });
+    const Packed wp = pack(wname, ufmt, Cout, 3, Cin, [=](int n, int t, int ci) { return wd[((size_t)n * Cin + ci) * 3 + t]; });
     ConvGemmParams p{};
     p.A = aptr(in); p.lda = in.ld; p.in_Lp = in.Lp(); p.in_stride = 2; p.in_off = 0; p.taps = 3; p.Cin = Cin;
-    p.W = wp;
+    set_w(p, wp); set_in(p, in); set_out(p, out);
     p.Out = (void*)aptr(out); p.ldc = out.ld; p.out_Lp = out.Lp(); p.out_stride = 1; p.out_off = 1;
     p.L = out.L; p.N = Cout; p.bias = vec(wname + ".bias"); p.mode = MODE_BIAS;
-    const int L = out.L, pr = prec;
-    ops.push_back([this, p, L](int, int Bp, hipStream_t s) mutable {
+    const int L = out.L, uf = ufmt;
+    ops.push_back([this, p, L, uf](int, int Bp, hipStream_t s) mutable {
       p.M = Bp * L;
-      run_gemm(p, s);
+      run_gemm(p, uf, s);
     });
   }
   // Upsample1d: ConvTranspose1d(C, C, 4, 2, 1) as two 2-tap GEMMs (even / odd outputs)
@@ -341,18 +403,18 @@ struct DenoiserState {
     const float* wd = w.data;
     for (int par = 0; par < 2; ++par) {
       const int k0 = par == 0 ? 3 : 2, k1 = par == 0 ? 1 : 0;     // tap 0 -> earlier input row
-      void* wp = pack(wname + (par ? ".odd" : ".even"), Cout, 2, Cin, [=](int n, int t, int ci) {
+      const Packed wp = pack(wname + (par ? ".odd" : ".even"), ufmt, Cout, 2, Cin, [=](int n, int t, int ci) {
         return wd[((size_t)ci * Cout + n) * 4 + (t == 0 ? k0 : k1)];
       });
       ConvGemmParams p{};
       p.A = aptr(in); p.lda = in.ld; p.in_Lp = in.Lp(); p.in_stride = 1; p.in_off = par; p.taps = 2; p.Cin = Cin;
-      p.W = wp;
+      set_w(p, wp); set_in(p, in); set_out(p, out);
       p.Out = (void*)aptr(out); p.ldc = out.ld; p.out_Lp = out.Lp(); p.out_stride = 2; p.out_off = 1 + par;
       p.L = in.L; p.N = Cout; p.bias = vec(wname + ".bias"); p.mode = MODE_BIAS;
-      const int L = in.L, pr = prec;
-      ops.push_back([this, p, L](int, int Bp, hipStream_t s) mutable {
+      const int L = in.L, uf = ufmt;
+      ops.push_back([this, p, L, uf](int, int Bp, hipStream_t s) mutable {
         p.M = Bp * L;
-        run_gemm(p, s);
+        run_gemm(p, uf, s);
       });
     }
   }
@@ -378,15 +440,30 @@ struct DenoiserState {
 void DenoiserState::build(int prec_, int Bmax_) {
   free_workspace();
   prec = prec_;
+  // DITREE_PREC_*  ->  formats.  The split (f32-class) instantiations keep the small encoder (1 % of the FLOPs) in f32.
+  switch (prec) {
+    case DITREE_PREC_BF16: ufmt = fmt_make(ST_BF16, false); efmt = ST_BF16; break;
+    case DITREE_PREC_F32: ufmt = fmt_make(ST_F32, false); efmt = ST_F32; break;
+    case DITREE_PREC_F16X3: ufmt = fmt_make(ST_F16, true); efmt = ST_F32; break;
+    case DITREE_PREC_BF16X3: ufmt = fmt_make(ST_BF16, true); efmt = ST_F32; break;
+    case DITREE_PREC_F16: ufmt = fmt_make(ST_F16, false); efmt = ST_F16; break;
+    default: throw std::runtime_error("unknown precision");
+  }
   Bmax = (Bmax_ + 15) / 16 * 16;
   const int C0 = dims[0], C1 = dims[1], C2 = dims[2];
   const int L0 = P, L1 = P / 2, L2 = P / 4;
-  if (P % 64 != 0) throw std::runtime_error("pred_horizon must be a multiple of 64");
+  if (P % 16 != 0 || P < 16 || P > 256 || (256 % P) != 0) throw std::runtime_error("pred_horizon must be 16, 32, 64, 128 or 256");
+  if (fmt_split(ufmt) && P % 64 != 0) throw std::runtime_error("the split precisions need pred_horizon % 64 == 0 (halo / gemm16 tiles)");
+  if (fmt_split(ufmt) && ((C0 | C1 | C2) & 255) != 0)
+    throw std::runtime_error("the split precisions need down_dims that are multiples of 256 (halo / gemm16 tiles)");
   x_cur = (float*)dalloc((size_t)Bmax * P * D * 4);
   temb = (float*)dalloc(256 * 4);
   map_emb = (float*)dalloc((size_t)Bmax * E * 4);
   condK = (cond_dim + 63) / 64 * 64;
-  condA = dalloc((size_t)Bmax * condK * es());
+  // the FiLM GEMM runs on whole 256-row tiles: rows padded (zero rows in, ignored rows out)
+  const int Brows = (Bmax + 255) / 256 * 256;
+  cond_plane = planes() == 2 ? (long long)Brows * condK * es() : 0;
+  condA = dalloc((size_t)Brows * condK * es() * planes());
 
   // ---------------- FiLM: all cond_encoder Linear layers batched into one GEMM -------------------------
   std::vector<std::string> crbs = {"unet.down_modules.0.0", "unet.down_modules.0.1", "unet.down_modules.1.0",
@@ -399,7 +476,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
     film_offs.push_back(film_cols);
     film_cols += (int)P_(c + ".cond_encoder.1.weight").dims[0];
   }
-  film = (float*)dalloc((size_t)Bmax * film_cols * 4);
+  film = (float*)dalloc((size_t)Brows * film_cols * 4);
   {
     std::vector<const float*> wsrc, bsrc;
     std::vector<int> rows;
@@ -411,7 +488,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
     std::vector<int> start(rows.size());
     for (size_t i = 0, a = 0; i < rows.size(); ++i) { start[i] = (int)a; a += rows[i]; }
     const int cd = cond_dim;
-    void* wp = pack("film.all", film_cols, 1, condK, [=](int n, int, int ci) {
+    const Packed wp = pack("film.all", ufmt, film_cols, 1, condK, [=](int n, int, int ci) {
       size_t i = std::upper_bound(start.begin(), start.end(), n) - start.begin() - 1;
       return ci < cd ? wsrc[i][(size_t)(n - start[i]) * cd + ci] : 0.0f;
     });
@@ -420,12 +497,14 @@ void DenoiserState::build(int prec_, int Bmax_) {
     float* bd = upload_f32("film.bias", ball.data(), film_cols);
     ConvGemmParams p{};
     p.A = condA; p.lda = condK; p.in_Lp = 0; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = condK;
-    p.W = wp; p.Out = film; p.ldc = film_cols; p.out_Lp = 0; p.out_stride = 1; p.out_off = 0;
+    set_w(p, wp); p.a_plane = cond_plane;
+    p.Out = film; p.ldc = film_cols; p.out_Lp = 0; p.out_stride = 1; p.out_off = 0;
     p.N = film_cols; p.bias = bd; p.mode = MODE_BIAS; p.out_f32 = 1;
-    const int pr = prec;
-    film_op = [this, p](int, int Bp, hipStream_t s) mutable {
-      p.M = Bp; p.L = Bp; p.in_Lp = Bp; p.out_Lp = Bp;
-      run_gemm(p, s);
+    const int uf = ufmt;
+    film_op = [this, p, uf](int, int Bp, hipStream_t s) mutable {
+      const int Mr = fmt_st(uf) == ST_F32 ? Bp : (Bp + 255) / 256 * 256;
+      p.M = Mr; p.L = Mr; p.in_Lp = Mr; p.out_Lp = Mr;
+      run_gemm(p, uf, s);
     };
   }
 
@@ -433,8 +512,9 @@ void DenoiserState::build(int prec_, int Bmax_) {
   int fc = 0;   // film cursor follows `crbs` order
   // first layer input: im2col rows [x[l-1], x[l], x[l+1]] padded to 64 columns, unpadded rows
   Act a0;
-  a0.L = L0; a0.C = 64; a0.ld = 64; a0.coff = 0; a0.padded = false;
-  a0.p = dalloc((size_t)Bmax * L0 * 64 * es());
+  a0.L = L0; a0.C = 64; a0.ld = 64; a0.coff = 0; a0.padded = false; a0.fmt = ufmt;
+  a0.plane = planes() == 2 ? (long long)Bmax * L0 * 64 * es() : 0;
+  a0.p = dalloc((size_t)Bmax * L0 * 64 * es() * planes());
   named["a0"] = a0;
   {
     // down 0, block 1: Conv1d(D, C0, 3) as a 1-tap GEMM over the im2col rows
@@ -442,7 +522,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
     const HostParam& w = P_(pre + ".blocks.0.block.0.weight");
     const float* wd = w.data;
     const int Dd = D;
-    void* wp = pack(pre + ".blocks.0.block.0", C0, 1, 64, [=](int n, int, int ci) {
+    const Packed wp = pack(pre + ".blocks.0.block.0", ufmt, C0, 1, 64, [=](int n, int, int ci) {
       if (ci >= 3 * Dd) return 0.0f;
       const int t = ci / Dd, d = ci - t * Dd;
       return wd[((size_t)n * Dd + d) * 3 + t];
@@ -450,7 +530,8 @@ void DenoiserState::build(int prec_, int Bmax_) {
     Act h = make_act("d0b1.h", L0, C0);
     ConvGemmParams p{};
     p.A = a0.p; p.lda = 64; p.in_Lp = L0; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = 64;
-    p.W = wp; p.Out = h.p; p.ldc = h.ld; p.out_Lp = h.Lp(); p.out_stride = 1; p.out_off = 1;
+    set_w(p, wp); set_in(p, a0); set_out(p, h);
+    p.Out = h.p; p.ldc = h.ld; p.out_Lp = h.Lp(); p.out_stride = 1; p.out_off = 1;
     p.L = L0; p.N = C0; p.bias = vec(pre + ".blocks.0.block.0.bias"); p.mode = MODE_GN_MISH_FILM; p.eps = 1e-5f;
     p.gamma = vec(pre + ".blocks.0.block.1.weight"); p.beta = vec(pre + ".blocks.0.block.1.bias"); p.group_ch = C0 / 8;
     p.film = film; p.film_ld = film_cols; p.film_off = film_offs[0];
@@ -459,15 +540,17 @@ void DenoiserState::build(int prec_, int Bmax_) {
     // residual Conv1d(D, C0, 1): centre-tap columns of the same rows
     const HostParam& wr = P_(pre + ".residual_conv.weight");
     const float* wrd = wr.data;
-    void* wrp = pack(pre + ".residual_conv", C0, 1, 64, [=](int n, int, int ci) {
+    const Packed wrp = pack(pre + ".residual_conv", ufmt, C0, 1, 64, [=](int n, int, int ci) {
       return (ci >= Dd && ci < 2 * Dd) ? wrd[(size_t)n * Dd + (ci - Dd)] : 0.0f;
     });
     Act res = make_act("d0b1.res", L0, C0);
     ConvGemmParams q{};
     q.A = a0.p; q.lda = 64; q.in_Lp = L0; q.in_stride = 1; q.in_off = 0; q.taps = 1; q.Cin = 64;
-    q.W = wrp; q.Out = res.p; q.ldc = res.ld; q.out_Lp = res.Lp(); q.out_stride = 1; q.out_off = 1;
+    set_w(q, wrp); set_in(q, a0); set_out(q, res);
+    q.Out = res.p; q.ldc = res.ld; q.out_Lp = res.Lp(); q.out_stride = 1; q.out_off = 1;
     q.L = L0; q.N = C0; q.bias = vec(pre + ".residual_conv.bias"); q.mode = MODE_BIAS;
-    unet_ops.push_back([this, q, L](int, int Bp, hipStream_t s) mutable { q.M = Bp * L; run_gemm(q, s); });
+    const int uf = ufmt;
+    unet_ops.push_back([this, q, L, uf](int, int Bp, hipStream_t s) mutable { q.M = Bp * L; run_gemm(q, uf, s); });
     Act o = make_act("d0b1.out", L0, C0);
     add_conv3(unet_ops, pre + ".blocks.1.block.0", h, o, MODE_GN_MISH_RES, pre + ".blocks.1.block.1", 0, &res);
     fc = film_offs[1];
@@ -524,8 +607,8 @@ void DenoiserState::build(int prec_, int Bmax_) {
   // each, far fewer than the 256 CUs).
   {
     const std::string R = "encoder.resnet18.";
-    const int pr = prec;
-    const size_t E_ = es();
+    const int pr = efmt;
+    const size_t E_ = ees();
     zero_row = dalloc(256);
     sub_cap = (Bmax + ENC_SUBS - 1) / ENC_SUBS;
     sub_cap = (sub_cap + 15) / 16 * 16;
@@ -538,8 +621,8 @@ void DenoiserState::build(int prec_, int Bmax_) {
     const size_t colreg = col_region, goutreg = gout_region;
     auto ebuf = [&](const std::string& name, int HW, int C) {
       Act a;
-      a.L = HW; a.C = C; a.ld = C; a.coff = 0; a.padded = false;
-      a.p = dalloc((size_t)Bmax * HW * C * es());
+      a.L = HW; a.C = C; a.ld = C; a.coff = 0; a.padded = false; a.fmt = efmt;
+      a.p = dalloc((size_t)Bmax * HW * C * ees());
       named[name] = a;
       return a;
     };
@@ -568,7 +651,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
       const int K = tl.n * Cin, Kpad = (K + 63) / 64 * 64;
       if ((size_t)OH * OH * Kpad > col_per_sample || (size_t)OH * OH * Cout > gout_per_sample)
         throw std::runtime_error("encoder scratch region too small for " + wname);
-      void* wp = pack(wname, Cout, 1, Kpad, [=](int n, int, int kk) {
+      const Packed wp = pack(wname, efmt, Cout, 1, Kpad, [=](int n, int, int kk) {
         if (kk >= K) return 0.0f;
         const int c = kk % Cin, t = kk / Cin, kw = tl.kw[t], kh = tl.kh[t];
         if (!fold_in) return wd[(((size_t)n * Cw + c) * k + kh) * k + kw];
@@ -611,7 +694,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
           // measured on MI355X at B = 1024: 28.2 ms per round with split-K vs 29.6 without; DITREE_SPLITK=0 disables
           static int use_split = -1;
           if (use_split < 0) { const char* e = getenv("DITREE_SPLITK"); use_split = (e && !atoi(e)) ? 0 : 1; }
-          if (conv2d_small_eligible(prec)) {
+          if (conv2d_small_eligible(pr)) {
             // 64 x 64 tiles, three work-groups per CU: split only the layers that cannot fill those slots
             static int small_target = -1;
             if (small_target < 0) { const char* e = getenv("DITREE_C2D_TARGET"); small_target = (e && atoi(e) > 0) ? atoi(e) : 768; }
@@ -642,9 +725,10 @@ void DenoiserState::build(int prec_, int Bmax_) {
           p.A = colr; p.lda = Kpad; p.taps = 1; p.Cin = Kpad;
         }
         p.in_Lp = M; p.in_stride = 1; p.in_off = 0;
-        p.W = wp; p.Out = goutr; p.ldc = Cout; p.out_Lp = M; p.out_stride = 1; p.out_off = 0;
+        set_w(p, wp);
+        p.Out = goutr; p.ldc = Cout; p.out_Lp = M; p.out_stride = 1; p.out_off = 0;
         p.L = M; p.M = M; p.N = Cout; p.mode = MODE_BIAS; p.out_f32 = 1;
-        run_gemm(p, s);
+        run_gemm(p, pr, s);
       });
     };
     auto gn = [&](const std::string& gname, const Act& out, const Act* res, bool relu) {
@@ -746,16 +830,17 @@ void DenoiserState::build(int prec_, int Bmax_) {
       const HostParam& w = P_(R + "fc.weight");
       const float* wd = w.data;
       const int Kf = (int)w.dims[1], Nf = (int)w.dims[0];
-      void* wp = pack(R + "fc", Nf, 1, Kf, [=](int n, int, int ci) { return wd[(size_t)n * Kf + ci]; });
+      const Packed wp = pack(R + "fc", efmt, Nf, 1, Kf, [=](int n, int, int ci) { return wd[(size_t)n * Kf + ci]; });
       float* bd = vec(R + "fc.bias");
       const char* ip = (const char*)pooled.p;
       float* op = map_emb;
       enc_ops.push_back([=, this](int b0, int Bn, int, hipStream_t s) {
         ConvGemmParams p{};
         p.A = ip + (size_t)b0 * Kf * E_; p.lda = Kf; p.in_Lp = Bn; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = Kf;
-        p.W = wp; p.Out = op + (size_t)b0 * Nf; p.ldc = Nf; p.out_Lp = Bn; p.out_stride = 1; p.out_off = 0;
+        set_w(p, wp);
+        p.Out = op + (size_t)b0 * Nf; p.ldc = Nf; p.out_Lp = Bn; p.out_stride = 1; p.out_off = 0;
         p.L = Bn; p.M = Bn; p.N = Nf; p.bias = bd; p.mode = MODE_BIAS; p.out_f32 = 1;
-        run_gemm(p, s);
+        run_gemm(p, pr, s);
       });
     }
   }
@@ -768,6 +853,27 @@ static int parse_manifest(DenoiserState* st, const char* manifest, int64_t n_flo
   std::string line;
   while (std::getline(in, line)) {
     if (line.empty()) continue;
+    if (line.rfind("#config", 0) == 0) {          // "#config pred_horizon 64 local_map_size 20": what the shapes do not tell
+      std::istringstream cs(line.substr(7));
+      std::string key;
+      int val;
+      while (cs >> key >> val) {
+        if (key == "pred_horizon") st->P = val;
+        else if (key == "local_map_size") st->lm = val;
+      }
+      continue;
+    }
+    if (line.rfind("#checksum", 0) == 0) {        // "#checksum <s1 hex> <s2 hex>": Fletcher-style sums over the blob's 32-bit words
+      std::istringstream cs(line.substr(9));
+      std::string a, b;
+      if (!(cs >> a >> b)) return -1;
+      const uint32_t* w = (const uint32_t*)st->blob.data();
+      uint64_t s1 = 0, s2 = 0;
+      for (int64_t i = 0; i < n_floats; ++i) { s1 += w[i]; s2 += s1; }
+      if (s1 != std::stoull(a, nullptr, 16) || s2 != std::stoull(b, nullptr, 16)) return -2;
+      continue;
+    }
+    if (line[0] == '#') continue;
     std::istringstream ls(line);
     std::string name;
     int64_t off, n;
@@ -815,7 +921,7 @@ static int denoise_core(ditree_ctx* ctx, const float* noise, int64_t noise_strid
   if (!noise || !local_map || !cond || !t0 || !dt || !act_norm || K <= 0 || (!actions && !x_out))
     return set_err(ctx, DITREE_E_ARG, "denoise: bad argument");
   const int Bp = (B + 15) / 16 * 16;
-  const int pr = st->prec;
+  const int uf = st->ufmt;
   {
     const size_t row = (size_t)st->P * st->D * 4;         // one candidate's (P, D) f32 noise
     if (noise_stride < (int64_t)st->P * st->D) return set_err(ctx, DITREE_E_ARG, "denoise: noise stride");
@@ -863,16 +969,16 @@ static int denoise_core(ditree_ctx* ctx, const float* noise, int64_t noise_strid
       st->temb_t = K == 1 ? t : -1.0f;                                  // several steps share one buffer: recompute
     }
     st->note_other();
-    launch_prep_cond(st->temb, st->map_emb, st->E, cond, st->G, st->condA, B, st->condK, pr, s);
+    launch_prep_cond(st->temb, st->map_emb, st->E, cond, st->G, st->condA, B, st->condK, uf, st->cond_plane, s);
     st->film_op(B, Bp, s);
     st->note_other();
-    launch_prep_sample(st->x_cur, st->named["a0"].p, Bp, st->P, st->D, pr, s);
+    launch_prep_sample(st->x_cur, st->named["a0"].p, Bp, st->P, st->D, uf, st->named["a0"].plane, s);
     for (auto& op : st->unet_ops) op(B, Bp, s);
     const bool last = (k == K - 1);
     st->note_other();
-    launch_final_proj_flow(st->final_h.p, st->final_h.C, st->final_h.Lp(), st->dev_f["unet.final_conv.1.weight"],
+    launch_final_proj_flow(st->final_h.p, st->final_h.C, st->final_h.Lp(), st->final_h.plane, st->dev_f["unet.final_conv.1.weight"],
                            st->dev_f["unet.final_conv.1.bias"], st->D, st->x_cur, dt[k], act_norm,
-                           (last && actions) ? actions : nullptr, B, st->P, pr, s, raw);
+                           (last && actions) ? actions : nullptr, B, st->P, uf, s, raw);
   }
   if (x_out) HIP_TRY(ctx, hipMemcpyAsync(x_out, st->x_cur, (size_t)B * st->P * st->D * 4, hipMemcpyDeviceToDevice, s));
   HIP_TRY(ctx, hipGetLastError());
@@ -906,7 +1012,9 @@ int32_t ditree_load_weights(ditree_ctx* ctx, const float* blob, int64_t n_floats
   st->ctx = ctx;
   try {
     st->blob.assign(blob, blob + n_floats);
-    if (parse_manifest(st, manifest, n_floats) != 0) throw std::runtime_error("malformed manifest");
+    const int prc = parse_manifest(st, manifest, n_floats);
+    if (prc == -2) throw std::runtime_error("weight blob does not match the manifest checksum");
+    if (prc != 0) throw std::runtime_error("malformed manifest");
     const HostParam& w0 = st->P_("unet.down_modules.0.0.blocks.0.block.0.weight");
     st->D = (int)w0.dims[1];
     for (int i = 0; i < 3; ++i)
@@ -915,7 +1023,8 @@ int32_t ditree_load_weights(ditree_ctx* ctx, const float* blob, int64_t n_floats
     st->cond_dim = (int)st->P_("unet.down_modules.0.0.cond_encoder.1.weight").dims[1];
     st->E = (int)st->P_("encoder.resnet18.fc.weight").dims[0];
     st->G = st->cond_dim - 256 - st->E;
-    if (st->G < 0 || 3 * st->D > 64 || st->D > 2) throw std::runtime_error("unsupported dimensions (car config: action_dim 2)");
+    if (st->G < 0 || (st->D != 2 && st->D != 8)) throw std::runtime_error("unsupported dimensions (action_dim 2 or 8)");
+    if (st->lm != 20 && st->lm != 16) throw std::runtime_error("local_map_size must be 20 (car) or 16 (ant)");
     if (st->P_("unet.diffusion_step_encoder.1.weight").dims[1] != 256) throw std::runtime_error("diffusion_step_embed_dim must be 256");
     for (int i = 0; i < 3; ++i)
       if (st->dims[i] % 64 != 0 || st->dims[i] > 4096) throw std::runtime_error("down_dims must be multiples of 64, <= 4096");
@@ -933,7 +1042,7 @@ int32_t ditree_denoise_reserve(ditree_ctx* ctx, int32_t max_batch, int32_t preci
   if (!ctx) return DITREE_E_ARG;
   DenoiserState* st = ctx->dn;
   if (!st || !st->loaded) return set_err(ctx, DITREE_E_STATE, "denoise_reserve: weights not loaded");
-  if (max_batch <= 0 || (precision != DITREE_PREC_BF16 && precision != DITREE_PREC_F32))
+  if (max_batch <= 0 || precision < DITREE_PREC_BF16 || precision > DITREE_PREC_F16)
     return set_err(ctx, DITREE_E_ARG, "denoise_reserve: bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (st->prec == precision && st->Bmax >= max_batch) return DITREE_OK;
@@ -962,9 +1071,19 @@ int32_t ditree_denoise_eval(ditree_ctx* ctx, const float* sample, const float* l
   if (!ctx->dn) return set_err(ctx, DITREE_E_STATE, "denoise_eval: weights not loaded");
   if (!out) return set_err(ctx, DITREE_E_ARG, "denoise_eval: bad argument");
   const float one = 1.0f;
-  const double unit[4] = {0.0, 0.0, 1.0, 1.0};
+  double unit[16];
+  for (int d = 0; d < 8; ++d) { unit[d] = 0.0; unit[8 + d] = 1.0; }
+  for (int d = 0; d < ctx->dn->D && d < 8; ++d) { unit[d] = 0.0; unit[ctx->dn->D + d] = 1.0; }
   return denoise_core(ctx, sample, (int64_t)ctx->dn->P * ctx->dn->D, nullptr, local_map, cond, B, 1, &timestep, &one, unit,
                       nullptr, out, (hipStream_t)stream, 1.0f, 1, reuse_encoder);
+}
+
+int32_t ditree_denoise_dims(ditree_ctx* ctx, int32_t* dims5) {
+  if (!ctx) return DITREE_E_ARG;
+  DenoiserState* st = ctx->dn;
+  if (!st || !st->loaded || !dims5) return set_err(ctx, DITREE_E_STATE, "denoise_dims: weights not loaded");
+  dims5[0] = st->P; dims5[1] = st->D; dims5[2] = st->lm; dims5[3] = st->G; dims5[4] = st->E;
+  return DITREE_OK;
 }
 
 int32_t ditree_profile(ditree_ctx* ctx, int32_t enable) {
@@ -1010,7 +1129,7 @@ int32_t ditree_denoise_debug_read(ditree_ctx* ctx, const char* name, int32_t B, 
   if (it == st->named.end()) return set_err(ctx, DITREE_E_ARG, "debug_read: unknown buffer " + nm);
   const Act& a = it->second;
   if ((int64_t)B * a.L * a.C > capacity) return set_err(ctx, DITREE_E_ARG, "debug_read: capacity");
-  launch_unpack_act(a.p, a.ld, a.coff, a.Lp(), a.padded ? 1 : 0, out, B, a.L, a.C, st->prec, s);
+  launch_unpack_act(a.p, a.ld, a.coff, a.Lp(), a.padded ? 1 : 0, out, B, a.L, a.C, a.fmt, a.plane, s);
   dims3[0] = B; dims3[1] = a.L; dims3[2] = a.C;
   HIP_TRY(ctx, hipGetLastError());
   return DITREE_OK;

@@ -544,16 +544,26 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
 //   A fragments are double-buffered per 32-deep sub-step, B fragments per half (64 fragment VGPRs in all);
 //   phase n reads what phase n+1 needs; the barrier sits before the last phase, which carries the LDS-DMA issue.
 // =================================================================================================
+template <int ET, bool SPLIT>
 __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t (&acc)[4][8], char* smem, int tm, int tn,
                                                 int tid, int lane, int r4, int h4, int wm, int wn) {
   const int c_l = wn * 128 + 8 * r4;                          // lane's 8 consecutive channels in the tile
   const int n0 = tn * 256 + c_l;
-  if (p.bias != nullptr) {
-    const f32x4_t b0 = *(const f32x4_t*)(p.bias + n0), b1 = *(const f32x4_t*)(p.bias + n0 + 4);
+  {
+    f32x4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (p.bias != nullptr) { b0 = *(const f32x4_t*)(p.bias + n0); b1 = *(const f32x4_t*)(p.bias + n0 + 4); }
+    if constexpr (ET == 1) {                                  // f16 weights are stored scaled by a power of two
+      const float ws = p.w_scale;
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+      for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { acc[mb][j] += b0[j]; acc[mb][4 + j] += b1[j]; }
+        for (int j = 0; j < 4; ++j) { acc[mb][j] = acc[mb][j] * ws + b0[j]; acc[mb][4 + j] = acc[mb][4 + j] * ws + b1[j]; }
+    } else if (p.bias != nullptr) {
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[mb][j] += b0[j]; acc[mb][4 + j] += b1[j]; }
+    }
   }
   // 16-row block mb of this wave: tile rows wm*64 + mb*16 .. +15 (inside one sample: 16 | L)
   int blk_b[4], blk_l[4];
@@ -564,16 +574,23 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
     blk_b[mb] = b;
     blk_l[mb] = m0 - b * p.L;
   }
+  // SPLIT: the row goes out as two planes, hi = rnd16(v) and lo = rnd16(v - hi)
   auto store_row = [&](int mb, int i, const float (&v)[8]) {
     const int b = blk_b[mb], l = blk_l[mb] + 4 * h4 + i;
     const long long orow = (long long)b * p.out_Lp + (long long)l * p.out_stride + p.out_off;
     const long long oidx = orow * p.ldc + p.out_coff + n0;
     short8_t o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(v[j]);
+    for (int j = 0; j < 8; ++j) o[j] = (short)f2e<ET>(v[j]);
     *(short8_t*)((char*)p.Out + oidx * 2) = o;
+    if constexpr (SPLIT) {
+      short8_t o2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o2[j] = (short)f2e<ET>(v[j] - e2f<ET>((unsigned short)o[j]));
+      *(short8_t*)((char*)p.Out + p.out_plane + oidx * 2) = o2;
+    }
   };
-  if (p.mode < MODE_GN_MISH) {                                // plain store: bf16 activations, or f32 (the FiLM table)
+  if (p.mode < MODE_GN_MISH) {                                // plain store: 16-bit activations, or f32 (the FiLM table)
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -600,7 +617,9 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
   const f32x4_t bet0 = *(const f32x4_t*)(p.beta + n0), bet1 = *(const f32x4_t*)(p.beta + n0 + 4);
   // FiLM rows (per sample) and residual rows are fetched two / one 16-row block ahead.  The two modes exclude
   // each other, so both use the same 2 x 4 x 16-B prefetch registers:
-  //   FiLM: pre[blk & 1] = {scale lo, scale hi, bias lo, bias hi} (f32);  residual: pre[blk & 1][i] = 8 bf16 of row i
+  //   FiLM: pre[blk & 1] = {scale lo, scale hi, bias lo, bias hi} (f32);  residual: pre[blk & 1][i] = 8 elements of row i
+  //   (SPLIT: no look-ahead for the residual -- pre[0] = hi plane, pre[1] = lo plane of the CURRENT block; the epilogue is
+  //   a few % of a split kernel and a second pair of prefetch registers would spill)
   f32x4_t pre[2][4];
   auto fetch_film = [&](int blk) {
     const float* fr = p.film + (long long)blk_b[blk] * p.film_ld + p.film_off + n0;
@@ -613,12 +632,18 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long rrow = (long long)blk_b[blk] * p.res_Lp + blk_l[blk] + 4 * h4 + i + p.res_off;
-      pre[blk & 1][i] = *(const f32x4_t*)((const char*)p.Res + (rrow * p.ldres + n0) * 2);
+      const char* rp = (const char*)p.Res + (rrow * p.ldres + n0) * 2;
+      if constexpr (SPLIT) {
+        pre[0][i] = *(const f32x4_t*)rp;
+        pre[1][i] = *(const f32x4_t*)(rp + p.res_plane);
+      } else {
+        pre[blk & 1][i] = *(const f32x4_t*)rp;
+      }
     }
   };
   const bool has_film = p.mode == MODE_GN_MISH_FILM, has_res = p.mode == MODE_GN_MISH_RES;
   if (has_film) { fetch_film(0); fetch_film(1); }
-  if (has_res) fetch_res(0);
+  if (has_res && !SPLIT) fetch_res(0);
   __syncthreads();
   const int spt = 256 / p.L;
   const int gi = c_l / p.group_ch;
@@ -627,36 +652,75 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
   int slot[4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) slot[mb] = blk_b[mb] - tm * spt;
-  // one pass: sum and sum of squares (f32), var = E[x^2] - mean^2
+  // group reduction of a per-lane partial: the 16 lanes r4 of a row block hold 8 channels each -> xor 1, 2, 4 (64
+  // channels), 8 when the group is 128+ wide; h4 (xor 16, 32) walks the rows
+  auto wave_sum = [&](float s) {
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+    if (wide) s += __shfl_xor(s, 8);
+    return s;
+  };
+  float mean_[4], rstd_[4];
+  if constexpr (!SPLIT) {
+    // one pass: sum and sum of squares (f32), var = E[x^2] - mean^2
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
-    float s = 0.f, q = 0.f;
+    for (int mb = 0; mb < 4; ++mb) {
+      float s = 0.f, q = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+      for (int j = 0; j < 8; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float v = acc[mb][j][i];
-        s += v;
-        q = fmaf(v, v, q);
+        for (int i = 0; i < 4; ++i) {
+          const float v = acc[mb][j][i];
+          s += v;
+          q = fmaf(v, v, q);
+        }
+      s = wave_sum(s);
+      q = wave_sum(q);
+      if (lane == 0 || (!wide && lane == 8)) {
+        atomicAdd(&s_sum[slot[mb] * 4 + gi], s);
+        atomicAdd(&s_sq[slot[mb] * 4 + gi], q);
       }
-    s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
-    s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
-    s += __shfl_xor(s, 4); q += __shfl_xor(q, 4);
-    s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
-    s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-    if (wide) { s += __shfl_xor(s, 8); q += __shfl_xor(q, 8); }
-    if (lane == 0 || (!wide && lane == 8)) {
-      atomicAdd(&s_sum[slot[mb] * 4 + gi], s);
-      atomicAdd(&s_sq[slot[mb] * 4 + gi], q);
     }
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      mean_[mb] = s_sum[slot[mb] * 4 + gi] * inv_cnt;
+      const float var = fmaxf(s_sq[slot[mb] * 4 + gi] * inv_cnt - mean_[mb] * mean_[mb], 0.0f);
+      rstd_[mb] = rsqrtf(var + p.eps);
+    }
+  } else {
+    // f32-class instantiations: mean first, then centred squares (as torch's GroupNorm)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += acc[mb][j][i];
+      s = wave_sum(s);
+      if (lane == 0 || (!wide && lane == 8)) atomicAdd(&s_sum[slot[mb] * 4 + gi], s);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      mean_[mb] = s_sum[slot[mb] * 4 + gi] * inv_cnt;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float d = acc[mb][j][i] - mean_[mb]; q = fmaf(d, d, q); }
+      q = wave_sum(q);
+      if (lane == 0 || (!wide && lane == 8)) atomicAdd(&s_sq[slot[mb] * 4 + gi], q);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) rstd_[mb] = rsqrtf(s_sq[slot[mb] * 4 + gi] * inv_cnt + p.eps);
   }
-  __syncthreads();
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
-    const float mean = s_sum[slot[mb] * 4 + gi] * inv_cnt;
-    const float var = fmaxf(s_sq[slot[mb] * 4 + gi] * inv_cnt - mean * mean, 0.0f);
-    const float rstd = rsqrtf(var + p.eps);
-    if (has_res && mb < 3) fetch_res(mb + 1);
+    const float mean = mean_[mb], rstd = rstd_[mb];
+    if constexpr (SPLIT) { if (has_res) fetch_res(mb); }
+    else { if (has_res && mb < 3) fetch_res(mb + 1); }
     float ga[8], be[8], fs[8], fb[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -677,11 +741,20 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
     for (int i = 0; i < 4; ++i) {
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = mish_f<0>(acc[mb][j][i] * ga[j] + be[j]) * fs[j] + fb[j];
+      for (int j = 0; j < 8; ++j) {
+        if constexpr (SPLIT) v[j] = mish_f<1>((acc[mb][j][i] - mean) * ga[j] + (j < 4 ? bet0[j & 3] : bet1[j & 3])) * fs[j] + fb[j];
+        else v[j] = mish_f<0>(acc[mb][j][i] * ga[j] + be[j]) * fs[j] + fb[j];
+      }
       if (has_res) {
-        const short8_t rv = __builtin_bit_cast(short8_t, pre[mb & 1][i]);
+        const short8_t rv = __builtin_bit_cast(short8_t, pre[SPLIT ? 0 : (mb & 1)][i]);
+        if constexpr (SPLIT) {
+          const short8_t rl = __builtin_bit_cast(short8_t, pre[1][i]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += bf2f((unsigned short)rv[j]);
+          for (int j = 0; j < 8; ++j) v[j] += e2f<ET>((unsigned short)rv[j]) + e2f<ET>((unsigned short)rl[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += e2f<ET>((unsigned short)rv[j]);
+        }
       }
       store_row(mb, i, v);
     }
@@ -694,7 +767,7 @@ extern "C" int ditree_debug_halo_stamp(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_stamp), sizeof(g_halo_stamp));
 }
 #endif
-template <bool SNAKE>
+template <int ET, bool SPLIT>
 __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int A_BUF = 40960, W_BUF = 32768, W_BASE = 2 * A_BUF;
@@ -709,7 +782,12 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
   const int L = p.L, Lp = p.in_Lp, S = 256 / L;
   const int a_rows = S * Lp;
   const int nc = p.Cin >> 6;
+  // SPLIT: every 64-channel chunk is walked three times -- pass 0: A hi x W hi, 1: A hi x W lo, 2: A lo x W hi; `v` below is
+  // the virtual chunk 3 c + pass (the LDS double buffers and the barrier protocol only see its parity)
+  const int nv = SPLIT ? 3 * nc : nc;
+  const int a_plane = (int)p.a_plane, w_plane = (int)p.w_plane;
   const long long K = 3LL * p.Cin;
+  constexpr bool SNAKE = true;
 
   // ---- staging sources (buffer addressing, as conv3_halo_kernel) ------------------------------------
   // pieces 0..3 of the A block differ by 64 rows (a wave-uniform byte offset, folded into the scalar offset);
@@ -746,13 +824,17 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
     }
   }
   const int w_tap = p.Cin * 2;
-  auto issue_a = [&](int c, int i) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (LDS_AS void*)(smem + (c & 1) * A_BUF + (w + 8 * i) * 1024), 16,
-                                             i < 4 ? pa0 : pa4, c * 128 + (i < 4 ? i * a_piece : 0), 0, 0);
+  auto issue_a = [&](int v, int i) {
+    int c = v, po = 0;
+    if constexpr (SPLIT) { c = v / 3; po = (v - 3 * c == 2) ? a_plane : 0; }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (LDS_AS void*)(smem + (v & 1) * A_BUF + (w + 8 * i) * 1024), 16,
+                                             i < 4 ? pa0 : pa4, c * 128 + (i < 4 ? i * a_piece : 0) + po, 0, 0);
   };
-  auto issue_w = [&](int c, int t, int q) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (LDS_AS void*)(smem + W_BASE + ((c + t) & 1) * W_BUF + (w * 4 + q) * 1024),
-                                             16, (q & 1) ? pbo : pbe, (int)wq[q] + c * 128 + t * w_tap, 0, 0);
+  auto issue_w = [&](int v, int t, int q) {
+    int c = v, po = 0;
+    if constexpr (SPLIT) { c = v / 3; po = (v - 3 * c == 1) ? w_plane : 0; }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (LDS_AS void*)(smem + W_BASE + ((v + t) & 1) * W_BUF + (w * 4 + q) * 1024),
+                                             16, (q & 1) ? pbo : pbe, (int)wq[q] + c * 128 + t * w_tap + po, 0, 0);
   };
 
   // ---- fragment addressing ---------------------------------------------------------------------
@@ -776,24 +858,24 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[mb][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  bf16x8_t af[2][4], bq[2][4];
+  short8_t af[2][4], bq[2][4];
   auto rdA = [&](int set, int c, int t, int ks) {
     const char* ab = smem + (c & 1) * A_BUF;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       const int row = lrow0 + lstep[mb] + t;
       const int ps = (((ks << 2) | h4) ^ ((row >> 1) & 7)) << 4;
-      af[set][mb] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(ab + row * 128 + ps));
+      af[set][mb] = *(const short8_t*)(ab + row * 128 + ps);
     }
   };
   auto rdB = [&](int set, int c, int t, int ks, int half) {
     const char* wb = smem + W_BASE + ((c + t) & 1) * W_BUF + b_row_off + half * 8192;
     const int psb = (((ks << 2) | h4) ^ swl) << 4;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) bq[set][jj] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(wb + jj * 2048 + psb));
+    for (int jj = 0; jj < 4; ++jj) bq[set][jj] = *(const short8_t*)(wb + jj * 2048 + psb);
   };
   auto mm = [&](int aset, int bset, int half, int mb, int jj) {
-    acc[mb][half * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[aset][mb], bq[bset][jj], acc[mb][half * 4 + jj], 0, 0, 0);
+    acc[mb][half * 4 + jj] = mfma16<ET>(af[aset][mb], bq[bset][jj], acc[mb][half * 4 + jj]);
   };
   // snake order: consecutive MFMAs always share one operand (A along a row of the 4 x 4 block, B at the turn)
   auto mm16 = [&](int aset, int bset, int half) {
@@ -885,35 +967,35 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
 #ifdef HALO16_STAMP
   const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  for (int c = 0; c < nc - 2; ++c) {
+  for (int c = 0; c < nv - 2; ++c) {
     step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, c);          // waits W(c,1); A(c+1) may stay in flight
     step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, c);
     step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, c);          // stages W(c+1,1) then A(c+2)
   }
 #ifdef HALO16_STAMP
-  if (blockIdx.x == 100 && tid == 0 && nc >= 32) {
+  if (blockIdx.x == 100 && tid == 0 && nv >= 32) {
     g_halo_stamp[0] = __builtin_amdgcn_s_memtime() - st0;
     g_halo_stamp[1] = __builtin_amdgcn_s_memrealtime() - rt0;
-    g_halo_stamp[2] = (unsigned long long)(nc - 2) * 3;
+    g_halo_stamp[2] = (unsigned long long)(nv - 2) * 3;
   }
 #endif
   // The counted wait (vmcnt(5)) is only used inside the loop above, whose body holds no other vector-memory
   // operation.  The two tail chunks wait for everything: register spills the compiler may place here (scratch
   // accesses count in vmcnt) must not take part in a counted wait.
   {
-    const int c = nc - 2;
+    const int c = nv - 2;
     step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, c);
     step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, c);
     step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, c);
   }
   {
-    const int c = nc - 1;
+    const int c = nv - 1;
     step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, c);
     step(I1{}, Tt{}, Ff{}, Ff{}, I0{}, c);
     step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, c);
   }
   __syncthreads();
-  gemm_epilogue16(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
+  gemm_epilogue16<ET, SPLIT>(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
 }
 
 // =================================================================================================
@@ -929,6 +1011,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
 //   (slot ^ (row >> 1) & 7), staged by LDS-DMA: 16 one-KiB pieces per stage, 4 per wave.
 //   Output f32 [M][N] (the GroupNorm kernel follows), rows >= M masked.
 // =================================================================================================
+template <int ET>
 __global__ void __launch_bounds__(256) conv2d_small_kernel(ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 16384;
@@ -1005,9 +1088,9 @@ __global__ void __launch_bounds__(256) conv2d_small_kernel(ConvGemmParams p) {
     const char* st = smem + (k % 3) * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8_t af = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(st + a_off + ((((ks << 1) | h) ^ sa) << 4)));
-      const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(st + b_off + ((((ks << 1) | h) ^ sb) << 4)));
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+      const short8_t af = *(const short8_t*)(st + a_off + ((((ks << 1) | h) ^ sa) << 4));
+      const short8_t bf = *(const short8_t*)(st + b_off + ((((ks << 1) | h) ^ sb) << 4));
+      acc = mfma32<ET>(af, bf, acc);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's reads of stage k are complete
   }
@@ -1018,13 +1101,8 @@ __global__ void __launch_bounds__(256) conv2d_small_kernel(ConvGemmParams p) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int m = tm * 64 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-    if (m < p.M) ((float*)p.Out)[out_extra + (long long)m * p.ldc + p.out_coff + n] = acc[i] + bias;
+    if (m < p.M) ((float*)p.Out)[out_extra + (long long)m * p.ldc + p.out_coff + n] = (ET == 1 ? acc[i] * p.w_scale : acc[i]) + bias;
   }
-}
-bool conv2d_small_eligible(int prec) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("DITREE_C2D_SMALL"); on = (e && !atoi(e)) ? 0 : 1; }
-  return on && prec == 0;
 }
 
 // =================================================================================================
@@ -1038,6 +1116,7 @@ bool conv2d_small_eligible(int prec) {
 //   a sample (8 | L), so its source offset is wave-uniform + 8 lane-dependent rows: two lane offsets (the XOR swizzle
 //   depends on the piece parity) + scalar offsets, as for the weights.
 // =================================================================================================
+template <int ET, bool SPLIT>
 __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BUF = 32768, W_BASE = 2 * BUF;
@@ -1048,7 +1127,10 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
   const int ntn = p.N >> 8, ntm = p.M >> 8;
   const int tile = xcd_remap(blockIdx.x, ntm * ntn);
   const int tm = tile / ntn, tn = tile - tm * ntn;
-  const int nc = p.Cin >> 6, nk = p.taps * nc;
+  const int nc = p.Cin >> 6, nk0 = p.taps * nc;
+  // SPLIT: K-step kv = 3 k + pass; pass 0: A hi x W hi, 1: A hi x W lo, 2: A lo x W hi
+  const int nk = SPLIT ? 3 * nk0 : nk0;
+  const int a_plane = (int)p.a_plane, w_plane = (int)p.w_plane;
   const long long K = (long long)p.taps * p.Cin;
 
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
@@ -1074,18 +1156,32 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
     }
   }
   const int tap_bytes = p.lda * 2;                                   // one activation row further per tap
-  auto issue = [&](int k) {                                          // K-step k -> buffers k & 1
+  // scalar source offsets of (virtual) K-step kv: activations / weights
+  auto src_off = [&](int kv, int& ao, int& wo) {
+    int k = kv, pa_ = 0, pw_ = 0;
+    if constexpr (SPLIT) {
+      k = kv / 3;
+      const int pass = kv - 3 * k;
+      pa_ = pass == 2 ? a_plane : 0;
+      pw_ = pass == 1 ? w_plane : 0;
+    }
     const int t = k / nc, c = k - t * nc;
-    char* ab = smem + (k & 1) * BUF;
-    char* wb = smem + W_BASE + (k & 1) * BUF;
+    ao = t * tap_bytes + c * 128 + pa_;
+    wo = k * 128 + pw_;
+  };
+  auto issue = [&](int kv) {                                         // K-step kv -> buffers kv & 1
+    int ao, wo;
+    src_off(kv, ao, wo);
+    char* ab = smem + (kv & 1) * BUF;
+    char* wb = smem + W_BASE + (kv & 1) * BUF;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (LDS_AS void*)(ab + (w * 4 + q) * 1024), 16, (q & 1) ? pao : pae,
-                                               aq[q] + t * tap_bytes + c * 128, 0, 0);
+                                               aq[q] + ao, 0, 0);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (LDS_AS void*)(wb + (w * 4 + q) * 1024), 16, (q & 1) ? pbo : pbe,
-                                               wq[q] + k * 128, 0, 0);
+                                               wq[q] + wo, 0, 0);
   };
 
   const int a_row = wm * 64 + r4;                                    // + 16 mb
@@ -1098,19 +1194,19 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
   for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[mb][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  bf16x8_t af[2][4], bq[2][4];
+  short8_t af[2][4], bq[2][4];
   auto rdA = [&](int set, int k, int ks) {
     const char* ab = smem + (k & 1) * BUF + a_off + ((((ks << 2) | h4) ^ swa) << 4);
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) af[set][mb] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(ab + mb * 2048));
+    for (int mb = 0; mb < 4; ++mb) af[set][mb] = *(const short8_t*)(ab + mb * 2048);
   };
   auto rdB = [&](int set, int k, int ks, int half) {
     const char* wb = smem + W_BASE + (k & 1) * BUF + b_off + half * 8192 + ((((ks << 2) | h4) ^ swb) << 4);
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) bq[set][jj] = __builtin_bit_cast(bf16x8_t, *(const short8_t*)(wb + jj * 2048));
+    for (int jj = 0; jj < 4; ++jj) bq[set][jj] = *(const short8_t*)(wb + jj * 2048);
   };
   auto mm = [&](int aset, int bset, int half, int mb, int jj) {
-    acc[mb][half * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[aset][mb], bq[bset][jj], acc[mb][half * 4 + jj], 0, 0, 0);
+    acc[mb][half * 4 + jj] = mfma16<ET>(af[aset][mb], bq[bset][jj], acc[mb][half * 4 + jj]);
   };
   auto mm16 = [&](int aset, int bset, int half) {
 #pragma unroll
@@ -1137,6 +1233,8 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     __builtin_amdgcn_sched_barrier(0);
+    int ao2 = 0, wo2 = 0;
+    if constexpr (ISSUE) src_off(k + 2, ao2, wo2);
     if constexpr (HAS_NEXT) {
       // stage k+1 (requested one K-step ago) has landed; every wave is done reading stage k
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1151,13 +1249,13 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
         mm(1, 1, 1, mb, (mb & 1) ? 3 - jj : jj);
         if constexpr (ISSUE) {
           // one LDS-DMA issue behind every second MFMA (see conv3_halo16_kernel)
-          const int m = mb * 4 + jj, i = (m & 1) ? -1 : (m >> 1), t2 = (k + 2) / nc, c2 = (k + 2) - t2 * nc;
+          const int m = mb * 4 + jj, i = (m & 1) ? -1 : (m >> 1);
           if (i >= 0 && i < 4)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (LDS_AS void*)(smem + (k & 1) * BUF + (w * 4 + i) * 1024), 16,
-                                                     (i & 1) ? pao : pae, aq[i] + t2 * tap_bytes + c2 * 128, 0, 0);
+                                                     (i & 1) ? pao : pae, aq[i] + ao2, 0, 0);
           else if (i >= 4 && i < 8)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (LDS_AS void*)(smem + W_BASE + (k & 1) * BUF + (w * 4 + i - 4) * 1024),
-                                                     16, ((i - 4) & 1) ? pbo : pbe, wq[i - 4] + (k + 2) * 128, 0, 0);
+                                                     16, ((i - 4) & 1) ? pbo : pbe, wq[i - 4] + wo2, 0, 0);
         }
       }
     if constexpr (HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);
@@ -1181,106 +1279,138 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
   if (nk >= 2) step(Tt{}, Ff{}, nk - 2);
   step(Ff{}, Ff{}, nk - 1);
   __syncthreads();
-  gemm_epilogue16(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
+  gemm_epilogue16<ET, SPLIT>(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
 }
-static bool gemm16_eligible(const ConvGemmParams& p, int prec) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("DITREE_GEMM16"); on = (e && !atoi(e)) ? 0 : 1; }
-  return on && prec == 0 && !p.c2d && (!p.out_f32 || p.mode == MODE_BIAS) && p.taps >= 1 && p.taps <= 3 && (p.M & 255) == 0 && (p.N & 255) == 0 &&
-         (p.Cin & 63) == 0 && (p.L & 15) == 0 && p.M > 0 && (p.mode == MODE_BIAS || (256 % p.L) == 0);
+// fmt = storage type | split << 2 (denoise.h).  The 16-bit tiles (halo, gemm16, small Conv2d) exist for bf16 and f16;
+// the hi/lo split forms only on the halo / gemm16 pipeline; f32 runs everything on conv_gemm_kernel<1>.
+static bool gemm16_eligible(const ConvGemmParams& p, int fmt) {
+  return fmt_st(fmt) != ST_F32 && !p.c2d && (!p.out_f32 || p.mode == MODE_BIAS) && p.taps >= 1 && p.taps <= 3 && (p.M & 255) == 0 &&
+         (p.N & 255) == 0 && (p.Cin & 63) == 0 && (p.L & 15) == 0 && p.M > 0 && (p.mode == MODE_BIAS || (256 % p.L) == 0);
 }
-
-static bool halo_eligible(const ConvGemmParams& p, int prec) {
-  static int halo = -1;
-  if (halo < 0) { const char* e = getenv("DITREE_NO_HALO"); halo = (e && atoi(e)) ? 0 : 1; }
-  return prec == 0 && halo && !p.c2d && p.taps == 3 && p.in_stride == 1 && p.in_Lp == p.L + 2 && (256 % p.L) == 0 &&
+static bool halo_eligible(const ConvGemmParams& p, int fmt) {
+  return fmt_st(fmt) != ST_F32 && !p.c2d && p.taps == 3 && p.in_stride == 1 && p.in_Lp == p.L + 2 && (256 % p.L) == 0 &&
          p.L >= 16 && (p.M & 255) == 0 && (p.N & 255) == 0 && (p.Cin & 63) == 0 && p.Cin >= 192;
 }
-int conv_gemm_kind(const ConvGemmParams& p, int prec) { return halo_eligible(p, prec) ? 0 : (p.c2d ? 2 : 1); }
+bool conv2d_small_eligible(int fmt) { return fmt_st(fmt) != ST_F32 && !fmt_split(fmt); }
+int conv_gemm_kind(const ConvGemmParams& p, int fmt) { return halo_eligible(p, fmt) ? 0 : (p.c2d ? 2 : 1); }
+bool conv_gemm_supported(const ConvGemmParams& p, int fmt) {
+  return !fmt_split(fmt) || halo_eligible(p, fmt) || gemm16_eligible(p, fmt);
+}
 
-void launch_conv_gemm(const ConvGemmParams& p, int prec, hipStream_t s) {
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("DITREE_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
+// > 64 KB of dynamic LDS needs the attribute once per kernel AND per device
+static void ensure_lds_attrs() {
+  static bool done[64] = {};
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || done[dev]) return;
+  done[dev] = true;
+  const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
+  hipFuncSetAttribute((const void*)conv_gemm_kernel<0, false>, at, 131072);
+  hipFuncSetAttribute((const void*)conv_gemm_kernel<1, false>, at, 131072);
+  hipFuncSetAttribute((const void*)conv_gemm_kernel<2, false>, at, 131072);
+  hipFuncSetAttribute((const void*)conv_gemm_kernel<0, true>, at, 131072);
+  hipFuncSetAttribute((const void*)conv_gemm_kernel<1, true>, at, 131072);
+  hipFuncSetAttribute((const void*)conv_gemm_kernel<2, true>, at, 131072);
+  hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, false>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16_kernel<1, false>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, true>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16_kernel<1, true>, at, 147456);
+  hipFuncSetAttribute((const void*)gemm16_kernel<0, false>, at, 131072);
+  hipFuncSetAttribute((const void*)gemm16_kernel<1, false>, at, 131072);
+  hipFuncSetAttribute((const void*)gemm16_kernel<0, true>, at, 131072);
+  hipFuncSetAttribute((const void*)gemm16_kernel<1, true>, at, 131072);
+}
+
+void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
+  ensure_lds_attrs();
+  const int st = fmt_st(fmt);
+  const bool split = fmt_split(fmt), f16 = st == ST_F16;
   const int ntn = (p.N + 255) >> 8, ntm = (p.M + 255) >> 8;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)conv_gemm_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    hipFuncSetAttribute((const void*)conv_gemm_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    hipFuncSetAttribute((const void*)conv_gemm_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    hipFuncSetAttribute((const void*)conv_gemm_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    attr_set = true;
-  }
   const dim3 grid(ntm * ntn), block(512);
-  const bool halo_ok = halo_eligible(p, prec);
-  if (halo_ok) {
-    static bool attr2 = false;
-    if (!attr2) {
-      hipFuncSetAttribute((const void*)conv3_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
-      hipFuncSetAttribute((const void*)conv3_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
-      hipFuncSetAttribute((const void*)conv3_halo_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
-      hipFuncSetAttribute((const void*)conv3_halo_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
-      hipFuncSetAttribute((const void*)conv3_halo16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
-      hipFuncSetAttribute((const void*)conv3_halo16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
-      attr2 = true;
+  if (halo_eligible(p, fmt)) {
+    if (split) {
+      if (f16) hipLaunchKernelGGL((conv3_halo16_kernel<1, true>), grid, block, 147456, s, p);
+      else hipLaunchKernelGGL((conv3_halo16_kernel<0, true>), grid, block, 147456, s, p);
+    } else {
+      if (f16) hipLaunchKernelGGL((conv3_halo16_kernel<1, false>), grid, block, 147456, s, p);
+      else hipLaunchKernelGGL((conv3_halo16_kernel<0, false>), grid, block, 147456, s, p);
     }
-    static int shape16 = -1;               // DITREE_HALO_MFMA=32 selects the 32x32x16 kernel (A/B runs)
-    if (shape16 < 0) { const char* e = getenv("DITREE_HALO_MFMA"); shape16 = (e && atoi(e) == 32) ? 0 : 1; }
-    if (dbg == 0 && shape16) {
-      static int snake = -1;
-      if (snake < 0) { const char* e = getenv("DITREE_HALO_SNAKE"); snake = (e && !atoi(e)) ? 0 : 1; }
-      if (snake) hipLaunchKernelGGL(conv3_halo16_kernel<true>, grid, block, 147456, s, p);
-      else hipLaunchKernelGGL(conv3_halo16_kernel<false>, grid, block, 147456, s, p);
-      return;
-    }
-    if (dbg == 1) hipLaunchKernelGGL(conv3_halo_kernel<1>, grid, block, 147456, s, p);
-    else if (dbg == 2) hipLaunchKernelGGL(conv3_halo_kernel<2>, grid, block, 147456, s, p);
-    else if (dbg == 3) hipLaunchKernelGGL(conv3_halo_kernel<3>, grid, block, 147456, s, p);
-    else hipLaunchKernelGGL(conv3_halo_kernel<0>, grid, block, 147456, s, p);
     return;
   }
-  if (!halo_ok && gemm16_eligible(p, prec)) {
-    static bool attr4 = false;
-    if (!attr4) {
-      hipFuncSetAttribute((const void*)gemm16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      attr4 = true;
+  if (gemm16_eligible(p, fmt)) {
+    if (split) {
+      if (f16) hipLaunchKernelGGL((gemm16_kernel<1, true>), grid, block, 131072, s, p);
+      else hipLaunchKernelGGL((gemm16_kernel<0, true>), grid, block, 131072, s, p);
+    } else {
+      if (f16) hipLaunchKernelGGL((gemm16_kernel<1, false>), grid, block, 131072, s, p);
+      else hipLaunchKernelGGL((gemm16_kernel<0, false>), grid, block, 131072, s, p);
     }
-    hipLaunchKernelGGL(gemm16_kernel, grid, block, 131072, s, p);
     return;
   }
-  if (p.c2d && conv2d_small_eligible(prec) && (p.N & 63) == 0 && (p.Cin & 63) == 0 && p.out_f32 && p.mode == MODE_BIAS) {
-    hipLaunchKernelGGL(conv2d_small_kernel, dim3(((p.M + 63) >> 6) * (p.N >> 6), p.splitk > 1 ? p.splitk : 1), dim3(256),
-                       3 * 16384, s, p);
+  if (split) abort();      // host contract (conv_gemm_supported): a split GEMM always fits the halo / gemm16 tiles
+  if (p.c2d && conv2d_small_eligible(fmt) && (p.N & 63) == 0 && (p.Cin & 63) == 0 && p.out_f32 && p.mode == MODE_BIAS) {
+    const dim3 g2(((p.M + 63) >> 6) * (p.N >> 6), p.splitk > 1 ? p.splitk : 1);
+    if (f16) hipLaunchKernelGGL(conv2d_small_kernel<1>, g2, dim3(256), 3 * 16384, s, p);
+    else hipLaunchKernelGGL(conv2d_small_kernel<0>, g2, dim3(256), 3 * 16384, s, p);
     return;
   }
   if (p.c2d) {
-    static bool attr3 = false;
-    if (!attr3) {
-      hipFuncSetAttribute((const void*)conv_gemm_kernel<0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      hipFuncSetAttribute((const void*)conv_gemm_kernel<1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      attr3 = true;
-    }
     const dim3 grid2(ntm * ntn, p.splitk > 1 ? p.splitk : 1);
-    if (prec == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 0, true>), grid2, block, 131072, s, p);
-    else hipLaunchKernelGGL((conv_gemm_kernel<0, 0, true>), grid2, block, 131072, s, p);
+    if (st == ST_F32) hipLaunchKernelGGL((conv_gemm_kernel<1, true>), grid2, block, 131072, s, p);
+    else if (f16) hipLaunchKernelGGL((conv_gemm_kernel<2, true>), grid2, block, 131072, s, p);
+    else hipLaunchKernelGGL((conv_gemm_kernel<0, true>), grid2, block, 131072, s, p);
     return;
   }
-  if (prec == 1) hipLaunchKernelGGL((conv_gemm_kernel<1, 0>), grid, block, 131072, s, p);
-  else if (dbg == 1) hipLaunchKernelGGL((conv_gemm_kernel<0, 1>), grid, block, 131072, s, p);
-  else if (dbg == 2) hipLaunchKernelGGL((conv_gemm_kernel<0, 2>), grid, block, 131072, s, p);
-  else hipLaunchKernelGGL((conv_gemm_kernel<0, 0>), grid, block, 131072, s, p);
+  if (st == ST_F32) hipLaunchKernelGGL((conv_gemm_kernel<1, false>), grid, block, 131072, s, p);
+  else if (f16) hipLaunchKernelGGL((conv_gemm_kernel<2, false>), grid, block, 131072, s, p);
+  else hipLaunchKernelGGL((conv_gemm_kernel<0, false>), grid, block, 131072, s, p);
 }
 
 // ============================================================================= small kernels
-template <int PREC>
-__device__ __forceinline__ void store_elem(void* base, long long idx, float v) {
-  if constexpr (PREC == 0) ((unsigned short*)base)[idx] = f2bf(v);
-  else ((float*)base)[idx] = v;
+// FMT = storage type | split << 2 (denoise.h).  `plane` = bytes from the hi plane to the lo plane of a split buffer.
+template <int FMT>
+__device__ __forceinline__ void store_elem(void* base, long long idx, float v, long long plane = 0) {
+  constexpr int ST = FMT & 3;
+  if constexpr (ST == ST_F32) {
+    ((float*)base)[idx] = v;
+  } else {
+    constexpr int ET = ST == ST_F16 ? 1 : 0;
+    const unsigned short hi = f2e<ET>(v);
+    ((unsigned short*)base)[idx] = hi;
+    if constexpr ((FMT & 4) != 0) ((unsigned short*)((char*)base + plane))[idx] = f2e<ET>(v - e2f<ET>(hi));
+  }
 }
-template <int PREC>
-__device__ __forceinline__ float load_elem(const void* base, long long idx) {
-  if constexpr (PREC == 0) return bf2f(((const unsigned short*)base)[idx]);
-  else return ((const float*)base)[idx];
+template <int FMT>
+__device__ __forceinline__ float load_elem(const void* base, long long idx, long long plane = 0) {
+  constexpr int ST = FMT & 3;
+  if constexpr (ST == ST_F32) {
+    return ((const float*)base)[idx];
+  } else {
+    constexpr int ET = ST == ST_F16 ? 1 : 0;
+    float v = e2f<ET>(((const unsigned short*)base)[idx]);
+    if constexpr ((FMT & 4) != 0) v += e2f<ET>(((const unsigned short*)((const char*)base + plane))[idx]);
+    return v;
+  }
 }
+// exact Mish for the f32 and the split (f32-class) formats, the fast form for plain 16-bit storage
+#define MISH_OF(FMT) mish_f<((FMT) == ST_BF16 || (FMT) == ST_F16) ? 0 : 1>
+// run CALL(FMT) with FMT a compile-time constant
+#define DISPATCH_FMT(fmt, CALL)                                   \
+  switch (fmt) {                                                  \
+    case 0: CALL(0); break;                                       \
+    case 1: CALL(1); break;                                       \
+    case 2: CALL(2); break;                                       \
+    case 4: CALL(4); break;                                       \
+    case 6: CALL(6); break;                                       \
+    default: abort();                                             \
+  }
+#define DISPATCH_ST(fmt, CALL)                                    \
+  switch (fmt) {                                                  \
+    case 0: CALL(0); break;                                       \
+    case 1: CALL(1); break;                                       \
+    case 2: CALL(2); break;                                       \
+    default: abort();                                             \
+  }
 
 // x (B, P, D) f32 -> A0 rows (b, l): [x[l-1,:], x[l,:], x[l+1,:], 0 ...] (K padded to 64): the
 // im2col of the first Conv1d(D -> C, 3) (conditional_unet1d.py:214-218 with dim_in = input_dim).
@@ -1293,7 +1423,8 @@ template <int PREC>
 __global__ void __launch_bounds__(256) gn1d_kernel(void* __restrict__ x, int ld, int Lp, int row_off, int coff, int L, int C,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                    int mode, const float* __restrict__ film, int film_ld, int film_off,
-                                                   const void* __restrict__ res, int ldres, int res_Lp, int res_off) {
+                                                   const void* __restrict__ res, int ldres, int res_Lp, int res_off,
+                                                   long long x_plane, long long res_plane) {
   __shared__ float red[8];
   const int b = blockIdx.x >> 3, g = blockIdx.x & 7;
   const int gc = C >> 3, vpr = gc >> 3, nvec = L * vpr;          // channels per group, 8-channel vectors per row
@@ -1302,7 +1433,7 @@ __global__ void __launch_bounds__(256) gn1d_kernel(void* __restrict__ x, int ld,
   auto load8 = [&](int l, int c, float (&o)[8]) {
     const long long idx = ((long long)b * Lp + l + row_off) * ld + coff + c;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = load_elem<PREC>(x, idx + j);
+    for (int j = 0; j < 8; ++j) o[j] = load_elem<PREC>(x, idx + j, x_plane);
   };
   auto wg_sum = [&](float v) {
 #pragma unroll
@@ -1335,26 +1466,24 @@ __global__ void __launch_bounds__(256) gn1d_kernel(void* __restrict__ x, int ld,
     const long long idx = ((long long)b * Lp + l + row_off) * ld + coff + c;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float y = mish_f<PREC>((o[j] - mean) * rstd * gamma[c + j] + beta[c + j]);
+      float y = MISH_OF(PREC)((o[j] - mean) * rstd * gamma[c + j] + beta[c + j]);
       if (mode == MODE_GN_MISH_FILM) {
         const float* fr = film + (long long)b * film_ld + film_off + c + j;
         y = y * fr[0] + fr[C];
       } else if (mode == MODE_GN_MISH_RES) {
-        y += load_elem<PREC>(res, ((long long)b * res_Lp + l + res_off) * ldres + c + j);
+        y += load_elem<PREC>(res, ((long long)b * res_Lp + l + res_off) * ldres + c + j, res_plane);
       }
-      store_elem<PREC>(x, idx + j, y);
+      store_elem<PREC>(x, idx + j, y, x_plane);
     }
   }
 }
 void launch_gn1d(void* x, int ld, int Lp, int row_off, int coff, int L, int C, const float* gamma, const float* beta, float eps,
                  int mode, const float* film, int film_ld, int film_off, const void* res, int ldres, int res_Lp, int res_off,
-                 int B, int prec, hipStream_t s) {
-  if (prec == 0)
-    hipLaunchKernelGGL(gn1d_kernel<0>, dim3(B * 8), dim3(256), 0, s, x, ld, Lp, row_off, coff, L, C, gamma, beta, eps, mode, film,
-                       film_ld, film_off, res, ldres, res_Lp, res_off);
-  else
-    hipLaunchKernelGGL(gn1d_kernel<1>, dim3(B * 8), dim3(256), 0, s, x, ld, Lp, row_off, coff, L, C, gamma, beta, eps, mode, film,
-                       film_ld, film_off, res, ldres, res_Lp, res_off);
+                 int B, int fmt, long long x_plane, long long res_plane, hipStream_t s) {
+#define CALL(F) hipLaunchKernelGGL(gn1d_kernel<F>, dim3(B * 8), dim3(256), 0, s, x, ld, Lp, row_off, coff, L, C, gamma, beta, eps, \
+                                   mode, film, film_ld, film_off, res, ldres, res_Lp, res_off, x_plane, res_plane)
+  DISPATCH_FMT(fmt, CALL)
+#undef CALL
 }
 
 // Encoder stem in one launch: Conv2d(1 -> 64, 7x7, stride 2, pad 3; the three identical input channels of
@@ -1414,7 +1543,8 @@ __global__ void __launch_bounds__(256) encoder_stem_kernel(const float* __restri
   for (int j = 0; j < 25; ++j) {
     float y = fmaf(v[j], ga, be);
     y = y > 0.f ? y : 0.f;
-    if constexpr (PREC == 0) y = bf2f(f2bf(y));      // the activation is stored as bf16 before the pool in the layered path
+    if constexpr (PREC == ST_BF16) y = bf2f(f2bf(y));      // the activation is stored as bf16 before the pool in the layered path
+    if constexpr (PREC == ST_F16) y = h2f(f2h(y));
     s_act[(q + 4 * j) * 64 + c] = y;
   }
   __syncthreads();
@@ -1432,13 +1562,14 @@ __global__ void __launch_bounds__(256) encoder_stem_kernel(const float* __restri
   }
 }
 void launch_encoder_stem(const float* lm, const float* W, const float* gamma, const float* beta, void* out, int B, float eps,
-                         int prec, hipStream_t s) {
-  if (prec == 0) hipLaunchKernelGGL(encoder_stem_kernel<0>, dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps);
-  else hipLaunchKernelGGL(encoder_stem_kernel<1>, dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps);
+                         int fmt, hipStream_t s) {
+#define CALL(F) hipLaunchKernelGGL(encoder_stem_kernel<F>, dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps)
+  DISPATCH_ST(fmt, CALL)
+#undef CALL
 }
 
 template <int PREC>
-__global__ void prep_sample_kernel(const float* __restrict__ x, void* __restrict__ A0, int B, int P, int D) {
+__global__ void prep_sample_kernel(const float* __restrict__ x, void* __restrict__ A0, int B, int P, int D, long long plane) {
   const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= (long long)B * P) return;
@@ -1449,13 +1580,14 @@ __global__ void prep_sample_kernel(const float* __restrict__ x, void* __restrict
     const int ls = l + t - 1;
     if (ls >= 0 && ls < P) v = x[((long long)b * P + ls) * D + d];
   }
-  store_elem<PREC>(A0, row * 64 + lane, v);
+  store_elem<PREC>(A0, row * 64 + lane, v, plane);
 }
-void launch_prep_sample(const float* x, void* A0, int B, int P, int D, int prec, hipStream_t s) {
+void launch_prep_sample(const float* x, void* A0, int B, int P, int D, int fmt, long long plane, hipStream_t s) {
   long long rows = (long long)B * P;
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  if (prec == 0) hipLaunchKernelGGL(prep_sample_kernel<0>, grid, block, 0, s, x, A0, B, P, D);
-  else hipLaunchKernelGGL(prep_sample_kernel<1>, grid, block, 0, s, x, A0, B, P, D);
+#define CALL(F) hipLaunchKernelGGL(prep_sample_kernel<F>, grid, block, 0, s, x, A0, B, P, D, plane)
+  DISPATCH_FMT(fmt, CALL)
+#undef CALL
 }
 
 // Time embedding of one flow step: sinusoidal(256) -> Linear(256,1024) -> Mish -> Linear(1024,256)
@@ -1498,7 +1630,7 @@ void launch_time_embed(float t, const float* W1, const float* b1, const float* W
 // (conditional_unet1d.py:59-64 cond_encoder = Mish -> Linear, :293 global_feature).
 template <int PREC>
 __global__ void prep_cond_kernel(const float* __restrict__ temb, const float* __restrict__ map_emb, int E,
-                                 const float* __restrict__ cond, int G, void* __restrict__ out, int B, int Kpad) {
+                                 const float* __restrict__ cond, int G, void* __restrict__ out, int B, int Kpad, long long plane) {
   const int b = blockIdx.x;
   for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
     float v = 0.f;
@@ -1507,78 +1639,90 @@ __global__ void prep_cond_kernel(const float* __restrict__ temb, const float* __
     else if (k < 256 + E) v = map_emb[(long long)b * E + (k - 256)];
     else if (k < 256 + E + G) v = cond[(long long)b * G + (k - 256 - E)];
     else live = false;
-    store_elem<PREC>(out, (long long)b * Kpad + k, live ? mish_f<PREC>(v) : 0.f);
+    store_elem<PREC>(out, (long long)b * Kpad + k, live ? MISH_OF(PREC)(v) : 0.f, plane);
   }
 }
 void launch_prep_cond(const float* temb, const float* map_emb, int E, const float* cond, int G, void* out, int B,
-                      int Kpad, int prec, hipStream_t s) {
-  if (prec == 0) hipLaunchKernelGGL(prep_cond_kernel<0>, dim3(B), dim3(256), 0, s, temb, map_emb, E, cond, G, out, B, Kpad);
-  else hipLaunchKernelGGL(prep_cond_kernel<1>, dim3(B), dim3(256), 0, s, temb, map_emb, E, cond, G, out, B, Kpad);
+                      int Kpad, int fmt, long long plane, hipStream_t s) {
+#define CALL(F) hipLaunchKernelGGL(prep_cond_kernel<F>, dim3(B), dim3(256), 0, s, temb, map_emb, E, cond, G, out, B, Kpad, plane)
+  DISPATCH_FMT(fmt, CALL)
+#undef CALL
 }
 
 // Final Conv1d(C -> D, 1) + flow Euler step + un-normalise (conditional_unet1d.py:253-256,
 // policies/fm_policy.py:193,201-203).  One wave per position; Y is the padded channels-last
 // output of the last Conv1dBlock.
-template <int PREC>
-__global__ void __launch_bounds__(256) final_proj_flow_kernel(const void* __restrict__ Y, int C, int Lp,
+struct ActNormArg { double mu[8], sg[8]; };
+template <int PREC, int D>
+__global__ void __launch_bounds__(256) final_proj_flow_kernel(const void* __restrict__ Y, int C, int Lp, long long plane,
                                                               const float* __restrict__ W /*[D][C]*/,
-                                                              const float* __restrict__ bias, int D,
+                                                              const float* __restrict__ bias,
                                                               float* __restrict__ x /*[B][P][D] in/out*/, float dt,
-                                                              double mu0, double mu1, double sg0, double sg1,
-                                                              double* __restrict__ actions, int B, int P, int raw) {
+                                                              ActNormArg nm, double* __restrict__ actions, int B, int P, int raw) {
   const long long pos = blockIdx.x * 4LL + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (pos >= (long long)B * P) return;
   const int b = (int)(pos / P), l = (int)(pos - (long long)b * P);
   const long long row = (long long)b * Lp + l + 1;
-  float s[2] = {0.f, 0.f};
-  // a lane takes 8 consecutive channels per pass (16-B loads of bf16 rows; C is a multiple of 8)
+  float s[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) s[d] = 0.f;
+  // a lane takes 8 consecutive channels per pass (16-B loads of 16-bit rows; C is a multiple of 8)
   for (int c = lane * 8; c < C; c += 512) {
     float y[8];
-    if constexpr (PREC == 1) {
+    if constexpr ((PREC & 3) == ST_F32) {
       const f32x4_t y0 = *(const f32x4_t*)((const float*)Y + row * C + c), y1 = *(const f32x4_t*)((const float*)Y + row * C + c + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { y[j] = y0[j]; y[4 + j] = y1[j]; }
     } else {
+      constexpr int ET = (PREC & 3) == ST_F16 ? 1 : 0;
       const short8_t yv = *(const short8_t*)((const unsigned short*)Y + row * C + c);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) y[j] = bf2f((unsigned short)yv[j]);
-    }
-    for (int d = 0; d < 2; ++d) {
-      if (d < D) {
-        const f32x4_t w0 = *(const f32x4_t*)(W + (long long)d * C + c), w1 = *(const f32x4_t*)(W + (long long)d * C + c + 4);
+      for (int j = 0; j < 8; ++j) y[j] = e2f<ET>((unsigned short)yv[j]);
+      if constexpr ((PREC & 4) != 0) {
+        const short8_t yl = *(const short8_t*)((const unsigned short*)((const char*)Y + plane) + row * C + c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s[d] = fmaf(y[j], w0[j], s[d]); }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s[d] = fmaf(y[4 + j], w1[j], s[d]); }
+        for (int j = 0; j < 8; ++j) y[j] += e2f<ET>((unsigned short)yl[j]);
       }
     }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const f32x4_t w0 = *(const f32x4_t*)(W + (long long)d * C + c), w1 = *(const f32x4_t*)(W + (long long)d * C + c + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[d] = fmaf(y[j], w0[j], s[d]); }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s[d] = fmaf(y[4 + j], w1[j], s[d]); }
+    }
   }
-  for (int d = 0; d < 2; ++d) {
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) s[d] += __shfl_xor(s[d], m);
   }
-  if (lane < D && lane < 2) {
-    const float v = s[lane] + bias[lane];
+  if (lane < D) {
+    float sv = s[0];
+    double sg = nm.sg[0], mu = nm.mu[0];
+#pragma unroll
+    for (int d = 1; d < D; ++d) if (lane == d) { sv = s[d]; sg = nm.sg[d]; mu = nm.mu[d]; }
+    const float v = sv + bias[lane];
     const long long xi = pos * D + lane;
     const float xn = raw ? v : x[xi] + v * dt;              // naction + vel_pred * dt[k]; raw: the network output itself
     x[xi] = xn;
-    if (actions != nullptr) {
-      const double sg = lane == 0 ? sg0 : sg1, mu = lane == 0 ? mu0 : mu1;
-      actions[xi] = (double)xn * sg + mu;                   // float32 * float64 -> float64 (:203)
-    }
+    if (actions != nullptr) actions[xi] = (double)xn * sg + mu;     // float32 * float64 -> float64 (:203)
   }
 }
-void launch_final_proj_flow(const void* Y, int C, int Lp, const float* W, const float* bias, int D, float* x, float dt,
-                            const double* act_norm, double* actions, int B, int P, int prec, hipStream_t s, int raw) {
+// act_norm = [mu[0..D), sigma[0..D)] (host)
+void launch_final_proj_flow(const void* Y, int C, int Lp, long long plane, const float* W, const float* bias, int D, float* x,
+                            float dt, const double* act_norm, double* actions, int B, int P, int fmt, hipStream_t s, int raw) {
   long long pos = (long long)B * P;
   dim3 grid((unsigned)((pos + 3) / 4)), block(256);
-  if (prec == 0)
-    hipLaunchKernelGGL(final_proj_flow_kernel<0>, grid, block, 0, s, Y, C, Lp, W, bias, D, x, dt, act_norm[0],
-                       act_norm[1], act_norm[2], act_norm[3], actions, B, P, raw);
-  else
-    hipLaunchKernelGGL(final_proj_flow_kernel<1>, grid, block, 0, s, Y, C, Lp, W, bias, D, x, dt, act_norm[0],
-                       act_norm[1], act_norm[2], act_norm[3], actions, B, P, raw);
+  ActNormArg nm{};
+  for (int d = 0; d < D && d < 8; ++d) { nm.mu[d] = act_norm[d]; nm.sg[d] = act_norm[D + d]; }
+#define CALLD(F, DD) hipLaunchKernelGGL((final_proj_flow_kernel<F, DD>), grid, block, 0, s, Y, C, Lp, plane, W, bias, x, dt, nm, actions, B, P, raw)
+#define CALL(F) do { if (D == 2) CALLD(F, 2); else if (D == 8) CALLD(F, 8); else abort(); } while (0)
+  DISPATCH_FMT(fmt, CALL)
+#undef CALL
+#undef CALLD
 }
 
 // ------------------------------------------------------------------------------- encoder helpers
@@ -1606,15 +1750,12 @@ __global__ void im2col2d_kernel(const void* __restrict__ in, void* __restrict__ 
   }
 }
 void launch_im2col2d(const void* in, bool src_f32, void* out, int B, int H, int W, int C, const TapList& taps, int stride,
-                     int pad, int OH, int OW, int Kpad, int prec, hipStream_t s) {
+                     int pad, int OH, int OW, int Kpad, int fmt, hipStream_t s) {
   dim3 grid((unsigned)((long long)B * OH * OW)), block(Kpad >= 256 ? 256 : 64);
-  if (prec == 0) {
-    if (src_f32) hipLaunchKernelGGL((im2col2d_kernel<0, true>), grid, block, 0, s, in, out, B, H, W, C, taps, stride, pad, OH, OW, Kpad);
-    else hipLaunchKernelGGL((im2col2d_kernel<0, false>), grid, block, 0, s, in, out, B, H, W, C, taps, stride, pad, OH, OW, Kpad);
-  } else {
-    if (src_f32) hipLaunchKernelGGL((im2col2d_kernel<1, true>), grid, block, 0, s, in, out, B, H, W, C, taps, stride, pad, OH, OW, Kpad);
-    else hipLaunchKernelGGL((im2col2d_kernel<1, false>), grid, block, 0, s, in, out, B, H, W, C, taps, stride, pad, OH, OW, Kpad);
-  }
+#define CALL(F) do { if (src_f32) hipLaunchKernelGGL((im2col2d_kernel<F, true>), grid, block, 0, s, in, out, B, H, W, C, taps, stride, pad, OH, OW, Kpad); \
+                     else hipLaunchKernelGGL((im2col2d_kernel<F, false>), grid, block, 0, s, in, out, B, H, W, C, taps, stride, pad, OH, OW, Kpad); } while (0)
+  DISPATCH_ST(fmt, CALL)
+#undef CALL
 }
 
 // GroupNorm (C/16 groups, local_map_encoder.py:63-76) on the f32 GEMM output [B][HW][C] (sum of the split-K
@@ -1691,7 +1832,7 @@ __global__ void __launch_bounds__(256) gn2d_kernel(const float* __restrict__ in,
       } else {
         const short4_t r = *(const short4_t*)((const unsigned short*)res + idx);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] += bf2f((unsigned short)r[j]);
+        for (int j = 0; j < 4; ++j) y[j] += e2f<(PREC == ST_F16 ? 1 : 0)>((unsigned short)r[j]);
       }
     }
     if (relu) {
@@ -1704,18 +1845,19 @@ __global__ void __launch_bounds__(256) gn2d_kernel(const float* __restrict__ in,
     } else {
       short4_t o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (short)f2bf(y[j]);
+      for (int j = 0; j < 4; ++j) o[j] = (short)f2e<(PREC == ST_F16 ? 1 : 0)>(y[j]);
       *(short4_t*)((unsigned short*)out + idx) = o;
     }
   }
 }
 void launch_gn2d(const float* in, int nslab, long long slab_stride, const float* gamma, const float* beta, const void* res,
-                 int relu, void* out, int B, int HW, int C, float eps, int prec, hipStream_t s) {
+                 int relu, void* out, int B, int HW, int C, float eps, int fmt, hipStream_t s) {
   // host-side shape contract of the kernel (ResNet-18 stages on maps up to 10 x 10)
   if (C < 64 || C > 1024 || (C & (C - 1)) != 0 || (HW + 256 / (C >> 2) - 1) / (256 / (C >> 2)) > GN2D_MAXP) abort();
   dim3 grid((unsigned)B), block(256);
-  if (prec == 0) hipLaunchKernelGGL(gn2d_kernel<0>, grid, block, 0, s, in, nslab, slab_stride, gamma, beta, res, relu, out, HW, C, eps);
-  else hipLaunchKernelGGL(gn2d_kernel<1>, grid, block, 0, s, in, nslab, slab_stride, gamma, beta, res, relu, out, HW, C, eps);
+#define CALL(F) hipLaunchKernelGGL(gn2d_kernel<F>, grid, block, 0, s, in, nslab, slab_stride, gamma, beta, res, relu, out, HW, C, eps)
+  DISPATCH_ST(fmt, CALL)
+#undef CALL
 }
 
 // MaxPool2d(3, 2, 1) on NHWC.
@@ -1738,11 +1880,12 @@ __global__ void maxpool2d_kernel(const void* __restrict__ in, void* __restrict__
     }
   store_elem<PREC>(out, idx, best);
 }
-void launch_maxpool2d(const void* in, void* out, int B, int H, int W, int C, int OH, int OW, int prec, hipStream_t s) {
+void launch_maxpool2d(const void* in, void* out, int B, int H, int W, int C, int OH, int OW, int fmt, hipStream_t s) {
   long long total = (long long)B * OH * OW * C;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  if (prec == 0) hipLaunchKernelGGL(maxpool2d_kernel<0>, grid, block, 0, s, in, out, B, H, W, C, OH, OW);
-  else hipLaunchKernelGGL(maxpool2d_kernel<1>, grid, block, 0, s, in, out, B, H, W, C, OH, OW);
+#define CALL(F) hipLaunchKernelGGL(maxpool2d_kernel<F>, grid, block, 0, s, in, out, B, H, W, C, OH, OW)
+  DISPATCH_ST(fmt, CALL)
+#undef CALL
 }
 
 // AdaptiveAvgPool2d(1) on NHWC -> [B][C].
@@ -1755,27 +1898,29 @@ __global__ void avgpool2d_kernel(const void* __restrict__ in, void* __restrict__
   for (int q = 0; q < HW; ++q) s += load_elem<PREC>(in, ((long long)b * HW + q) * C + c);
   store_elem<PREC>(out, idx, s / (float)HW);
 }
-void launch_avgpool2d(const void* in, void* out, int B, int HW, int C, int prec, hipStream_t s) {
+void launch_avgpool2d(const void* in, void* out, int B, int HW, int C, int fmt, hipStream_t s) {
   long long total = (long long)B * C;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  if (prec == 0) hipLaunchKernelGGL(avgpool2d_kernel<0>, grid, block, 0, s, in, out, B, HW, C);
-  else hipLaunchKernelGGL(avgpool2d_kernel<1>, grid, block, 0, s, in, out, B, HW, C);
+#define CALL(F) hipLaunchKernelGGL(avgpool2d_kernel<F>, grid, block, 0, s, in, out, B, HW, C)
+  DISPATCH_ST(fmt, CALL)
+#undef CALL
 }
 
 // debug / test support: padded channels-last activation -> f32 [B][L][C]
 template <int PREC>
 __global__ void unpack_act_kernel(const void* __restrict__ in, int ld, int coff, int Lp, int roff, float* __restrict__ out,
-                                  int B, int L, int C) {
+                                  int B, int L, int C, long long plane) {
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (idx >= (long long)B * L * C) return;
   const int c = (int)(idx % C);
   const int l = (int)((idx / C) % L), b = (int)(idx / ((long long)C * L));
-  out[idx] = load_elem<PREC>(in, ((long long)b * Lp + l + roff) * ld + coff + c);
+  out[idx] = load_elem<PREC>(in, ((long long)b * Lp + l + roff) * ld + coff + c, plane);
 }
-void launch_unpack_act(const void* in, int ld, int coff, int Lp, int roff, float* out, int B, int L, int C, int prec,
-                       hipStream_t s) {
+void launch_unpack_act(const void* in, int ld, int coff, int Lp, int roff, float* out, int B, int L, int C, int fmt,
+                       long long plane, hipStream_t s) {
   long long total = (long long)B * L * C;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  if (prec == 0) hipLaunchKernelGGL(unpack_act_kernel<0>, grid, block, 0, s, in, ld, coff, Lp, roff, out, B, L, C);
-  else hipLaunchKernelGGL(unpack_act_kernel<1>, grid, block, 0, s, in, ld, coff, Lp, roff, out, B, L, C);
+#define CALL(F) hipLaunchKernelGGL(unpack_act_kernel<F>, grid, block, 0, s, in, ld, coff, Lp, roff, out, B, L, C, plane)
+  DISPATCH_FMT(fmt, CALL)
+#undef CALL
 }

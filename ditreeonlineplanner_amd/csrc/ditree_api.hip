@@ -315,6 +315,15 @@ int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditr
   if (!p->inject_actions && (!p->t0 || !p->dt || p->K <= 0))
     return set_err(ctx, DITREE_E_ARG, "expand_round: flow schedule missing");
   const int B = round->B, A = tree->A, nC = tree->n_chunks, P = p->P;
+  if (!p->inject_actions) {
+    // the scratch buffers below are sized from the caller's P / lm_n; the denoiser strides them by ITS dimensions
+    int32_t d5[5];
+    if (ditree_denoise_dims(ctx, d5) != DITREE_OK) return DITREE_E_STATE;
+    if (P != d5[0] || p->lm_n != d5[2] || d5[1] != 2 || d5[3] != 7)
+      return set_err(ctx, DITREE_E_ARG, "expand_round: pred_horizon " + std::to_string(P) + " / local map " + std::to_string(p->lm_n) +
+                     " do not match the loaded denoiser (P " + std::to_string(d5[0]) + ", action_dim " + std::to_string(d5[1]) +
+                     ", map " + std::to_string(d5[2]) + ", cond " + std::to_string(d5[3]) + "; the car engine needs action_dim 2, cond 7)");
+  }
   if (B == 0) return DITREE_OK;
   hipStream_t s = (hipStream_t)stream;
   rc = ensure_scratch(ctx, B, p->lm_n, P);

@@ -70,7 +70,8 @@ class NoisePredNet(nn.Module):
         """Upload the current parameters into ``ctx`` (repacked for MFMA inside the library)."""
         if precision is not None:
             self.precision = precision
-        blob, manifest = pack_state_dict(self.state_dict())
+        blob, manifest = pack_state_dict(self.state_dict(), pred_horizon=self.pred_horizon,
+                                         local_map_size=self.local_map_size)
         ctx.load_weights(blob, manifest)
         self._ctx = ctx
         self._reserved = 0

@@ -229,11 +229,14 @@ def _ctx_denoise(self, noise, local_map, cond, t0=None, dt=None, act_norm=None, 
     _chk(local_map, torch.float32, "local_map", dev)
     _chk(cond, torch.float32, "cond", dev)
     B = noise.shape[0]
+    self._check_denoiser_shapes(noise, local_map, cond)
     t0 = np.zeros(1, dtype=np.float32) if t0 is None else t0
     dt = np.ones(1, dtype=np.float32) if dt is None else dt
     t0a, t0p = _flt(t0)
     dta, dtp = _flt(dt)
     an, anp = _dbl(CAR_NORM[12:16] if act_norm is None else act_norm)
+    if an.size != 2 * noise.shape[2]:
+        raise ValueError(f"act_norm: need mu[{noise.shape[2]}], sigma[{noise.shape[2]}]")
     actions = torch.empty(noise.shape, dtype=torch.float64, device=dev) if want_actions else None
     xout = None if want_actions else torch.empty_like(noise)
     check(self._h, lib().ditree_denoise(self._h, _ptr(noise), _ptr(local_map), _ptr(cond), B, len(t0a), t0p, dtp,
@@ -247,10 +250,30 @@ def _ctx_denoise_eval(self, sample, local_map, cond, timestep, reuse_encoder=Fal
     _chk(sample, torch.float32, "sample", dev)
     _chk(local_map, torch.float32, "local_map", dev)
     _chk(cond, torch.float32, "cond", dev)
+    self._check_denoiser_shapes(sample, local_map, cond)
     out = torch.empty_like(sample)
     check(self._h, lib().ditree_denoise_eval(self._h, _ptr(sample), _ptr(local_map), _ptr(cond), sample.shape[0],
                                              float(timestep), int(bool(reuse_encoder)), _ptr(out), self.stream), "denoise_eval")
     return out
+
+
+def _ctx_denoise_dims(self):
+    """(pred_horizon, action_dim, local_map_size, obs-cond width, map embedding) of the loaded denoiser."""
+    d = (C.c_int32 * 5)()
+    check(self._h, lib().ditree_denoise_dims(self._h, d), "denoise_dims")
+    return tuple(int(v) for v in d)
+
+
+def _ctx_check_denoiser_shapes(self, sample, local_map, cond):
+    """The library strides its inputs by the loaded network's dimensions: reject tensors of any other shape."""
+    P, D, lm, G, _ = self.denoise_dims()
+    B = sample.shape[0]
+    if tuple(sample.shape) != (B, P, D):
+        raise ValueError(f"sample / noise must be ({B}, {P}, {D}) for the loaded denoiser, got {tuple(sample.shape)}")
+    if tuple(local_map.shape) != (B, lm, lm):
+        raise ValueError(f"local_map must be ({B}, {lm}, {lm}), got {tuple(local_map.shape)}")
+    if tuple(cond.shape) != (B, G):
+        raise ValueError(f"cond must be ({B}, {G}), got {tuple(cond.shape)}")
 
 
 def _ctx_debug_read(self, name, B, capacity=1 << 26):
@@ -267,6 +290,8 @@ Context.denoise_reserve = _ctx_denoise_reserve
 Context.denoise = _ctx_denoise
 Context.denoise_eval = _ctx_denoise_eval
 Context.debug_read = _ctx_debug_read
+Context.denoise_dims = _ctx_denoise_dims
+Context._check_denoiser_shapes = _ctx_check_denoiser_shapes
 
 
 def _ctx_profile(self, enable=True):

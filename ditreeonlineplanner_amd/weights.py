@@ -97,9 +97,24 @@ def noise_pred_net_param_shapes(input_dim=2, embedding_dim=400, additional_globa
     return sh
 
 
-def pack_state_dict(state_dict):
+def blob_checksum(blob: np.ndarray):
+    """Fletcher-style (s1, s2) over the blob's 32-bit words, both mod 2**64 (what ditree_load_weights re-computes)."""
+    w = np.ascontiguousarray(blob, dtype=np.float32).view(np.uint32).reshape(-1)
+    n = w.size
+    s1 = s2 = 0
+    mask = (1 << 64) - 1
+    with np.errstate(over="ignore"):
+        for lo in range(0, n, 1 << 24):
+            c = w[lo:lo + (1 << 24)].astype(np.uint64)
+            s1 = (s1 + int(c.sum(dtype=np.uint64))) & mask
+            s2 = (s2 + int((c * np.arange(n - lo, n - lo - c.size, -1, dtype=np.uint64)).sum(dtype=np.uint64))) & mask
+    return s1, s2
+
+
+def pack_state_dict(state_dict, pred_horizon=None, local_map_size=None, checksum=True):
     """-> (blob float32 ndarray, manifest text) in the format ditree_load_weights parses:
-    one line per tensor: ``name offset n_elems ndim d0 d1 ...``."""
+    one line per tensor: ``name offset n_elems ndim d0 d1 ...``; ``#config`` carries what the tensor shapes do not
+    tell (pred_horizon, local_map_size), ``#checksum`` guards the blob."""
     lines, chunks, off = [], [], 0
     for name, t in state_dict.items():
         a = t.detach().to("cpu", torch.float32).contiguous().numpy().reshape(-1)
@@ -107,4 +122,15 @@ def pack_state_dict(state_dict):
         lines.append(f"{name} {off} {a.size} {t.dim()} {dims}")
         chunks.append(a)
         off += a.size
-    return np.concatenate(chunks).astype(np.float32, copy=False), "\n".join(lines) + "\n"
+    blob = np.concatenate(chunks).astype(np.float32, copy=False)
+    cfg = []
+    if pred_horizon is not None:
+        cfg.append(f"pred_horizon {int(pred_horizon)}")
+    if local_map_size is not None:
+        cfg.append(f"local_map_size {int(local_map_size)}")
+    if cfg:
+        lines.append("#config " + " ".join(cfg))
+    if checksum:
+        s1, s2 = blob_checksum(blob)
+        lines.append(f"#checksum {s1:x} {s2:x}")
+    return blob, "\n".join(lines) + "\n"

@@ -211,8 +211,15 @@ int32_t ditree_load_weights(ditree_ctx* ctx, const float* blob, int64_t n_floats
 
 /* Allocate the activation workspace for up to max_batch candidates. */
 int32_t ditree_denoise_reserve(ditree_ctx* ctx, int32_t max_batch, int32_t precision);
-#define DITREE_PREC_BF16 0          /* bf16 MFMA inputs, fp32 accumulate (throughput path) */
-#define DITREE_PREC_F32 1           /* fp32 MFMA (v_mfma_f32_32x32x2_f32), parity path */
+#define DITREE_PREC_BF16 0          /* bf16 MFMA inputs, fp32 accumulate (throughput path; 8 significand bits) */
+#define DITREE_PREC_F32 1           /* fp32 MFMA (v_mfma_f32_32x32x2_f32): the reference's arithmetic, 1/16 of the bf16 rate */
+#define DITREE_PREC_F16X3 2         /* f32-class: every operand as f16 hi + lo planes, 3 f16 MFMAs per product (22 bits),
+                                       f32 accumulate, encoder in f32; 1/3 of the 16-bit rate.  f16 range: |x| <= 65504 */
+#define DITREE_PREC_BF16X3 3        /* the same split on bf16 (16 significand bits, f32 range) */
+#define DITREE_PREC_F16 4           /* plain f16 MFMA inputs (11 significand bits) at the bf16 rate */
+
+/* Dimensions of the loaded denoiser: dims5 = {pred_horizon, action_dim, local_map_size, obs-cond width, map embedding}. */
+int32_t ditree_denoise_dims(ditree_ctx* ctx, int32_t* dims5);
 
 /* policies/fm_policy.py:155-203 + local_map_encoder.py:101-109 +
  * model/diffusion/conditional_unet1d.py:268-347: K flow steps of
@@ -221,7 +228,7 @@ int32_t ditree_denoise_reserve(ditree_ctx* ctx, int32_t max_batch, int32_t preci
  *   local_map [dev] (B, 20, 20) f32 already scaled to {-1, +1}
  *   cond      [dev] (B, 7) f32
  *   t0, dt    [host] K floats (common/fm_utils.py:4-17)
- *   act_norm  [host] 4 doubles mu[2], sigma[2]
+ *   act_norm  [host] 2*D doubles mu[D], sigma[D] (D = action_dim of the loaded net)
  *   actions   [dev] (B, P, 2) f64   un-normalised actions
  *   x_out     [dev] (B, P, 2) f32 or NULL: the normalised sample after the last step */
 int32_t ditree_denoise(ditree_ctx* ctx, const float* noise, const float* local_map,

@@ -1,8 +1,10 @@
 """GPU parity: MFMA denoiser (encoder + FiLM U-Net + flow step) against the torch-CPU fp32 oracle.
 
-Tolerances (relative L2 over the whole tensor, stated per precision):
-  PREC_F32  (v_mfma_f32_32x32x2_f32, exact f32 products):  1e-4  -- summation-order noise only
-  PREC_BF16 (bf16 MFMA inputs, f32 accumulate, bf16 activations between layers): 4e-2
+Every instantiation (include/ditree.h DITREE_PREC_*) is held to three bounds per tapped layer and on the output, set at
+about twice what profiles/r02_denoiser_precision_report.json records on MI355X (TOL below):
+  * relative L2 over the tensor;
+  * max |err| / rms(ref)  -- one wrong element in a layer (an O(1) error) breaks this by orders of magnitude;
+  * element-wise  |got - ref| <= atol * rms(ref) + rtol * |ref|  with NO violation allowed.
 The oracle's U-Net half is bit-identical to the reference class (tests/golden/network.npz);
 its ResNet-18-GN half is restated from the torchvision topology: parity unpinned there."""
 import json
@@ -26,8 +28,50 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-@pytest.fixture(scope="module")
-def oracle_net():
+# precision -> (rel L2, max|err| / rms(ref), element-wise atol (x rms), rtol)
+TOL = {
+    1: dict(l2=1e-5, maxn=1e-4, atol=1e-4, rtol=1e-4),        # f32 MFMA: summation-order noise only
+    2: dict(l2=1e-5, maxn=1e-4, atol=1e-4, rtol=1e-4),        # f16 x3: f32-class
+    3: dict(l2=2e-4, maxn=2e-3, atol=2e-3, rtol=2e-3),        # bf16 x3: 16 significand bits
+    4: dict(l2=2e-3, maxn=3e-2, atol=3e-2, rtol=2e-2),        # plain f16: 11 bits
+    0: dict(l2=1.6e-2, maxn=2e-1, atol=2e-1, rtol=1e-1),      # plain bf16: 8 bits
+}
+PRECS = sorted(TOL)
+
+
+def err_stats(got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    d = np.abs(got - ref)
+    rms = float(np.sqrt(np.mean(ref ** 2)) + 1e-30)
+    return dict(rel_l2=float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30)), max_norm=float(d.max() / rms),
+                rms=rms, rel_elem=float((d / (np.abs(ref) + rms)).max()))
+
+
+def check_close(got, ref, tol, what):
+    """-> list of violated bounds (empty = pass)."""
+    st = err_stats(got, ref)
+    bad = []
+    if not st["rel_l2"] < tol["l2"]:
+        bad.append(f"{what}: rel L2 {st['rel_l2']:.3g} >= {tol['l2']}")
+    if not st["max_norm"] < tol["maxn"]:
+        bad.append(f"{what}: max|err|/rms {st['max_norm']:.3g} >= {tol['maxn']}")
+    d = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(ref, dtype=np.float64))
+    viol = int((d > tol["atol"] * st["rms"] + tol["rtol"] * np.abs(ref)).sum())
+    if viol or not np.isfinite(d).all():
+        bad.append(f"{what}: {viol} element(s) outside atol*rms + rtol*|ref|")
+    return bad
+
+
+def tap_to_blc(ref, B):
+    if ref.ndim == 2:
+        return ref.reshape(B, 1, -1)
+    if ref.ndim == 4:                                                                        # (B,C,H,W) -> (B,HW,C)
+        return np.transpose(ref.reshape(B, ref.shape[1], -1), (0, 2, 1))
+    return np.transpose(ref, (0, 2, 1))                                                      # (B,C,L) -> (B,L,C)
+
+
+def _make_oracle_net():
     torch.manual_seed(0)
     net = OD.init_noise_pred_net().eval()
     # default init leaves the FiLM / GN parameters trivial; perturb so every epilogue term is exercised
@@ -40,7 +84,16 @@ def oracle_net():
 
 
 @pytest.fixture(scope="module")
+def oracle_net():
+    return _make_oracle_net()
+
+
+@pytest.fixture(scope="module")
 def inputs():
+    return _make_inputs()
+
+
+def _make_inputs():
     g = torch.Generator().manual_seed(5)
     B = 24
     from oracle import geometry as G
@@ -101,37 +154,76 @@ def _oracle_with_taps(net, noise, lm, cond):
     return x1, taps
 
 
-@pytest.mark.parametrize("prec,tol", [(1, 1e-4), (0, 4e-2)])
-def test_denoiser_layers_and_output(ctx, oracle_net, inputs, prec, tol):
+@pytest.mark.parametrize("prec", PRECS)
+def test_denoiser_layers_and_output(ctx, oracle_net, inputs, prec):
     noise, lm, cond = inputs
     B = noise.shape[0]
     _bind(ctx, oracle_net, prec, B)
     x1_ref, taps = _oracle_with_taps(oracle_net, noise, lm, cond)
     x1 = ctx.denoise(noise.cuda(), lm.cuda(), cond.cuda(), want_actions=False)
-    report = {}
+    report, bad = {}, []
     for name, _ in LAYERS:
         if name == "enc.pool":
             continue
         got = ctx.debug_read(name, B).cpu().numpy()
-        ref = taps[name].numpy()
-        if ref.ndim == 2:
-            ref = ref.reshape(B, 1, -1)
-        elif ref.ndim == 4:                                                                  # (B,C,H,W) -> (B,HW,C)
-            ref = np.transpose(ref.reshape(B, ref.shape[1], -1), (0, 2, 1))
-        else:
-            ref = np.transpose(ref, (0, 2, 1))                                               # (B,C,L) -> (B,L,C)
-        report[name] = rel(got, ref)
-    report["x1"] = rel(x1.cpu().numpy(), x1_ref)
+        ref = tap_to_blc(taps[name].numpy(), B)
+        report[name] = err_stats(got, ref)
+        bad += check_close(got, ref, TOL[prec], name)
+    report["x1"] = err_stats(x1.cpu().numpy(), x1_ref)
+    bad += check_close(x1.cpu().numpy(), x1_ref, TOL[prec], "x1")
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, f"denoiser_layers_prec{prec}.json"), "w") as f:
         json.dump(report, f, indent=1)
-    print(json.dumps(report, indent=1))
-    bad = {k: v for k, v in report.items() if not (v < tol)}
     assert not bad, bad
 
 
-@pytest.mark.parametrize("prec,tol", [(1, 1e-4), (0, 4e-2)])
-def test_actions_and_multi_step(ctx, oracle_net, inputs, prec, tol):
+@pytest.mark.parametrize("prec", PRECS)
+def test_one_corrupted_element_is_caught(ctx, oracle_net, inputs, prec):
+    """The bounds must see a single wrong element per layer (round 1 recorded a kernel variant with exactly that defect
+    that a whole-tensor L2 at 4e-2 could not see): overwrite one element of every tapped tensor with a neighbour's value."""
+    noise, lm, cond = inputs
+    B = noise.shape[0]
+    _bind(ctx, oracle_net, prec, B)
+    _, taps = _oracle_with_taps(oracle_net, noise, lm, cond)
+    ctx.denoise(noise.cuda(), lm.cuda(), cond.cuda(), want_actions=False)
+    rng = np.random.default_rng(7)
+    for name in ("d0b1.out", "skip1", "mid2.out", "u1b2.out", "final.in"):
+        got = ctx.debug_read(name, B).cpu().numpy()
+        ref = tap_to_blc(taps[name].numpy(), B)
+        assert not check_close(got, ref, TOL[prec], name)
+        rms = float(np.sqrt(np.mean(ref ** 2)))
+        # a wrong value of typical magnitude in one place: pick an element that differs from its replacement by >= rms
+        flat = got.reshape(-1).copy()
+        for _ in range(1000):
+            i, j = rng.integers(0, flat.size, 2)
+            if abs(flat[i] - flat[j]) >= rms:
+                break
+        flat[i] = flat[j]
+        assert check_close(flat.reshape(got.shape), ref, TOL[prec], name), (name, "corruption not detected")
+
+
+def test_bench_size_batch_rows_against_oracle(ctx, oracle_net):
+    """16 random rows of a B = 1024 call (the bench configuration, bf16) against the oracle run on those rows alone."""
+    g = torch.Generator().manual_seed(11)
+    B = 1024
+    from oracle import geometry as G
+    maze = load_maze("boxes").astype(np.float32)
+    rng = np.random.default_rng(12)
+    poses = np.stack([rng.uniform(-9, 9, B), rng.uniform(-9, 9, B), rng.uniform(-3.1, 3.1, B)], axis=1)
+    lm = torch.tensor(OS.scale_local_map(G.create_local_map(maze, poses[:, 0], poses[:, 1], poses[:, 2], 20, 0.2, 1.0, (10.0, 10.0))))
+    noise = torch.randn(B, 64, 2, generator=g)
+    cond = torch.randn(B, 7, generator=g) * 0.7
+    rows = np.sort(rng.choice(B, 16, replace=False))
+    x_ref = OS.flow_sample(oracle_net, noise[rows], lm[rows], cond[rows], k_steps=1)
+    for prec in (0, 2):
+        _bind(ctx, oracle_net, prec, B)
+        x = ctx.denoise(noise.cuda(), lm.cuda(), cond.cuda(), want_actions=False).cpu().numpy()
+        bad = check_close(x[rows], x_ref, TOL[prec], f"x1 rows of B=1024, prec {prec}")
+        assert not bad, bad
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_actions_and_multi_step(ctx, oracle_net, inputs, prec):
     """K = 4 flow steps (exp schedule, fm_utils.py) and the un-normalised f64 actions."""
     noise, lm, cond = inputs
     B = noise.shape[0]
@@ -141,7 +233,8 @@ def test_actions_and_multi_step(ctx, oracle_net, inputs, prec, tol):
     a_ref = OS.unnormalize_actions(xk_ref)
     a = ctx.denoise(noise.cuda(), lm.cuda(), cond.cuda(), t0=t0.numpy(), dt=dt.numpy(), want_actions=True)
     assert a.dtype == torch.float64
-    assert rel(a.cpu().numpy(), a_ref) < tol
+    # four network evaluations feed each other: allow twice the single-step bound
+    assert rel(a.cpu().numpy(), a_ref) < 2 * TOL[prec]["l2"]
 
 
 def test_batch_sizes_agree(ctx, oracle_net, inputs):
@@ -172,12 +265,13 @@ class _ToyScheduler:
         return self._Out(a * sample - 0.1 * model_output)
 
 
-@pytest.mark.parametrize("prec,tol", [(1, 1e-4), (0, 4e-2)])
-def test_raw_network_evaluation_and_diffusion_loop(ctx, oracle_net, inputs, prec, tol):
+@pytest.mark.parametrize("prec", [1, 2, 0])
+def test_raw_network_evaluation_and_diffusion_loop(ctx, oracle_net, inputs, prec):
     """ditree_denoise_eval = net(sample, map, timestep, cond) at arbitrary (unscaled) timesteps, with and without
     re-using the map embedding; then the sampler facade's policy='diffusion' branch against the same loop on the oracle."""
     noise, lm, cond = inputs
     B = noise.shape[0]
+    tol = 2 * TOL[prec]["l2"]
     _bind(ctx, oracle_net, prec, B)
     with torch.no_grad():
         for i, t in enumerate((0.0, 7.0, 63.0)):
@@ -215,14 +309,15 @@ def test_raw_network_evaluation_and_diffusion_loop(ctx, oracle_net, inputs, prec
 
 
 @pytest.mark.parametrize("size,dims", [("small", (64, 128, 256)), ("medium", (256, 512, 1024)), ("xlarge", (1024, 2048, 4096))])
-@pytest.mark.parametrize("prec,tol", [(1, 1e-4), (0, 4e-2)])
-def test_other_denoiser_sizes(ctx, inputs, size, dims, prec, tol):
+@pytest.mark.parametrize("prec", [1, 2, 0])
+def test_other_denoiser_sizes(ctx, inputs, size, dims, prec):
     """The reference's `denoiser_size` small / medium / xlarge (run_scenarios.py:92-97): channel counts whose GroupNorm groups do
     not fit the fused 256-channel epilogue run conv + bias in the GEMM and GroupNorm / Mish / FiLM / residual in
     gn1d_kernel; one flow step and the actions against the oracle network of the same size."""
     from ditreeonlineplanner_amd.model import NoisePredNet
     noise, lm, cond = inputs
     B = 8
+    tol = 2 * TOL[prec]["l2"]
     torch.manual_seed(3)
     onet = OD.init_noise_pred_net(down_dims=dims).eval()
     g = torch.Generator().manual_seed(1)
@@ -232,6 +327,12 @@ def test_other_denoiser_sizes(ctx, inputs, size, dims, prec, tol):
                 p.add_(0.2 * torch.randn(p.shape, generator=g))
     net = NoisePredNet(down_dims=dims)
     net.load_state_dict(onet.state_dict())
+    if prec == 2 and size == "small":
+        # the split instantiations only exist on the 256-channel tiles: a clean error, not a fallback
+        from ditreeonlineplanner_amd._lib import DitreeError
+        with pytest.raises(DitreeError, match="multiples of 256"):
+            net.bind(ctx, precision=prec, max_batch=B)
+        return
     net.bind(ctx, precision=prec, max_batch=B)
     x_ref = OS.flow_sample(onet, noise[:B], lm[:B], cond[:B], k_steps=1)
     x = ctx.denoise(noise[:B].cuda().contiguous(), lm[:B].cuda().contiguous(), cond[:B].cuda().contiguous(), want_actions=False)
