@@ -148,12 +148,14 @@ class ExpansionEngine:
     def __init__(self, ctx: Context, maze, start_state, goal_state, edge_length=64, action_horizon=8,
                  pred_horizon=64, local_map_size=20, local_map_scale=0.2, s_global=1.0, batch=1024,
                  capacity=65536, k_steps=1, emulate_sticky_done=True, norm=CAR_NORM, rank=0, world_size=1,
-                 process_group=None, early_exit=False, run_type=0):
+                 process_group=None, early_exit=False, run_type=0, goal_scale=None):
         self.ctx = ctx
         self.maze = np.asarray(maze, dtype=np.float32)
         self.H, self.A, self.P = edge_length, action_horizon, pred_horizon
         self.n_chunks = edge_length // action_horizon
         self.lm_n, self.lm_scale, self.s_global = local_map_size, local_map_scale, s_global
+        # divisor of the goal offset inside tanh (fm_policy.py:125-143 uses the SAMPLER's local_map_size)
+        self.goal_scale = float(local_map_size if goal_scale is None else goal_scale)
         self.batch = batch
         self.k_steps = k_steps
         self.sticky = int(bool(emulate_sticky_done))
@@ -169,7 +171,7 @@ class ExpansionEngine:
         from .common.fm_utils import get_timesteps
         t0, dt = get_timesteps("exp", k_steps, 4.0)
         self.t0, self.dt = t0.numpy().copy(), dt.numpy().copy()
-        ctx.upload_maze(self.maze)
+        ctx.upload_maze(self.maze, owner=self)
         self.reset(start_state, goal_state)
 
     # ------------------------------------------------------------------ state
@@ -185,7 +187,13 @@ class ExpansionEngine:
 
     def update_maze(self, maze):
         self.maze = np.asarray(maze, dtype=np.float32)
-        self.ctx.upload_maze(self.maze)
+        self.ctx.upload_maze(self.maze, owner=self)
+
+    def ensure_maze(self):
+        """The ctx's device maze must be THIS engine's before any launch that reads it (another planner, or a
+        check_collision call, may have uploaded its own since)."""
+        if self.ctx.maze_owner is not self:
+            self.ctx.upload_maze(self.maze, owner=self)
 
     def shard(self, B):
         """Contiguous candidate block of this rank."""
@@ -203,6 +211,7 @@ class ExpansionEngine:
             raise ValueError(f"round of {B} candidates exceeds engine batch {self.rb.B}")
         lo, hi, per = self.shard(B)
         n = hi - lo
+        self.ensure_maze()
         rp = RoundParams()
         rp.n_nodes = self.tree.n_nodes_host
         rp.samples = samples[lo:hi].data_ptr() if n else None
@@ -216,7 +225,7 @@ class ExpansionEngine:
             a, p = conv(arr)
             keep.append(a)
             setattr(rp, name, p)
-        rp.lm_n, rp.lm_size, rp.s_global = self.lm_n, float(self.lm_n), float(self.s_global)
+        rp.lm_n, rp.lm_size, rp.s_global = self.lm_n, self.goal_scale, float(self.s_global)
         rp.early_exit = self.early_exit
         if n > 0:
             rd = self.rb.desc(lo, n)
@@ -232,6 +241,7 @@ class ExpansionEngine:
         allgather_round_fields(self.rb.fields()[:-1], per, self.rank, self.world, self.pg)
 
     def accept(self, B):
+        self.ensure_maze()                        # run_type > 0: the commit kernel evaluates check_obstacle_ahead
         rd = self.rb.desc(0, B)
         check(self.ctx._h, lib().ditree_accept(self.ctx._h, C.byref(self.tree.desc), C.byref(rd), self.sticky,
                                                 self.ctx.stream), "accept")

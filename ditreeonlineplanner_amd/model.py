@@ -37,6 +37,7 @@ class NoisePredNet(nn.Module):
                  down_dims=(512, 1024, 2048), pred_horizon=64, local_map_size=20, seed=None):
         super().__init__()
         self.input_dim, self.embedding_dim = input_dim, embedding_dim
+        self.down_dims = tuple(int(d) for d in down_dims)
         self.global_cond_dim = additional_global_cond_dim
         self.pred_horizon, self.local_map_size = pred_horizon, local_map_size
         gen = torch.Generator().manual_seed(0 if seed is None else seed)
@@ -73,11 +74,21 @@ class NoisePredNet(nn.Module):
         blob, manifest = pack_state_dict(self.state_dict(), pred_horizon=self.pred_horizon,
                                          local_map_size=self.local_map_size)
         ctx.load_weights(blob, manifest)
+        ctx.weights_owner = self
         self._ctx = ctx
+        self._bound_version = self.param_version()
         self._reserved = 0
         if max_batch:
             self.reserve(max_batch)
         return self
+
+    def param_version(self):
+        """Changes whenever a parameter is written in place (load_state_dict, copy_, add_ ...)."""
+        return sum(int(p._version) for p in self.parameters())
+
+    def is_current(self, ctx):
+        """True when `ctx` holds THESE parameters (not another net's, not a stale copy)."""
+        return self._ctx is ctx and ctx.weights_owner is self and getattr(self, "_bound_version", None) == self.param_version()
 
     def reserve(self, max_batch):
         if self._ctx is None:
@@ -102,6 +113,8 @@ class NoisePredNet(nn.Module):
         t = torch.as_tensor(timestep, dtype=torch.float32).reshape(-1).cpu()
         if not bool((t == t[0]).all()):
             raise ValueError("per-sample timesteps are not supported")
+        if not self.is_current(self._ctx):
+            self.bind(self._ctx)                  # another net was bound to the ctx, or the parameters changed
         self.reserve(x.shape[0])
         # one Euler step with dt = 1 from x: x1 = x + v  ->  v = x1 - x; t0 carries t / 20
         x1 = self._ctx.denoise(x, lm, gc, t0=np.array([float(t[0]) / 20.0], dtype=np.float32),

@@ -61,6 +61,10 @@ class Context:
         if rc != 0:
             raise _lib.DitreeError(f"ditree_ctx_create failed ({rc})")
         self.maze_shape = None
+        # One ctx holds ONE device maze and ONE weight set, but several planners / nets may share it (the facades'
+        # default_context): whoever uploaded last is recorded here, and every user re-uploads when it is not the owner.
+        self.maze_owner = None
+        self.weights_owner = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -78,13 +82,16 @@ class Context:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # ------------------------------------------------------------------ maze
-    def upload_maze(self, maze):
+    def upload_maze(self, maze, owner=None):
+        """Copy the known maze to the device.  ``owner``: the object whose maze this is (``maze_owner`` afterwards);
+        anonymous uploads (owner None) make every engine re-upload its own maze before its next launch."""
         m = np.ascontiguousarray(np.asarray(maze, dtype=np.float32))
         if m.ndim != 2:
             raise ValueError("maze must be 2-D")
         check(self._h, lib().ditree_upload_maze(self._h, m.ctypes.data_as(C.POINTER(C.c_float)), m.shape[0],
                                                  m.shape[1], self.stream), "upload_maze")
         self.maze_shape = m.shape
+        self.maze_owner = owner
 
     # ------------------------------------------------------------------ nearest node
     def nn_argmin(self, queries, node_xy, n_nodes=None, gather=None):
@@ -215,6 +222,7 @@ def _ctx_load_weights(self, blob, manifest):
     blob = np.ascontiguousarray(blob, dtype=np.float32)
     check(self._h, lib().ditree_load_weights(self._h, C.c_void_p(blob.ctypes.data), blob.size,
                                              manifest.encode(), self.stream), "load_weights")
+    self.weights_owner = None               # NoisePredNet.bind records itself
 
 
 def _ctx_denoise_reserve(self, max_batch, precision=_lib.PREC_BF16):

@@ -34,6 +34,12 @@ class RRT_Planner(BasePlanner):
         self.prop_duration_schedule = kwargs.get("prop_duration", [64])
         if len(self.prop_duration_schedule) != 1:
             raise NotImplementedError("prop_duration schedules with more than one length need sequential visits")
+        # plan() runs the fused flow-matching rounds (ditree_expand_round: K Euler steps inside the library).  A sampler
+        # built for policy='diffusion' needs its scheduler's step between network calls (fm_policy.py:164-182): that loop
+        # lives in DiffusionSampler.forward, not in the round kernel -- refuse instead of sampling with the wrong rule.
+        if getattr(sampler, "policy", "flow_matching") != "flow_matching":
+            raise NotImplementedError("RRT_Planner.plan expands with the flow-matching sampler; policy="
+                                      f"{getattr(sampler, 'policy', None)!r} is only available through DiffusionSampler.forward")
         self.offline_time_budget = kwargs.get("offline_time_budget", 60)
         self.plan_count = 0
         self.init_main_path = None
@@ -50,7 +56,7 @@ class RRT_Planner(BasePlanner):
             capacity=self.capacity, k_steps=getattr(sampler, "num_diffusion_iters", 1),
             norm=getattr(sampler, "norm", None) if getattr(sampler, "norm", None) is not None else None,
             emulate_sticky_done=kwargs.get("emulate_sticky_done", True), early_exit=kwargs.get("early_exit", True),
-            run_type=self.run_type)
+            run_type=self.run_type, goal_scale=getattr(sampler, "local_map_size", None))
         self._engine.env_goal = np.asarray(self.env.goal, dtype=np.float64)
         from concurrent.futures import ThreadPoolExecutor
         self._draw_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ditree-draw")
@@ -111,7 +117,7 @@ class RRT_Planner(BasePlanner):
 
     def check_obstacle_ahead(self, state):
         """RRT.py:61-81 through the device op (the accept kernel evaluates the same function per new node)."""
-        self.ctx.upload_maze(np.asarray(self.maze, dtype=np.float32))
+        self.ctx.upload_maze(np.asarray(self.maze, dtype=np.float32), owner=None)
         st = torch.as_tensor(np.asarray(state, dtype=np.float64).reshape(1, -1), device=self.ctx.device)
         return bool(self.ctx.obstacle_ahead(st)[0].item())
 
@@ -178,6 +184,7 @@ class RRT_Planner(BasePlanner):
         pool = self._draw_pool if ahead else None
         pending = None
         cnt = None
+        steps_dev = torch.zeros((), dtype=torch.int64, device=dev)     # env steps = two-ball collision tests (cc_calls)
         while (time.time() - start_time) < self.time_budget:
             if self.max_candidates is not None and drawn >= self.max_candidates:
                 break
@@ -190,12 +197,15 @@ class RRT_Planner(BasePlanner):
             noise = torch.randn((B, eng.n_chunks, eng.P, 2), device=dev)
             cnt = eng.expand_round(torch.as_tensor(s, device=dev), torch.as_tensor(c, device=dev), noise=noise)
             drawn += B
+            steps_dev += eng.rb.chunk_steps[:B].sum()
             goal = int(cnt[CNT_GOAL]) if int(cnt[CNT_GOAL]) >= 0 else None
             if goal is not None:
                 break
         if pending is not None:
             pending.result()                     # never leave the helper running on the global RNGs
         iters = int(cnt[CNT_ITERS]) if cnt is not None else 0
+        from ..common import map_utils as _mu
+        _mu.add_cc_calls(int(steps_dev.item()))            # the counter the drivers read (run_scenarios.py:338,343)
         self.env.prob_map = orig_prob_map
         if goal is not None:
             self.env.done = True

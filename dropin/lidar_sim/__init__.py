@@ -1,1 +1,4 @@
+"""Drop-in package `lidar_sim`: engine-backed modules here, everything else from the reference checkout."""
+from _ditree_fallthrough import fall_through
 
+__path__ = fall_through(__path__, __name__)

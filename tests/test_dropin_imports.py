@@ -1,0 +1,125 @@
+"""The drop-in boundary: every first-party import at the top of the reference's three driver scripts resolves with
+`dropin/` first on the path (what `python -m ditreeonlineplanner_amd.run script.py` sets up), the engine-backed names come
+from this package, everything the engine does not replace falls through to the reference checkout, and the
+`common.map_utils.cc_calls` counter the drivers reset / read is the engine's.
+
+Runs in the build container only (it parses the scripts under /root/reference); third-party modules the container lacks
+(minari, gymnasium, gymnasium_robotics, diffusers, playsound, spatialmath, termcolor) are in-memory placeholders, as in
+tests/golden/make_golden.py."""
+import ast
+import importlib
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+REF = "/root/reference"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRIPTS = ["run_scenarios.py", "run_scenarios_with_lidar_DiTree.py", "run_scenarios_with_lidar_MPPI.py"]
+needs_ref = pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present (GPU box)")
+
+CHILD = r'''
+import ast, importlib, importlib.machinery, json, os, sys, types
+ref, repo, script = sys.argv[1:4]
+sys.path[:] = [os.path.join(repo, "dropin"), repo, ref] + [p for p in sys.path if p]
+os.environ["DITREE_REFERENCE_ROOT"] = ref
+os.chdir(ref)
+
+class _Any(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return type(name, (), {"__init__": lambda self, *a, **k: None, "__call__": lambda self, *a, **k: None})
+def placeholder(name):
+    parts = name.split(".")
+    for i in range(1, len(parts) + 1):
+        n = ".".join(parts[:i])
+        if n not in sys.modules:
+            m = _Any(n); m.__path__ = []; m.__spec__ = importlib.machinery.ModuleSpec(n, None)
+            sys.modules[n] = m
+THIRD = ["minari", "gymnasium", "gymnasium.spaces", "gymnasium_robotics", "diffusers.schedulers.scheduling_ddpm", "playsound",
+         "spatialmath.base", "spatialmath.base.transforms3d", "termcolor", "casadi"]
+for n in THIRD:
+    try:
+        importlib.import_module(n)
+    except ImportError:
+        placeholder(n)
+
+tree = ast.parse(open(os.path.join(ref, script)).read())
+out = {}
+for node in tree.body:                       # top-level statements only: the import block
+    if isinstance(node, ast.Import):
+        for a in node.names:
+            m = importlib.import_module(a.name)
+            out[a.name] = getattr(m, "__file__", None) or "<placeholder>"
+    elif isinstance(node, ast.ImportFrom) and node.level == 0:
+        m = importlib.import_module(node.module)
+        for a in node.names:
+            getattr(m, a.name)
+        out[node.module] = getattr(m, "__file__", None) or "<placeholder>"
+import common.map_utils
+common.map_utils.cc_calls = 0
+from ditreeonlineplanner_amd.common import map_utils as engine_mu
+engine_mu.add_cc_calls(7)
+out["__cc_calls__"] = common.map_utils.cc_calls
+out["__same_module__"] = common.map_utils is engine_mu
+print("RESULT " + json.dumps(out))
+'''
+
+
+def _resolve(script):
+    r = subprocess.run([sys.executable, "-c", CHILD, REF, REPO, script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[7:])
+
+
+@needs_ref
+@pytest.mark.parametrize("script", SCRIPTS)
+def test_script_import_block_resolves(script):
+    res = _resolve(script)
+    pkg = os.path.join(REPO, "ditreeonlineplanner_amd")
+    # engine-backed names come from this repository ...
+    for mod in ("car_env", "train_diffusion_policy", "policies.fm_policy", "policies.uniform_policy", "planners.RRT",
+                "common.map_utils", "drone_env", "planners.random_tree"):
+        assert mod in res, (mod, sorted(res))
+        assert res[mod].startswith(REPO), (mod, res[mod])
+    assert res["common.map_utils"].startswith(pkg)
+    # ... what the engine does not replace still comes from the reference checkout
+    assert res["planners.MPC"].startswith(REF), res["planners.MPC"]
+    for mod in ("obstacle_insertion", "plot_logger"):
+        if mod in res:
+            assert res[mod].startswith(REF), (mod, res[mod])
+    if script.endswith("MPPI.py"):
+        assert res["MPPI.mppi"].startswith(REPO)
+    # the counter the drivers reset and read (run_scenarios.py:338,343) is the engine's
+    assert res["__same_module__"] is True and res["__cc_calls__"] == 7
+
+
+def test_launcher_puts_dropin_first(tmp_path):
+    """`python -m ditreeonlineplanner_amd.run script.py` runs the script as __main__ with dropin/ ahead of the script's own
+    directory (plain `python script.py` would put the script's directory first and the reference's packages would win)."""
+    root = tmp_path / "ref"
+    (root / "planners").mkdir(parents=True)
+    (root / "planners" / "__init__.py").write_text("")
+    (root / "planners" / "RRT.py").write_text("RRT_Planner = 'reference'\n")
+    (root / "planners" / "other.py").write_text("X = 'from the checkout'\n")
+    (root / "main.py").write_text(textwrap.dedent("""
+        import os, sys
+        import planners.RRT, planners.other
+        print("RRT", planners.RRT.__file__)
+        print("OTHER", planners.other.X)
+        print("CWD", os.getcwd())
+        print("ARGV", sys.argv[1:])
+    """))
+    r = subprocess.run([sys.executable, "-m", "ditreeonlineplanner_amd.run", str(root / "main.py"), "--flag", "3"],
+                       capture_output=True, text=True, cwd=REPO, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = dict(ln.split(" ", 1) for ln in r.stdout.strip().splitlines())
+    assert out["RRT"].startswith(os.path.join(REPO, "dropin")), out
+    assert out["OTHER"] == "from the checkout"
+    assert os.path.realpath(out["CWD"]) == os.path.realpath(str(root))
+    assert out["ARGV"] == "['--flag', '3']"
