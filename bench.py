@@ -9,8 +9,13 @@ when N > 1).  Per-GPU batch is fixed (weak scaling); every candidate runs all 4 
 (no early-exit compaction), so one candidate = 23.72 GFLOP of algorithmic denoiser work
 (SURVEY.md section 8(d)).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision P] [--no-cpu-baseline]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Other workloads of BASELINE.json's config list (each prints its own one-line JSON with `roofline`):
+    --workload rollout       config 5: 65 536 car rollouts x T = 16 steps, the rollout kernel alone (no denoiser)
+    --workload lidar-round   config 4: a round of 8 192 candidates + one 181-ray lidar scan per candidate end pose
+    --workload ant-denoise   config 3: the ant-sized denoiser + glue, 4 096 candidates x 24 calls (dynamics blocked on an oracle)
 """
 import argparse
 import json
@@ -111,8 +116,293 @@ def pmc_traffic(kernel):
         return {"traffic": None}
 
 
+def _dist_setup(args):
+    """-> (rank, world, local, dist module or None, rehearse)"""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    rehearse = os.environ.get("DITREE_REHEARSE_ONE_GPU", "0") == "1"
+    if rehearse:
+        local = 0
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    return rank, world, local, dist, rehearse
+
+
+def _timed(step, args, dist, world, dev, rehearse):
+    """W warm-up steps, then K steps between barrier + synchronize; the max over ranks (the driver's contract)."""
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        et = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        elapsed = float(et.item())
+    return elapsed
+
+
+PEAK_HBM_GBS = 8000.0                                # HBM3E peak, MI355X_MICROARCH.md (6.3 TB/s achievable)
+
+
+def run_rollout(args):
+    """BASELINE config 5 -- "65 536 MPPI rollouts" -- as SURVEY.md section 8(d) defines it: the car rollout kernel alone
+    (propagate_action_sequence_env + CarEnv.step + is_colliding_car fused), K rollouts of T = 16 steps per launch per GPU,
+    every rank its own K (the path shards by rollout, no collective).  Algorithmic bytes per rollout: 48 (state) + 16 T
+    (actions, f64) + 48 T (states) + 8 (flags) = 56 + 64 T."""
+    rank, world, local, dist, rehearse = _dist_setup(args)
+    from ditreeonlineplanner_amd.ops import Context
+    K = args.batch if args.batch_set else 65536
+    T = args.horizon or 16
+    maze = load_maze("boxes")
+    ctx = Context(local)
+    dev = ctx.device
+    ctx.upload_maze(maze)
+    rng = np.random.default_rng(20260104 + rank)
+    Hh, W = maze.shape
+    free = np.argwhere(maze[1:-1, 1:-1] == 0) + 1
+    cell = free[rng.integers(0, len(free), K)]
+    x = (cell[:, 1] + 0.5) - W / 2 + rng.uniform(-0.25, 0.25, K)
+    y = Hh / 2 - (cell[:, 0] + 0.5) + rng.uniform(-0.25, 0.25, K)
+    st0 = np.stack([x, y, rng.uniform(-np.pi, np.pi, K), rng.uniform(0, 4, K), rng.uniform(0, 1, K),
+                    rng.uniform(-0.4, 0.4, K)], axis=1)
+    act = np.stack([rng.normal(0.45, 1.0, (K, T)), rng.normal(0.0, 0.92, (K, T))], axis=2)     # the action statistics of carmaze
+    s0 = torch.as_tensor(st0, device=dev)
+    a = torch.as_tensor(np.ascontiguousarray(act), device=dev)
+    state = s0.clone()
+    status = torch.zeros(K, dtype=torch.int32, device=dev)
+    goal = np.array([(17 + 0.5) - W / 2, Hh / 2 - (2 + 0.5)])
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    it = [0]
+    out = {}
+
+    def step():
+        state.copy_(s0)
+        status.zero_()
+        timed = it[0] >= args.warmup
+        if timed:
+            ev[it[0] - args.warmup][0].record()
+        out["r"] = ctx.car_rollout(state, a, goal, A=T, status=status, out=out.get("r"))
+        if timed:
+            ev[it[0] - args.warmup][1].record()
+        it[0] += 1
+
+    elapsed = _timed(step, args, dist, world, dev, rehearse)
+    k_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
+    if rank == 0:
+        st = out["r"][0].cpu().numpy() & 0xFF
+        avg_ms = float(np.mean(k_ms))
+        alg = K * (56 + 64 * T)
+        ach = alg / (avg_ms * 1e-3) / 1e9
+        res = {"metric": "car rollouts/sec (T=16 bicycle steps + goal + two-ball collision per step, no denoiser)",
+               "value": K * world * args.steps / elapsed, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"BASELINE config 5 as SURVEY 8(d) defines it: {K} car rollouts x T={T} per GPU on boxes.csv, "
+                                      "rollout kernel alone (the reference has no MPPI module and no ant MPPI script)",
+                          "rollouts_per_gpu": K, "horizon": T, "parallelism": f"rollouts sharded x{world}, no collective"},
+               "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                            "traffic": None, "kernel": "car_rollout_kernel", "avg_launch_ms": avg_ms,
+                            "algorithmic_bytes_per_launch": alg,
+                            "note": "FP64 transcendental-bound in practice (3 sincos + tanh + 9 sqrt/hypot per step): see DESIGN.md"},
+               "outcome": {"ok": int((st == 0).sum()), "goal": int((st == 1).sum()), "collided": int((st == 2).sum())}}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_lidar_round(args):
+    """BASELINE config 4: the car round with the lidar in the loop -- a round of B candidates (B = 8192 global; NN ->
+    4 x [map, cond, denoiser, 8 steps] -> accept) followed by one 181-ray `Lidar2DSim.scan` per candidate end pose on
+    the true maze (an extrapolation, the reference scans one pose every 0.2 s)."""
+    rank, world, local, dist, rehearse = _dist_setup(args)
+    from ditreeonlineplanner_amd import _lib
+    from ditreeonlineplanner_amd.engine import CNT_GOAL, CNT_LATCH, CNT_NODES, ExpansionEngine
+    from ditreeonlineplanner_amd.model import NoisePredNet
+    from ditreeonlineplanner_amd.ops import Context
+    Bglob = args.global_batch or (args.batch * world if args.batch_set else 8192)
+    if Bglob % world:
+        raise SystemExit("--global-batch must divide by the number of GPUs")
+    Bper = Bglob // world
+    maze = load_maze("boxes")
+    nodes, goal, samples, cond, noise = synth_inputs(maze, Bglob)
+    ctx = Context(local)
+    dev = ctx.device
+    net = NoisePredNet(seed=0)
+    net.bind(ctx, precision=_lib.PREC_NAMES[args.precision], max_batch=Bper)
+    eng = ExpansionEngine(ctx, maze, nodes[0], goal, edge_length=H, action_horizon=A, pred_horizon=P, batch=Bglob,
+                          capacity=N0 + Bglob, rank=rank, world_size=world, emulate_sticky_done=False)
+    t = eng.tree
+    nd = torch.as_tensor(nodes, device=dev)
+    t.state[:N0] = nd
+    t.xy[:N0] = nd[:, :2]
+    t.parent[:N0] = torch.arange(-1, N0 - 1, device=dev, dtype=torch.int32).clamp(min=0)
+    t.parent[0] = -1
+    t.has_prev[:N0] = 1
+
+    def reset_tree():
+        t.counters[CNT_NODES] = N0
+        t.counters[CNT_GOAL] = -1
+        t.counters[CNT_LATCH] = 0
+        t.n_nodes_host = N0
+    reset_tree()
+    s_dev = torch.as_tensor(samples, device=dev)
+    c_dev = torch.as_tensor(cond, device=dev)
+    n_dev = noise.to(dev)
+    true_maze = torch.as_tensor(maze.astype(np.float32), device=dev)
+    lo, hi, _ = eng.shard(Bglob)
+    Hh, W = maze.shape
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    it = [0]
+    keep = {}
+
+    def step():
+        eng.expand_round(s_dev, c_dev, noise=n_dev)
+        reset_tree()
+        # pose in cell units (x_col, y_row, yaw) of this rank's candidates' end states (scan_and_update_maze, :112-127)
+        es = eng.rb.end_state[lo:hi]
+        poses = torch.stack([es[:, 0] + W / 2, Hh / 2 - es[:, 1], es[:, 2]], dim=1).contiguous()
+        timed = it[0] >= args.warmup
+        if timed:
+            ev[it[0] - args.warmup][0].record()
+        keep["scan"] = ctx.lidar_scan(poses, true_maze, want_visited=True)
+        if timed:
+            ev[it[0] - args.warmup][1].record()
+        it[0] += 1
+
+    elapsed = _timed(step, args, dist, world, dev, rehearse)
+    if rank == 0:
+        avg_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+        alg = Bper * (24 + 181 * 25) + maze.size * 4 + Bper * maze.size          # poses + per-ray outputs + maze + visited bitmap
+        ach = alg / (avg_ms * 1e-3) / 1e9
+        res = {"metric": "candidate tree-expansions/sec (carmaze, H=32, lidar scan per candidate end pose)",
+               "value": Bglob * args.steps / elapsed, "unit": "candidate expansions/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+               "config": {"workload": f"BASELINE config 4: carmaze round of {Bglob} candidates (global) + one 181-ray lidar scan per "
+                                      f"candidate end pose, boxes.csv, {N0}-node snapshot, seeded random weights",
+                          "global_batch": Bglob, "batch_per_gpu": Bper, "parallelism": f"candidates sharded x{world}"},
+               "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                            "traffic": None, "kernel": "lidar_scan_kernel", "avg_launch_ms": avg_ms,
+                            "algorithmic_bytes_per_launch": alg, "kernel_time_share": avg_ms * 1e-3 * args.steps / elapsed,
+                            "note": "the round itself is MFMA-bound (see the default workload); this is the lidar kernel's line"}}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_ant_denoise(args):
+    """BASELINE config 3 (cfgs/antmaze.yaml + fm_policy, B = 4096 candidates, H = 48): the part of it that has an oracle --
+    per candidate 24 chunks (action_horizon 2) x [16 x 16 @ 0.8 local map (s_global 4), ant conditioning vector incl.
+    quaternion -> rot6d, ResNet-18-GN encoder on 16 x 16, FiLM U-Net at input_dim 8 / pred_horizon 16 / cond 497, flow
+    step, un-normalise] = 24 x 1.536 GFLOP = 36.86 GFLOP.  The MuJoCo dynamics between the chunks have no oracle here and
+    are not built: the candidate states stay where they are, i.e. this is "denoiser + glue only"."""
+    rank, world, local, dist, rehearse = _dist_setup(args)
+    from ditreeonlineplanner_amd import _lib
+    from ditreeonlineplanner_amd.model import NoisePredNet
+    from ditreeonlineplanner_amd.ops import Context
+    B = args.batch if args.batch_set else 4096
+    n_calls = 48 // 2
+    prec = args.precision if args.precision_set else "bf16"
+    if prec in ("f16x3", "bf16x3"):
+        raise SystemExit("the split instantiations need pred_horizon % 64 == 0; the ant config runs 16-step sequences")
+    maze = load_maze("boxes")
+    ctx = Context(local)
+    dev = ctx.device
+    ctx.upload_maze(maze)
+    net = NoisePredNet(input_dim=8, additional_global_cond_dim=97, pred_horizon=16, local_map_size=16, seed=0)
+    net.bind(ctx, precision=_lib.PREC_NAMES[prec], max_batch=B)
+    rng = np.random.default_rng(20260104 + rank)
+    Hh, W = maze.shape
+    obs = rng.normal(0.0, 1.0, (B, 3, 29))
+    free = np.argwhere(maze[1:-1, 1:-1] == 0) + 1
+    cell = free[rng.integers(0, len(free), B)]
+    obs[:, :, 0] = (((cell[:, 1] + 0.5) - W / 2) * 4.0)[:, None]
+    obs[:, :, 1] = ((Hh / 2 - (cell[:, 0] + 0.5)) * 4.0)[:, None]
+    obs[..., 2] = rng.uniform(0.4, 0.8, (B, 3))
+    q = rng.normal(size=(B, 3, 4))
+    obs[..., 3:7] = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    obs_d = torch.as_tensor(obs, device=dev)
+    last = obs_d[:, -1, :].contiguous()
+    prev = torch.as_tensor(rng.uniform(-1, 1, (B, 8)), device=dev)
+    hasp = torch.ones(B, dtype=torch.uint8, device=dev)
+    goal = torch.as_tensor(rng.uniform(-30, 30, (B, 2)), device=dev)
+    g = torch.Generator(device="cpu").manual_seed(20260104)
+    noise = torch.randn(n_calls, B, 16, 8, generator=g).to(dev)
+    with open(os.path.join(REPO, "ditreeonlineplanner_amd", "data", "metadata_antmaze.json")) as f:
+        md = json.load(f)
+    norm = np.array(md["Observations_mean"] + md["Observations_std"] + md["Actions_mean"] + md["Actions_std"])
+    act_norm = np.array(md["Actions_mean"] + md["Actions_std"])
+    lm = torch.empty(B, 16, 16, dtype=torch.float32, device=dev)
+
+    def step():
+        for j in range(n_calls):
+            ctx.local_map(last, n=16, scale=0.8, s_global=4.0, scaled=True, out=lm)
+            cond = ctx.cond_vector_ant(obs_d, prev, hasp, goal, 16, norm)
+            ctx.denoise(noise[j], lm, cond, act_norm=act_norm, want_actions=True)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile(1)
+    elapsed = _timed(step, dataclass_replace(args, warmup=0), dist, world, dev, rehearse)
+    prof = ctx.profile_read()
+    ctx.profile(0)
+    if rank == 0:
+        mac = 752_250_880 + 15_749_120
+        alg = 2.0 * mac * B * n_calls * args.steps
+        all_ms = sum(v["ms"] for v in prof.values())
+        peak = 157.3 if prec == "f32" else PEAK_BF16_TFLOPS
+        ach = alg / (all_ms * 1e-3) / 1e12
+        res = {"metric": "candidate tree-expansions/sec (antmaze, H=48; denoiser + glue only, dynamics blocked on an oracle)",
+               "value": B * world * args.steps / elapsed, "unit": "candidate expansions/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": prec, "data": "synthetic",
+               "config": {"workload": f"BASELINE config 3: cfgs/antmaze.yaml + fm_policy, batch={B} candidates per GPU, H=48 = 24 chunks x "
+                                      "[local map 16x16@0.8 s_global 4, ant cond vector (rot6d), encoder + U-Net P=16 D=8 cond 497, flow step]; "
+                                      "NO dynamics (MuJoCo: no oracle)", "batch_per_gpu": B, "calls_per_candidate": n_calls},
+               "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                            "kernel": "all MFMA kernels of the denoiser (L = 8 / 4 levels on conv_gemm_kernel + gn1d_kernel, unfused)",
+                            "per_kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
+                            "algorithmic_gflop_per_candidate": 2.0 * mac * n_calls / 1e9,
+                            "note": "events around every MFMA launch inside the timed region (costs a few %)"}}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def dataclass_replace(args, **kw):
+    import copy
+    a = copy.copy(args)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="expand", choices=["expand", "rollout", "lidar-round", "ant-denoise"])
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="fixed GLOBAL round size split over the GPUs (strong scaling); default: --batch per GPU (weak)")
+    ap.add_argument("--horizon", type=int, default=0, help="rollout workload: steps per rollout (default 16)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -124,6 +414,14 @@ def main():
     ap.add_argument("--no-early-exit-line", action="store_true",
                     help="skip the extra (informational) timing with alive-candidate compaction")
     args = ap.parse_args()
+    args.batch_set = any(a == "--batch" or a.startswith("--batch=") for a in sys.argv[1:])
+    args.precision_set = any(a == "--precision" or a.startswith("--precision=") for a in sys.argv[1:])
+    if args.workload == "rollout":
+        return run_rollout(args)
+    if args.workload == "lidar-round":
+        return run_lidar_round(args)
+    if args.workload == "ant-denoise":
+        return run_ant_denoise(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,6 +454,11 @@ def main():
 
     Bper = args.batch
     Btot = Bper * world
+    if args.global_batch:                      # strong scaling: a fixed global round split over the ranks
+        if args.global_batch % world:
+            raise SystemExit("--global-batch must divide by the number of GPUs")
+        Btot = args.global_batch
+        Bper = Btot // world
     maze = load_maze("boxes")
     nodes, goal, samples, cond, noise = synth_inputs(maze, Btot)
     ctx = Context(local)
@@ -253,8 +556,8 @@ def main():
         out = {
             "metric": "candidate tree-expansions/sec (carmaze, H=32)", "value": value,
             "unit": "candidate expansions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic" + (" (one-GPU rehearsal of N ranks over gloo: not a measurement)" if rehearse else ""),
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic" + (" (one-GPU rehearsal of N ranks over gloo: not a measurement)" if rehearse else ""),
             "config": {"workload": f"cfgs/carmaze.yaml + fm_policy flow sampler (K=1), batch={Bper} candidates per GPU, "
                                    f"H=32 (4 chunks x 8 steps), boxes.csv 20x20, {N0}-node tree snapshot, seeded random weights",
                        "batch_per_gpu": Bper, "global_batch": Btot, "edge_length": H, "action_horizon": A,

@@ -60,7 +60,8 @@ SIGNATURES = {
     "ditree_last_error": (C.c_char_p, [_vp]),
     "ditree_upload_maze": (_i32, [_vp, _pf, _i32, _i32, _vp]),
     "ditree_nn_argmin": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ditree_local_map": (_i32, [_vp, _vp, _vp, _i32, _i32, _pd, _f64, _i32, _vp, _vp]),
+    "ditree_local_map": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _pd, _f64, _i32, _vp, _vp]),
+    "ditree_cond_vector_ant": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _pd, _f64, _vp, _vp]),
     "ditree_cond_vector": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _pd, _f64, _vp, _vp]),
     "ditree_car_rollout": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _pd, _vp, _i64, _vp, _i64, _vp, _vp,
                                   _vp, _vp]),

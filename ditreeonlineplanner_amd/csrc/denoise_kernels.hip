@@ -306,7 +306,8 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
       const int rofs = (i & 3) + 8 * (i >> 2) + 4 * h;         // row within the 16-row block
       const int m = tm * 256 + wm * 64 + (blk >> 1) * 32 + (blk & 1) * 16 + rofs;
       if (m >= p.M || !n_ok) continue;
-      const int b = blk_b[blk], l = blk_l[blk] + rofs;
+      int b = blk_b[blk], l = blk_l[blk] + rofs;
+      if ((p.L & 15) != 0) { b = m / p.L; l = m - b * p.L; }      // short sequences (ant: L = 8, 4): rows of a block span samples
       const long long orow = (long long)b * p.out_Lp + (long long)l * p.out_stride + p.out_off;
       const long long oidx = orow * p.ldc + p.out_coff + n0;
       if (p.out_f32 || PREC == 1) {

@@ -108,18 +108,33 @@ static int fill_axis(ditree_ctx* ctx, const double* axis, int n, AxisArg* a) {
   return DITREE_OK;
 }
 
-int32_t ditree_local_map(ditree_ctx* ctx, const double* state, const int32_t* active, int32_t B, int32_t n,
+int32_t ditree_local_map(ditree_ctx* ctx, const double* state, int32_t state_stride, const int32_t* active, int32_t B, int32_t n,
                          const double* axis, double s_global, int32_t scaled, float* out, void* stream) {
   if (!ctx) return DITREE_E_ARG;
   if (!ctx->maze) return set_err(ctx, DITREE_E_STATE, "local_map: no maze uploaded");
   if (B == 0) return DITREE_OK;
-  if (!state || !out || B < 0) return set_err(ctx, DITREE_E_ARG, "local_map: bad argument");
+  if (!state || !out || B < 0 || state_stride < 3) return set_err(ctx, DITREE_E_ARG, "local_map: bad argument");
   AxisArg a;
   int rc = fill_axis(ctx, axis, n, &a);
   if (rc) return rc;
   if (B == 0) return DITREE_OK;
   launch_local_map(ctx->maze, ctx->rows, ctx->cols, state, active, nullptr, B, n, a, s_global, scaled, out,
-                   (hipStream_t)stream);
+                   (hipStream_t)stream, state_stride);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+int32_t ditree_cond_vector_ant(ditree_ctx* ctx, const double* obs, int32_t n_hist, const double* prev_action,
+                               const uint8_t* has_prev, const double* cond_goal, int32_t B, const double* norm,
+                               double local_map_size, float* out, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (B == 0) return DITREE_OK;
+  if (!obs || !prev_action || !has_prev || !cond_goal || !norm || !out || B < 0 || n_hist < 1 || n_hist > 3)
+    return set_err(ctx, DITREE_E_ARG, "cond_vector_ant: bad argument (1 <= n_hist <= 3)");
+  AntNormArg nm;
+  for (int i = 0; i < 27; ++i) { nm.obs_mean[i] = norm[i]; nm.obs_std[i] = norm[27 + i]; }
+  for (int i = 0; i < 8; ++i) { nm.act_mean[i] = norm[54 + i]; nm.act_std[i] = norm[62 + i]; }
+  launch_cond_vector_ant(obs, n_hist, prev_action, has_prev, cond_goal, B, nm, local_map_size, out, (hipStream_t)stream);
   HIP_TRY(ctx, hipGetLastError());
   return DITREE_OK;
 }

@@ -18,6 +18,10 @@ struct NormArg {
   double obs_mean[6], obs_std[6], act_mean[2], act_std[2];
 };
 
+struct AntNormArg {
+  double obs_mean[27], obs_std[27], act_mean[8], act_std[8];
+};
+
 struct DenoiserState;   // denoise_host.hip
 
 struct ditree_ctx {
@@ -60,7 +64,9 @@ void launch_nn_argmin(const double* queries, int q_stride, int B, const double* 
                       uint8_t* out_has_prev, hipStream_t s);
 void launch_local_map(const unsigned char* maze, int rows, int cols, const double* state,
                       const int32_t* active, const int32_t* idx, int B, int n, const AxisArg& axis,
-                      double s_global, int scaled, float* out, hipStream_t s);
+                      double s_global, int scaled, float* out, hipStream_t s, int state_stride = 6);
+void launch_cond_vector_ant(const double* obs, int n_hist, const double* prev_action, const uint8_t* has_prev,
+                            const double* cond_goal, int B, const AntNormArg& nm, double lm_size, float* out, hipStream_t s);
 void launch_cond_vector(const double* state, const double* prev_action, const uint8_t* has_prev,
                         const double* cond_goal, const int32_t* idx, int B, const NormArg& nm, double lm_size,
                         float* out, hipStream_t s);

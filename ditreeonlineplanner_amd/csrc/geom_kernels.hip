@@ -106,17 +106,19 @@ void launch_nn_argmin(const double* queries, int q_stride, int B, const double* 
 // One workgroup per candidate; maze staged in LDS; one thread per output cell.
 __global__ void __launch_bounds__(256)
 local_map_kernel(const unsigned char* __restrict__ maze, int rows, int cols, const double* __restrict__ state,
-                 const int32_t* __restrict__ active, const int32_t* __restrict__ idx, int n, AxisArg axis,
+                 int state_stride, const int32_t* __restrict__ active, const int32_t* __restrict__ idx, int n, AxisArg axis,
                  double s_global, int scaled, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int ob = blockIdx.x;                                        // dense output row
   const int b = idx ? idx[ob] : ob;                                 // candidate (compacted rounds pass an index list)
   if (active != nullptr && active[b] != DITREE_ST_OK) return;      // block-uniform
   stage_maze(lds, maze, rows * cols);
-  const double x = state[(size_t)b * 6 + 0], y = state[(size_t)b * 6 + 1], th = state[(size_t)b * 6 + 2];
+  // RRT.py:158-166 passes curr_state[0], curr_state[1], curr_state[2] for every env (for the ant, element 2 is the torso
+  // height, not a heading -- the reference's own behaviour, kept)
+  const double x = state[(size_t)b * state_stride + 0], y = state[(size_t)b * state_stride + 1], th = state[(size_t)b * state_stride + 2];
   const double c = cos(th), sn = sin(th);
-  // base_planner.py:113-114 with maze_size_scaling = 1: centre = (W/2, H/2); RRT.py:166
-  const double cx = (double)cols / 2.0, cy = (double)rows / 2.0;
+  // base_planner.py:88-89,100-101,113-114: centre = (W/2, H/2) * maze_size_scaling (car: 1, ant: s_global = 4); RRT.py:166
+  const double cx = (double)cols / 2.0 * s_global, cy = (double)rows / 2.0 * s_global;
   for (int cell = threadIdx.x; cell < n * n; cell += blockDim.x) {
     int i = cell / n, j = cell - i * n;                             // meshgrid: x_local[i][j] = xs[j], y_local = ys[i]
     double xl = axis.v[j], yl = axis.v[i];
@@ -133,9 +135,9 @@ local_map_kernel(const unsigned char* __restrict__ maze, int rows, int cols, con
 }
 void launch_local_map(const unsigned char* maze, int rows, int cols, const double* state, const int32_t* active,
                       const int32_t* idx, int B, int n, const AxisArg& axis, double s_global, int scaled, float* out,
-                      hipStream_t s) {
+                      hipStream_t s, int state_stride) {
   size_t lds = ((size_t)rows * cols + 15) & ~(size_t)15;
-  hipLaunchKernelGGL(local_map_kernel, dim3(B), dim3(256), lds, s, maze, rows, cols, state, active, idx, n, axis,
+  hipLaunchKernelGGL(local_map_kernel, dim3(B), dim3(256), lds, s, maze, rows, cols, state, state_stride, active, idx, n, axis,
                      s_global, scaled, out);
 }
 
@@ -176,6 +178,59 @@ void launch_cond_vector(const double* state, const double* prev_action, const ui
                         float* out, hipStream_t s) {
   hipLaunchKernelGGL(cond_vector_kernel, dim3((B + 255) / 256), dim3(256), 0, s, state, prev_action, has_prev,
                      cond_goal, idx, B, nm, lm_size, out);
+}
+
+// policies/fm_policy.py:60-143, antmaze branch.  obs (B, n_hist, 29) f64: [x, y | 27 observations]; the 27 are normalised
+// (:77), the quaternion is taken FROM THE NORMALISED values (:78, elements 3..6 = x, y, z, w) and replaced by the first two
+// columns of its rotation matrix (common/se3_utils.py:177-189), the last `obs_history` = 3 steps are kept (zero rows in
+// front when fewer are given, :96-102), x, y dropped (:107): 3 x 29 = 87 values; then the previous action (8, normalised;
+// raw zeros when there is none, :113-123) and tanh((goal - position) / local_map_size) with yaw = 0 (:82,125-143).
+__global__ void cond_vector_ant_kernel(const double* __restrict__ obs, int n_hist, const double* __restrict__ prev_action,
+                                       const uint8_t* __restrict__ has_prev, const double* __restrict__ cond_goal, int B,
+                                       AntNormArg nm, double lm_size, float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float* o = out + (size_t)b * 97;
+  for (int hs = 0; hs < 3; ++hs) {                        // slot hs of the 3-step history <- given step hs - (3 - n_hist)
+    const int src = hs - (3 - n_hist);
+    float* oh = o + hs * 29;
+    if (src < 0) {
+      for (int k = 0; k < 29; ++k) oh[k] = 0.0f;
+      continue;
+    }
+    const double* st = obs + ((size_t)b * n_hist + src) * 29;
+    double v[27];
+    for (int k = 0; k < 27; ++k) v[k] = (st[2 + k] - nm.obs_mean[k]) / nm.obs_std[k];
+    // obs_seq[..., 3:7] = v[1..4] = (qx, qy, qz, qw)
+    const double qx = v[1], qy = v[2], qz = v[3], qw = v[4];
+    const double r00 = 1.0 - 2.0 * (qy * qy + qz * qz);
+    const double r10 = 2.0 * (qx * qy + qw * qz);
+    const double r20 = 2.0 * (qx * qz - qw * qy);
+    const double r01 = 2.0 * (qx * qy - qw * qz);
+    const double r11 = 1.0 - 2.0 * (qx * qx + qz * qz);
+    const double r21 = 2.0 * (qy * qz + qw * qx);
+    oh[0] = (float)v[0];                                  // torso height
+    oh[1] = (float)r00; oh[2] = (float)r10; oh[3] = (float)r20; oh[4] = (float)r01; oh[5] = (float)r11; oh[6] = (float)r21;
+    for (int k = 5; k < 27; ++k) oh[2 + k] = (float)v[k];  // obs_seq[..., 7:] -> 22 values
+  }
+  float* oa = o + 87;
+  if (has_prev[b]) {
+    for (int k = 0; k < 8; ++k) oa[k] = (float)((prev_action[(size_t)b * 8 + k] - nm.act_mean[k]) / nm.act_std[k]);
+  } else {
+    for (int k = 0; k < 8; ++k) oa[k] = 0.0f;
+  }
+  const double* last = obs + ((size_t)b * n_hist + (n_hist - 1)) * 29;        // position = obs_seq[:, -1, :2] (:74)
+  const float gx = (float)(cond_goal[(size_t)b * 2 + 0] - last[0]);
+  const float gy = (float)(cond_goal[(size_t)b * 2 + 1] - last[1]);
+  const float sc = (float)lm_size;
+  // yaw = 0: the rotation matrix [[1, 0], [-0, 1]] leaves g unchanged
+  o[95] = tanhf(gx / sc);
+  o[96] = tanhf(gy / sc);
+}
+void launch_cond_vector_ant(const double* obs, int n_hist, const double* prev_action, const uint8_t* has_prev,
+                            const double* cond_goal, int B, const AntNormArg& nm, double lm_size, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(cond_vector_ant_kernel, dim3((B + 127) / 128), dim3(128), 0, s, obs, n_hist, prev_action, has_prev,
+                     cond_goal, B, nm, lm_size, out);
 }
 
 // ------------------------------------------------------------------------- collision

@@ -121,14 +121,38 @@ class Context:
 
     # ------------------------------------------------------------------ local map
     def local_map(self, state, n=20, scale=0.2, s_global=1.0, scaled=False, active=None, out=None):
+        """state (B, >= 3) f64: columns 0, 1, 2 are x, y and the rotation the reference passes (RRT.py:158-166)."""
         dev = self.device
         _chk(state, torch.float64, "state", dev)
+        if state.dim() != 2 or state.shape[1] < 3:
+            raise ValueError("state must be (B, >= 3)")
         B = state.shape[0]
         if out is None:
             out = torch.empty(B, n, n, dtype=torch.float32, device=dev)
         ax, axp = _dbl(local_axis(n, scale))
-        check(self._h, lib().ditree_local_map(self._h, _ptr(state), _ptr(active), B, n, axp, float(s_global),
-                                               int(bool(scaled)), _ptr(out), self.stream), "local_map")
+        check(self._h, lib().ditree_local_map(self._h, _ptr(state), int(state.shape[1]), _ptr(active), B, n, axp,
+                                               float(s_global), int(bool(scaled)), _ptr(out), self.stream), "local_map")
+        return out
+
+    # ------------------------------------------------------------------ cond vector (ant)
+    def cond_vector_ant(self, obs, prev_action, has_prev, cond_goal, local_map_size, norm):
+        """obs (B, n_hist <= 3, 29) f64, prev_action (B, 8) f64, has_prev (B,) u8, cond_goal (B, 2) f64 -> (B, 97) f32
+        (policies/fm_policy.py:60-143, antmaze branch); norm = obs_mean[27] + obs_std[27] + act_mean[8] + act_std[8]."""
+        dev = self.device
+        _chk(obs, torch.float64, "obs", dev)
+        _chk(prev_action, torch.float64, "prev_action", dev)
+        _chk(has_prev, torch.uint8, "has_prev", dev)
+        _chk(cond_goal, torch.float64, "cond_goal", dev)
+        if obs.dim() != 3 or obs.shape[2] != 29 or not 1 <= obs.shape[1] <= 3 or prev_action.shape[1] != 8:
+            raise ValueError("obs must be (B, 1..3, 29), prev_action (B, 8)")
+        B = obs.shape[0]
+        out = torch.empty(B, 97, dtype=torch.float32, device=dev)
+        nm, nmp = _dbl(norm)
+        if nm.size != 70:
+            raise ValueError("norm: 27 + 27 + 8 + 8 doubles")
+        check(self._h, lib().ditree_cond_vector_ant(self._h, _ptr(obs), int(obs.shape[1]), _ptr(prev_action), _ptr(has_prev),
+                                                     _ptr(cond_goal), B, nmp, float(local_map_size), _ptr(out),
+                                                     self.stream), "cond_vector_ant")
         return out
 
     # ------------------------------------------------------------------ cond vector
@@ -147,18 +171,22 @@ class Context:
         return out
 
     # ------------------------------------------------------------------ rollout
-    def car_rollout(self, state, actions, goal_xy, A=8, status=None, prev_action=None, has_prev=None):
+    def car_rollout(self, state, actions, goal_xy, A=8, status=None, prev_action=None, has_prev=None, out=None):
         """state (B,6) f64 [updated in place], actions (B, n>=A, 2) f64.
-        Returns (status, states (B,A+1,6), actions_out (B,A,2), steps)."""
+        Returns (status, states (B,A+1,6), actions_out (B,A,2), steps).  ``out``: a previous return value whose
+        buffers are reused (the kernel writes every row, so no clearing is needed)."""
         dev = self.device
         _chk(state, torch.float64, "state", dev)
         _chk(actions, torch.float64, "actions", dev)
         B = state.shape[0]
         if status is None:
             status = torch.zeros(B, dtype=torch.int32, device=dev)
-        states = torch.zeros(B, A + 1, 6, dtype=torch.float64, device=dev)
-        aout = torch.zeros(B, A, 2, dtype=torch.float64, device=dev)
-        steps = torch.zeros(B, dtype=torch.int32, device=dev)
+        if out is not None and tuple(out[1].shape) == (B, A + 1, 6):
+            _, states, aout, steps = out
+        else:
+            states = torch.zeros(B, A + 1, 6, dtype=torch.float64, device=dev)
+            aout = torch.zeros(B, A, 2, dtype=torch.float64, device=dev)
+            steps = torch.zeros(B, dtype=torch.int32, device=dev)
         g, gp = _dbl(goal_xy)
         check(self._h, lib().ditree_car_rollout(self._h, _ptr(state), _ptr(actions), actions.shape[1] * 2,
                                                  _ptr(status), B, A, gp, _ptr(states), (A + 1) * 6, _ptr(aout),

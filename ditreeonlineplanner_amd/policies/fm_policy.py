@@ -48,12 +48,16 @@ class DiffusionSampler(nn.Module):
                  position_conditioned=False, goal_conditioned=True, local_map_conditioned=True, local_map_size=16,
                  metadata=None, ctx=None, precision=None):
         super().__init__()
-        if "car" not in env_id.lower() or policy not in ("flow_matching", "diffusion") or prediction_type != "actions":
-            raise NotImplementedError("covered: carmaze, flow_matching / diffusion, action prediction")
+        self.is_ant = "ant" in env_id.lower()
+        if not ("car" in env_id.lower() or self.is_ant) or policy not in ("flow_matching", "diffusion") or prediction_type != "actions":
+            raise NotImplementedError("covered: carmaze and antmaze, flow_matching / diffusion, action prediction")
         if policy == "diffusion" and noise_scheduler is None:
             raise ValueError("policy='diffusion' needs a noise scheduler (set_timesteps / timesteps / step)")
-        if obs_history != 1 or action_history != 1 or position_conditioned or not goal_conditioned:
-            raise NotImplementedError("car config: obs_history = action_history = 1, goal conditioned")
+        if action_history != 1 or position_conditioned or not goal_conditioned or obs_history != (3 if self.is_ant else 1):
+            raise NotImplementedError("covered: car (obs_history 1) and ant (obs_history 3, run_scenarios.py:123-132), "
+                                      "action_history 1, goal conditioned")
+        if action_dim != (8 if self.is_ant else 2):
+            raise NotImplementedError("action_dim: 2 (car) or 8 (ant)")
         self.metadata = metadata if metadata is not None else load_metadata(env_id)
         self.env_id, self.policy, self.prediction_type = env_id, policy, prediction_type
         self.action_dim, self.pred_horizon = action_dim, pred_horizon
@@ -87,6 +91,10 @@ class DiffusionSampler(nn.Module):
 
     def ensure_bound(self, max_batch):
         net = self.noise_pred_net
+        # what the tensor shapes do not tell the library: sequence length and map size come from the sampler
+        if net.pred_horizon != self.pred_horizon or net.local_map_size != self.local_map_size:
+            net.pred_horizon, net.local_map_size = self.pred_horizon, self.local_map_size
+            net._ctx = None
         if not net.is_current(self.ctx) or net.precision != self.precision:
             net.bind(self.ctx, precision=self.precision)
         net.reserve(max_batch)
@@ -100,6 +108,8 @@ class DiffusionSampler(nn.Module):
         if obs_seq.ndim == 2:
             obs_seq = obs_seq[:, None]
         B = obs_seq.shape[0]
+        if self.is_ant:
+            return self._forward_ant(obs_seq, prev_actions, goal, local_map)
         state = torch.as_tensor(np.ascontiguousarray(obs_seq[:, -1, :]), device=dev)           # obs_history = 1
         if prev_actions is not None:
             pa = np.asarray(prev_actions, dtype=np.float64)
@@ -136,3 +146,45 @@ class DiffusionSampler(nn.Module):
             return x * self.metadata["Actions_std"] + self.metadata["Actions_mean"]          # :201-203
         actions = ctx.denoise(noise, lm, cond, t0=self.t0, dt=self.dt, act_norm=self.norm[12:16], want_actions=True)
         return actions.cpu().numpy()
+
+
+def _forward_ant(self, obs_seq, prev_actions, goal, local_map):
+    """policies/fm_policy.py:53-212, antmaze branch: (B, h, 29) observations -> (B, 16, 8) float64 actions."""
+    ctx = self.ctx
+    dev = ctx.device
+    B = obs_seq.shape[0]
+    if obs_seq.shape[2] != 29:
+        raise ValueError("antmaze observations are (B, h, 29): x, y + the 27 MuJoCo observations")
+    hist = np.ascontiguousarray(obs_seq[:, -3:, :])                                          # :96-102
+    if prev_actions is not None:
+        pa = np.asarray(prev_actions, dtype=np.float64)
+        if pa.ndim == 2:
+            pa = pa[None]
+        last = np.zeros((B, 8)) if pa.shape[1] == 0 else np.broadcast_to(pa[:, -1, :], (B, 8))
+        has_prev = np.ones(B, dtype=np.uint8)
+    else:
+        last, has_prev = np.zeros((B, 8)), np.zeros(B, dtype=np.uint8)
+    g = np.broadcast_to(np.asarray(goal, dtype=np.float64).reshape(-1, 2), (B, 2))
+    norm = np.concatenate([self.metadata["Observations_mean"], self.metadata["Observations_std"],
+                           self.metadata["Actions_mean"], self.metadata["Actions_std"]]).astype(np.float64)
+    cond = ctx.cond_vector_ant(torch.as_tensor(hist, device=dev), torch.as_tensor(np.ascontiguousarray(last), device=dev),
+                               torch.as_tensor(has_prev, device=dev),
+                               torch.as_tensor(np.ascontiguousarray(g, dtype=np.float64), device=dev), self.local_map_size, norm)
+    lm = torch.as_tensor(local_map, dtype=torch.float32, device=dev)
+    if lm.dim() == 2:
+        lm = lm.unsqueeze(0)
+    lm = (lm * 2 - 1).contiguous()
+    noise = torch.randn((B, self.pred_horizon, self.action_dim), device=dev)
+    self.ensure_bound(B)
+    if self.policy == "diffusion":
+        self.noise_scheduler.set_timesteps(self.num_diffusion_iters)
+        naction = noise
+        for i, k in enumerate(self.noise_scheduler.timesteps):
+            noise_pred = ctx.denoise_eval(naction.contiguous(), lm, cond, float(k), reuse_encoder=i > 0)
+            naction = self.noise_scheduler.step(model_output=noise_pred, timestep=k, sample=naction).prev_sample.to(torch.float32)
+        return naction.detach().to("cpu").numpy() * self.metadata["Actions_std"] + self.metadata["Actions_mean"]
+    act_norm = np.concatenate([self.metadata["Actions_mean"], self.metadata["Actions_std"]])
+    return ctx.denoise(noise, lm, cond, t0=self.t0, dt=self.dt, act_norm=act_norm, want_actions=True).cpu().numpy()
+
+
+DiffusionSampler._forward_ant = _forward_ant

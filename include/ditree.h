@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DITREE_VERSION 100          /* 0.1.0 */
+#define DITREE_VERSION 200          /* 0.1.0 */
 
 #define DITREE_OK 0
 #define DITREE_E_ARG (-1)           /* bad argument (null pointer, size out of range) */
@@ -73,13 +73,25 @@ int32_t ditree_nn_argmin(ditree_ctx* ctx, const double* queries, int32_t q_strid
                          double* out_prev_action, uint8_t* out_has_prev, void* stream);
 
 /* common/map_utils.py:391-459 create_local_map on the uploaded maze.
- *   state [dev] (B, 6) f64 (x, y, psi used); active [dev] (B,) i32 or NULL: rows with
+ *   state [dev] (B, state_stride) f64, elements 0, 1, 2 used as x, y, psi (car: stride 6; the reference passes
+ *   curr_state[2] for every env, planners/RRT.py:158-166, so the ant -- stride 29 -- rotates by its torso height);
+ *   active [dev] (B,) i32 or NULL: rows with
  *   active[b] != DITREE_ST_OK are skipped;  axis [host] n doubles = the reference's
  *   np.linspace(-L/2 + s/2, L/2 - s/2, n) (map_utils.py:422-423), uploaded into ctx.
  *   out [dev] (B, n, n) f32; values m, or 2m-1 when scaled != 0 (policies/fm_policy.py:152). */
-int32_t ditree_local_map(ditree_ctx* ctx, const double* state, const int32_t* active, int32_t B,
-                         int32_t n, const double* axis, double s_global, int32_t scaled,
+int32_t ditree_local_map(ditree_ctx* ctx, const double* state, int32_t state_stride, const int32_t* active,
+                         int32_t B, int32_t n, const double* axis, double s_global, int32_t scaled,
                          float* out, void* stream);
+
+/* policies/fm_policy.py:60-143, antmaze branch (obs_history 3, action_history 1, run_scenarios.py:123-132):
+ * conditioning vector (B, 97) f32 = 3 x [z, rot6d(normalised quaternion) (6), joints + velocities (22)] | previous action
+ * (8, normalised; raw zeros when has_prev == 0) | tanh((goal - position) / local_map_size) (2, yaw = 0).
+ *   obs [dev] (B, n_hist, 29) f64, 1 <= n_hist <= 3 (missing steps are zero rows in front, fm_policy.py:96-102);
+ *   prev_action [dev] (B, 8) f64; has_prev [dev] (B,) u8; cond_goal [dev] (B, 2) f64;
+ *   norm [host] 70 doubles: obs_mean[27], obs_std[27], act_mean[8], act_std[8] (metadata/antmaze.pt). */
+int32_t ditree_cond_vector_ant(ditree_ctx* ctx, const double* obs, int32_t n_hist, const double* prev_action,
+                               const uint8_t* has_prev, const double* cond_goal, int32_t B, const double* norm,
+                               double local_map_size, float* out, void* stream);
 
 /* policies/fm_policy.py:60-143 (car): conditioning vector (B, 7) f32 =
  * [(v-5)/5, (D-.5)/.5, delta/.4 | (a_prev-mu)/sigma or 0,0 | tanh(R(-psi)(g-p)/lm_size)].

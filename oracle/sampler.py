@@ -21,6 +21,59 @@ CAR_META = {
 }
 
 
+def _load_ant_meta():
+    """metadata/antmaze.pt of the reference: raw buffers read with pickletools (tests/golden/extract_metadata.py writes
+    ditreeonlineplanner_amd/data/metadata_antmaze.json; nothing is unpickled)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ditreeonlineplanner_amd", "data",
+                        "metadata_antmaze.json")
+    with open(path) as f:
+        d = json.load(f)
+    return {k: np.asarray(v, dtype=np.float64) for k, v in d.items() if not k.startswith("_")}
+
+
+ANT_META = _load_ant_meta()
+
+
+def q_to_rot6d(q):
+    """common/se3_utils.py:177-189 (q = [x, y, z, w])."""
+    qw, qx, qy, qz = q[..., 3], q[..., 0], q[..., 1], q[..., 2]
+    return np.stack([1 - 2 * (qy ** 2 + qz ** 2), 2 * (qx * qy + qw * qz), 2 * (qx * qz - qw * qy),
+                     2 * (qx * qy - qw * qz), 1 - 2 * (qx ** 2 + qz ** 2), 2 * (qy * qz + qw * qx)], axis=-1)
+
+
+def ant_cond_vector(obs_seq, prev_action, has_prev, goal_xy, local_map_size=16, obs_history=3, meta=None):
+    """fm_policy.py:60-143 for antmaze (obs_history 3, action_history 1, position_conditioned False).
+
+    obs_seq (B, h, 29) f64 with h <= obs_history given steps; prev_action (B, 8); has_prev (B,) bool (False = the
+    reference's ``prev_actions is None``: raw zeros); goal_xy (B, 2) or (2,).  Returns float32 (B, 97)."""
+    meta = ANT_META if meta is None else meta
+    obs = np.array(obs_seq, dtype=np.float64, copy=True)
+    B = obs.shape[0]
+    position = obs[:, -1, :2].copy()                                                        # :74
+    obs[..., 2:] = (obs[..., 2:] - meta["Observations_mean"]) / meta["Observations_std"]    # :77
+    rot = q_to_rot6d(obs[..., 3:7])                                                         # :78-79 (normalised quaternion)
+    obs = np.concatenate([obs[..., :3], rot, obs[..., 7:]], axis=-1)                        # :80
+    cond = np.zeros((B, obs_history, obs.shape[-1]))
+    pad = obs_history - obs.shape[1]
+    if pad > 0:
+        cond[:, pad:, :] = obs
+    else:
+        cond[:, :] = obs[:, -obs_history:, :]
+    obs_cond = torch.from_numpy(cond)[..., 2:].flatten(start_dim=1).to(torch.float32)        # :107,:112
+    act = np.zeros((B, 8))
+    hp = np.asarray(has_prev, dtype=bool)
+    act[hp] = (np.asarray(prev_action, dtype=np.float64)[hp] - meta["Actions_mean"]) / meta["Actions_std"]
+    act_cond = torch.from_numpy(act).to(torch.float32)
+    g = torch.tensor(np.broadcast_to(np.asarray(goal_xy, dtype=np.float64), (B, 2)) - position).float()
+    yaw = torch.zeros(B, dtype=torch.float32)                                               # :82
+    c, sn = torch.cos(yaw), torch.sin(yaw)
+    rotm = torch.stack([torch.stack([c, sn], dim=1), torch.stack([-sn, c], dim=1)], dim=1)
+    g = torch.tanh(torch.matmul(rotm, g.unsqueeze(2)).squeeze(2) / local_map_size)
+    return torch.cat([obs_cond, act_cond, g], dim=1).numpy()
+
+
 def get_timesteps(schedule: str, k_steps: int, exp_scale: float = 1.0):
     """common/fm_utils.py:4-17 (torch float32 arithmetic, as the reference)."""
     t = torch.linspace(0, 1, k_steps + 1)[:-1]

@@ -175,6 +175,42 @@ def gen_sampler(out):
     print(f"sampler pre/post: oracle vs reference max |d cond| = {err:.2e}")
 
 
+def gen_sampler_ant(out):
+    """The antmaze branch of the reference's DiffusionSampler.forward (quaternion -> rot6d of the normalised values, 3-step
+    history with front padding, 8-d previous action, yaw = 0) on a recording net; 1-, 2- and 3-step histories, with and
+    without a previous action."""
+    rng = np.random.default_rng(107)
+    n = 48
+    obs = rng.normal(0.0, 1.0, (n, 3, 29))
+    obs[..., :2] = rng.uniform(-18, 18, (n, 3, 2))
+    obs[..., 2] = rng.uniform(0.3, 0.9, (n, 3))
+    q = rng.normal(size=(n, 3, 4))
+    obs[..., 3:7] = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    prev = rng.uniform(-1, 1, (n, 8))
+    has_prev = rng.random(n) < 0.7
+    n_hist = rng.integers(1, 4, n)
+    goals = rng.uniform(-18, 18, (n, 2))
+    conds, acts = [], []
+    for i in range(n):
+        net = _RecordingNet()
+        smp = _ref_sampler(net)
+        smp.metadata = {k: v.copy() for k, v in OS.ANT_META.items()}
+        smp.action_dim, smp.env_id, smp.pred_horizon, smp.obs_history, smp.local_map_size = 8, "antmaze", 16, 3, 16
+        hist = obs[i, 3 - n_hist[i]:][None]
+        pa = prev[i][None, None] if has_prev[i] else None
+        torch.manual_seed(2000 + i)
+        a = smp(hist, prev_actions=pa, goal=goals[i], local_map=torch.zeros(1, 16, 16))
+        c = net.calls[0]
+        assert c["sample"].shape == (1, 16, 8) and c["cond"].shape == (1, 97)
+        conds.append(c["cond"].numpy()[0])
+        acts.append(a[0])
+        mine = OS.ant_cond_vector(hist, prev[i][None], has_prev[i:i + 1], goals[i])
+        assert np.abs(mine - conds[-1]).max() < 2e-7, (i, np.abs(mine - conds[-1]).max())
+    out.update(sampler_ant_obs=obs, sampler_ant_n_hist=n_hist, sampler_ant_prev=prev, sampler_ant_has_prev=has_prev,
+               sampler_ant_goals=goals, sampler_ant_cond_expected=np.array(conds))
+    print("ant sampler pre-processing: oracle == reference on", n, "cases")
+
+
 def gen_timesteps(out_json):
     res = {}
     for k in (1, 2, 4, 5, 8, 16):
@@ -738,6 +774,11 @@ def main():
         gen_prob_maps({})
         gen_traces_run_type23({})
         return
+    if sys.argv[1:] == ["ant"]:               # add the ant sampler fixtures to network.npz (other entries kept)
+        net = dict(np.load(os.path.join(HERE, "network.npz"), allow_pickle=False))
+        gen_sampler_ant(net)
+        np.savez_compressed(os.path.join(HERE, "network.npz"), **net)
+        return
     if sys.argv[1:] == ["online"]:
         online = {}
         gen_online(online)
@@ -750,6 +791,7 @@ def main():
     gen_kdtree(geo)
     gen_dynamics(geo)
     gen_sampler(net)
+    gen_sampler_ant(net)
     gen_timesteps(meta)
     gen_unet(net)
     gen_traces(traces)

@@ -1,0 +1,130 @@
+"""BASELINE config 3 (cfgs/antmaze.yaml + fm_policy): the ant-sized denoiser and its glue on the GPU.
+
+The ant's DYNAMICS (MuJoCo through gymnasium-robotics) have no oracle here and are not built; everything
+around them is: sampler pre-processing incl. quaternion -> rot6d (policies/fm_policy.py:77-82, common/se3_utils.py:177-189),
+the 16 x 16 @ 0.8 local map with s_global = 4 (run_scenarios.py:123-132; tests/test_gpu_geometry.py), and the denoiser at
+input_dim 8, pred_horizon 16, cond 97 (+ 400).  The oracle's U-Net at these dimensions is bit-identical to the reference class
+(golden `unet_ant_*`, tests/test_oracle_golden.py); its sampler pre-processing equals the reference on the `sampler_ant_*` cases."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser as OD
+from oracle import sampler as OS
+from tests.util import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    return t if dtype is None else t.to(dtype)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from ditreeonlineplanner_amd.ops import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def ant_norm():
+    m = OS.ANT_META
+    return np.concatenate([m["Observations_mean"], m["Observations_std"], m["Actions_mean"], m["Actions_std"]])
+
+
+def test_cond_vector_ant_matches_reference_cases(ctx):
+    g = golden("network")
+    obs, nh = g["sampler_ant_obs"], g["sampler_ant_n_hist"]
+    for h in (1, 2, 3):                     # the kernel takes one history length per launch
+        rows = np.nonzero(nh == h)[0]
+        if rows.size == 0:
+            continue
+        out = ctx.cond_vector_ant(dev(obs[rows][:, 3 - h:]), dev(g["sampler_ant_prev"][rows]),
+                                  dev(g["sampler_ant_has_prev"][rows].astype(np.uint8)), dev(g["sampler_ant_goals"][rows]),
+                                  16, ant_norm()).cpu().numpy()
+        exp = g["sampler_ant_cond_expected"][rows]
+        assert np.abs(out - exp).max() < 2e-6, (h, np.abs(out - exp).max())
+        if h < 3:                           # missing history steps are zero rows in front
+            assert np.array_equal(out[:, : (3 - h) * 29], np.zeros((rows.size, (3 - h) * 29), dtype=np.float32))
+        nop = ~g["sampler_ant_has_prev"][rows]
+        assert np.array_equal(out[nop, 87:95], np.zeros((int(nop.sum()), 8), dtype=np.float32))
+    with pytest.raises(ValueError):
+        ctx.cond_vector_ant(dev(obs[:2, :, :28].copy()), dev(g["sampler_ant_prev"][:2]), dev(np.ones(2, dtype=np.uint8)),
+                            dev(g["sampler_ant_goals"][:2]), 16, ant_norm())
+
+
+@pytest.fixture(scope="module")
+def ant_net():
+    torch.manual_seed(0)
+    net = OD.init_noise_pred_net(input_dim=8, action_dim=8, obs_dim=29, obs_history=3, action_history=1).eval()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.2 * torch.randn(p.shape, generator=g))
+    return net
+
+
+# precision -> relative L2 bound on the flow-step output (the L = 8 and L = 4 levels run the unfused GEMM + GroupNorm kernels)
+ANT_TOL = {1: 1e-5, 4: 2e-3, 0: 1.6e-2}
+
+
+@pytest.mark.parametrize("prec", [1, 4, 0])
+def test_ant_denoiser_against_oracle(ctx, ant_net, prec):
+    from ditreeonlineplanner_amd.model import NoisePredNet
+    g = torch.Generator().manual_seed(21)
+    B = 24
+    noise = torch.randn(B, 16, 8, generator=g)
+    cond = torch.randn(B, 97, generator=g) * 0.6
+    lm = (torch.rand(B, 16, 16, generator=g) < 0.3).float() * 2 - 1
+    net = NoisePredNet(input_dim=8, additional_global_cond_dim=97, pred_horizon=16, local_map_size=16)
+    net.load_state_dict(ant_net.state_dict())
+    net.bind(ctx, precision=prec, max_batch=B)
+    assert ctx.denoise_dims() == (16, 8, 16, 97, 400)
+    x_ref = OS.flow_sample(ant_net, noise, lm, cond, k_steps=1)
+    x = ctx.denoise(noise.cuda(), lm.cuda(), cond.cuda(), act_norm=np.concatenate([np.zeros(8), np.ones(8)]),
+                    want_actions=False).cpu().numpy()
+    r = float(np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref))
+    assert r < ANT_TOL[prec], (prec, r)
+    # un-normalised f64 actions with the ant statistics, and a ragged sub-batch
+    a = ctx.denoise(noise[:5].cuda().contiguous(), lm[:5].cuda().contiguous(), cond[:5].cuda().contiguous(),
+                    act_norm=np.concatenate([OS.ANT_META["Actions_mean"], OS.ANT_META["Actions_std"]]), want_actions=True)
+    assert a.dtype == torch.float64 and a.shape == (5, 16, 8)
+    assert np.abs(a.cpu().numpy() - x[:5].astype(np.float64)).max() < (1e-6 if prec == 1 else 1e-1)
+    # wrong shapes are refused, not mis-strided
+    with pytest.raises(ValueError):
+        ctx.denoise(torch.zeros(B, 64, 2, device="cuda"), lm.cuda(), cond.cuda(), want_actions=False)
+    # the split instantiations have no tiles for 16-step sequences: a clean error
+    from ditreeonlineplanner_amd._lib import DitreeError
+    with pytest.raises(DitreeError, match="pred_horizon"):
+        net.bind(ctx, precision=2, max_batch=B)
+
+
+def test_ant_sampler_facade(ctx, ant_net):
+    """DiffusionSampler(env_id='antmaze') end to end = explicit pre-processing + denoiser with the same device RNG state."""
+    from ditreeonlineplanner_amd._lib import PREC_F32
+    from ditreeonlineplanner_amd.policies.fm_policy import DiffusionSampler
+    from ditreeonlineplanner_amd.train_diffusion_policy import init_noise_pred_net
+    net = init_noise_pred_net(input_dim=8, action_dim=8, obs_dim=29, obs_history=3, action_history=1, goal_conditioned=True,
+                              goal_dim=2, local_map_conditioned=True, local_map_encoder="resnet", local_map_embedding_dim=400,
+                              local_map_size=16, down_dims=[512, 1024, 2048])
+    net.load_state_dict(ant_net.state_dict())
+    smp = DiffusionSampler(net, None, "antmaze", policy="flow_matching", pred_horizon=16, action_dim=8, prediction_type="actions",
+                           obs_history=3, action_history=1, goal_conditioned=True, num_diffusion_iters=1, local_map_size=16,
+                           ctx=ctx, precision=PREC_F32)
+    gq = golden("network")
+    obs = gq["sampler_ant_obs"][:6]
+    prev = gq["sampler_ant_prev"][:6]
+    goal = gq["sampler_ant_goals"][0]
+    lm01 = (np.random.default_rng(3).random((6, 16, 16)) < 0.3).astype(np.float32)
+    torch.manual_seed(77)
+    a = smp(obs, prev_actions=prev[:, None, :], goal=goal, local_map=lm01)
+    assert a.shape == (6, 16, 8) and a.dtype == np.float64 and np.isfinite(a).all()
+    torch.manual_seed(77)
+    noise = torch.randn((6, 16, 8), device="cuda")
+    cond = OS.ant_cond_vector(obs, prev, np.ones(6, dtype=bool), goal)
+    x_ref = OS.flow_sample(ant_net, noise.cpu(), lm01 * 2 - 1, cond, k_steps=1)
+    a_ref = x_ref.astype(np.float64) * OS.ANT_META["Actions_std"] + OS.ANT_META["Actions_mean"]
+    assert np.abs(a - a_ref).max() < 1e-4, np.abs(a - a_ref).max()

@@ -52,10 +52,11 @@ def test_local_map_bit_exact(ctx):
         ctx.upload_maze(maze)
         for tag, (n, scale, sg) in {"car": (20, 0.2, 1.0), "ant": (16, 0.8, 4.0)}.items():
             poses = g[f"localmap_{name}_{tag}_poses"]
-            if tag == "ant":
-                continue      # the engine's local map assumes map centre at maze_size_scaling 1 (car); ant is out of scope
-            st = np.zeros((len(poses), 6))
+            st = np.zeros((len(poses), 6 if tag == "car" else 29))
             st[:, :3] = poses
+            if tag == "ant":      # generated with positions scaled by s_global = 4 and theta = 0 (make_golden.gen_local_map)
+                st[:, :2] *= sg
+                st[:, 2] = 0.0
             out = ctx.local_map(dev(st), n=n, scale=scale, s_global=sg).cpu().numpy()
             exp = np.unpackbits(g[f"localmap_{name}_{tag}_expected"])[: out.size].reshape(out.shape)
             assert np.array_equal(out.astype(np.uint8), exp), (name, tag)
