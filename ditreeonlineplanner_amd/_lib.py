@@ -46,7 +46,8 @@ class RoundParams(C.Structure):
                 ("noise", C.c_void_p), ("inject_actions", C.c_void_p), ("P", C.c_int32), ("K", C.c_int32),
                 ("t0", C.POINTER(C.c_float)), ("dt", C.POINTER(C.c_float)), ("norm", C.POINTER(C.c_double)),
                 ("goal_xy", C.POINTER(C.c_double)), ("axis", C.POINTER(C.c_double)), ("lm_n", C.c_int32),
-                ("lm_size", C.c_double), ("s_global", C.c_double), ("early_exit", C.c_int32)]
+                ("lm_size", C.c_double), ("s_global", C.c_double), ("early_exit", C.c_int32),
+                ("chunk_budget", C.c_void_p)]
 
 
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
@@ -61,6 +62,7 @@ SIGNATURES = {
     "ditree_upload_maze": (_i32, [_vp, _pf, _i32, _i32, _vp]),
     "ditree_nn_argmin": (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ditree_local_map": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _pd, _f64, _i32, _vp, _vp]),
+    "ditree_chunk_budget": (_i32, [_vp, C.POINTER(Tree), _vp, _i32, _i32, C.POINTER(_i32), _i32, _vp, _vp, _vp]),
     "ditree_cond_vector_ant": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _pd, _f64, _vp, _vp]),
     "ditree_cond_vector": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _pd, _f64, _vp, _vp]),
     "ditree_car_rollout": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _pd, _vp, _i64, _vp, _i64, _vp, _vp,

@@ -288,7 +288,8 @@ struct DenoiserState {
     a.L = L; a.C = C; a.ld = C; a.coff = 0; a.padded = padded; a.fmt = ufmt;
     const size_t bytes = (size_t)Bmax * a.Lp() * C * es();
     a.plane = planes() == 2 ? (long long)bytes : 0;
-    if (bytes >= (1ull << 30)) throw std::runtime_error("activation plane of 1 GiB or more: lower the reserved batch");   // 32-bit buffer offsets
+    // split formats reach the lo plane through a 32-bit buffer offset from the tile base (2 GiB descriptor range)
+    if (planes() == 2 && bytes >= 0x7f000000ull) throw std::runtime_error("activation plane of 2 GiB or more: lower the reserved batch");
     a.p = dalloc(bytes * planes());
     named[name] = a;
     return a;

@@ -1134,7 +1134,16 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
   const int a_plane = (int)p.a_plane, w_plane = (int)p.w_plane;
   const long long K = (long long)p.taps * p.Cin;
 
-  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  // buffer descriptors based at the TILE's first activation row / weight row: the 32-bit offsets below then only span the
+  // tile (a few MB) plus, for the split formats, the distance to the lo plane (< 2 GiB, checked on the host)
+  long long a_tile0;
+  {
+    const int m0 = tm * 256;
+    const int b0 = m0 / p.L, l0 = m0 - b0 * p.L;
+    a_tile0 = (((long long)b0 * p.in_Lp + (long long)l0 * p.in_stride + p.in_off) * p.lda) * 2;
+  }
+  const __amdgpu_buffer_rsrc_t a_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + a_tile0), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.W + ((long long)tn * 256) * K * 2), 0, 0x7fffffff, 0x00020000);
   unsigned pae, pao, pbe, pbo;
@@ -1151,7 +1160,7 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
       const int r0 = (w * 4 + q) * 8;                                // tile row of the piece's first lane row
       const int m = tm * 256 + r0;
       const int b = m / p.L, l = m - b * p.L;
-      aq[q] = (int)((((long long)b * p.in_Lp + (long long)l * p.in_stride + p.in_off) * p.lda) * 2);
+      aq[q] = (int)((((long long)b * p.in_Lp + (long long)l * p.in_stride + p.in_off) * p.lda) * 2 - a_tile0);
       const int cu = (r0 & 128) + 8 * (r0 & 8) + ((r0 >> 4) & 7);    // W: LDS row wn*128 + j*16 + r4 <- channel wn*128 + 8*r4 + j
       wq[q] = (int)((long long)cu * K * 2);
     }

@@ -9,7 +9,8 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
                            int64_t act_stride, int32_t* status_io, int B, int A, double gx, double gy,
                            double* states_out, int64_t states_stride, double* actions_out, int64_t actout_stride,
                            int32_t* steps_out, int64_t steps_stride, int32_t* chunks_run, double* prev_action_io,
-                           uint8_t* has_prev_io, const int32_t* idx, int act_dense, hipStream_t s);
+                           uint8_t* has_prev_io, const int32_t* idx, int act_dense, hipStream_t s, const int32_t* budget,
+                           int chunk_j);
 int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const int32_t* noise_idx, const float* local_map,
                 const float* cond, int B, int K, const float* t0, const float* dt, const double* act_norm, double* actions,
                 float* x_out, hipStream_t s);
@@ -316,6 +317,26 @@ static int ensure_scratch(ditree_ctx* ctx, int B, int lm_n, int P) {
   return DITREE_OK;
 }
 
+int32_t ditree_chunk_budget(ditree_ctx* ctx, const ditree_tree* tree, const double* samples, int32_t B, int32_t n_nodes,
+                            const int32_t* schedule_chunks, int32_t n_schedule, int32_t* parent_scratch, int32_t* budget_out,
+                            void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  int rc = check_tree(ctx, tree);
+  if (rc) return rc;
+  if (B == 0) return DITREE_OK;
+  if (!samples || !schedule_chunks || !parent_scratch || !budget_out || B < 0 || n_schedule < 1 || n_schedule > 16 ||
+      n_nodes <= 0 || n_nodes > tree->capacity)
+    return set_err(ctx, DITREE_E_ARG, "chunk_budget: bad argument (1..16 schedule entries)");
+  for (int i = 0; i < n_schedule; ++i)
+    if (schedule_chunks[i] < 1 || schedule_chunks[i] > tree->n_chunks)
+      return set_err(ctx, DITREE_E_ARG, "chunk_budget: a schedule entry exceeds the tree's edge capacity (n_chunks)");
+  hipStream_t s = (hipStream_t)stream;
+  launch_nn_argmin(samples, 6, B, tree->xy, n_nodes, parent_scratch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+  launch_chunk_budget(parent_scratch, B, tree->num_visit, schedule_chunks, n_schedule, budget_out, s);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
 int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
                             const ditree_round_params* p, void* stream) {
   if (!ctx) return DITREE_E_ARG;
@@ -380,9 +401,9 @@ int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditr
     launch_car_rollout_ex(ctx->maze, ctx->rows, ctx->cols, ctx->cur_state, acts, act_stride, round->status, n_run, A,
                           p->goal_xy[0], p->goal_xy[1], round->states + (size_t)j * (A + 1) * 6, st_stride,
                           round->actions + (size_t)j * A * 2, ac_stride, round->chunk_steps + j, nC,
-                          round->chunks_run, ctx->prev_action, ctx->has_prev, idx, act_dense, s);
+                          round->chunks_run, ctx->prev_action, ctx->has_prev, idx, act_dense, s, p->chunk_budget, j);
     if (p->early_exit && j + 1 < nC) {
-      launch_compact_alive(round->status, B, ctx->alive_idx, ctx->alive_cnt, s);
+      launch_compact_alive(round->status, B, ctx->alive_idx, ctx->alive_cnt, s, p->chunk_budget, j + 1);
       HIP_TRY(ctx, hipMemcpyAsync(ctx->alive_cnt_host, ctx->alive_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, s));
       HIP_TRY(ctx, hipStreamSynchronize(s));
       n_run = *ctx->alive_cnt_host;

@@ -70,7 +70,10 @@ void launch_cond_vector_ant(const double* obs, int n_hist, const double* prev_ac
 void launch_cond_vector(const double* state, const double* prev_action, const uint8_t* has_prev,
                         const double* cond_goal, const int32_t* idx, int B, const NormArg& nm, double lm_size,
                         float* out, hipStream_t s);
-void launch_compact_alive(const int32_t* status, int B, int32_t* idx_out, int32_t* count, hipStream_t s);
+void launch_compact_alive(const int32_t* status, int B, int32_t* idx_out, int32_t* count, hipStream_t s,
+                          const int32_t* budget = nullptr, int next_chunk = 0);
+void launch_chunk_budget(const int32_t* parent, int B, const int32_t* num_visit, const int32_t* chunks, int n,
+                         int32_t* budget, hipStream_t s);
 void launch_gather_rows_f32(const float* src, int64_t src_stride, const int32_t* idx, float* dst, int row_floats, int n,
                             hipStream_t s);
 void launch_car_rollout(const unsigned char* maze, int rows, int cols, double* state_io,

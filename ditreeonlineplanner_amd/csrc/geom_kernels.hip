@@ -303,13 +303,15 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
                    int A, double gx, double gy, double* __restrict__ states_out, int64_t states_stride,
                    double* __restrict__ actions_out, int64_t actout_stride, int32_t* __restrict__ steps_out,
                    int64_t steps_stride, int32_t* __restrict__ chunks_run, double* __restrict__ prev_action_io,
-                   uint8_t* __restrict__ has_prev_io, const int32_t* __restrict__ idx, int act_dense) {
+                   uint8_t* __restrict__ has_prev_io, const int32_t* __restrict__ idx, int act_dense,
+                   const int32_t* __restrict__ budget, int chunk_j) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   stage_maze(lds, maze, rows * cols);
   const int ob = blockIdx.x * blockDim.x + threadIdx.x;
   if (ob >= B) return;
   const int b = idx ? idx[ob] : ob;                 // compacted rounds: actions are dense (row ob), the rest per candidate
   if (status_io[b] != DITREE_ST_OK) return;
+  if (budget != nullptr && chunk_j >= budget[b]) return;      // this visit's edge is shorter (prop_duration schedule)
   double s[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) s[k] = state_io[(size_t)b * 6 + k];
@@ -377,11 +379,13 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
                            int64_t act_stride, int32_t* status_io, int B, int A, double gx, double gy,
                            double* states_out, int64_t states_stride, double* actions_out, int64_t actout_stride,
                            int32_t* steps_out, int64_t steps_stride, int32_t* chunks_run, double* prev_action_io,
-                           uint8_t* has_prev_io, const int32_t* idx, int act_dense, hipStream_t s) {
+                           uint8_t* has_prev_io, const int32_t* idx, int act_dense, hipStream_t s, const int32_t* budget,
+                           int chunk_j) {
   size_t lds = ((size_t)rows * cols + 15) & ~(size_t)15;
   hipLaunchKernelGGL(car_rollout_kernel, dim3((B + 255) / 256), dim3(256), lds, s, maze, rows, cols, state_io,
                      actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out,
-                     actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense);
+                     actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense,
+                     budget, chunk_j);
 }
 void launch_car_rollout(const unsigned char* maze, int rows, int cols, double* state_io, const double* actions,
                         int64_t act_stride, int32_t* status_io, int B, int A, double gx, double gy,
@@ -389,7 +393,7 @@ void launch_car_rollout(const unsigned char* maze, int rows, int cols, double* s
                         int32_t* steps_out, double* prev_action_io, uint8_t* has_prev_io, hipStream_t s) {
   launch_car_rollout_ex(maze, rows, cols, state_io, actions, act_stride, status_io, B, A, gx, gy, states_out,
                         states_stride, actions_out, actout_stride, steps_out, 1, nullptr, prev_action_io,
-                        has_prev_io, nullptr, 1, s);
+                        has_prev_io, nullptr, 1, s, nullptr, 0);
 }
 
 // ------------------------------------------------------------------------- lidar
@@ -659,13 +663,14 @@ void launch_round_begin(int32_t* status, int32_t* chunks_run, int32_t* chunk_ste
 // idx_out[0..n) = candidates whose status is still DITREE_ST_OK, in candidate order; *count = n.
 // One workgroup, ordered prefix sum (the denoiser then runs on the n alive rows only).
 __global__ void __launch_bounds__(1024) compact_alive_kernel(const int32_t* __restrict__ status, int B,
-                                                             int32_t* __restrict__ idx_out, int32_t* __restrict__ count) {
+                                                             int32_t* __restrict__ idx_out, int32_t* __restrict__ count,
+                                                             const int32_t* __restrict__ budget, int next_chunk) {
   __shared__ int s_wave_sum[16];
   const int tid = threadIdx.x;
   int base = 0;
   for (int start = 0; start < B; start += blockDim.x) {
     const int b = start + tid;
-    const int alive = (b < B && status[b] == DITREE_ST_OK) ? 1 : 0;
+    const int alive = (b < B && status[b] == DITREE_ST_OK && (budget == nullptr || next_chunk < budget[b])) ? 1 : 0;
     int v = alive;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -685,8 +690,31 @@ __global__ void __launch_bounds__(1024) compact_alive_kernel(const int32_t* __re
   }
   if (tid == 0) *count = base;
 }
-void launch_compact_alive(const int32_t* status, int B, int32_t* idx_out, int32_t* count, hipStream_t s) {
-  hipLaunchKernelGGL(compact_alive_kernel, dim3(1), dim3(1024), 0, s, status, B, idx_out, count);
+void launch_compact_alive(const int32_t* status, int B, int32_t* idx_out, int32_t* count, hipStream_t s,
+                          const int32_t* budget, int next_chunk) {
+  hipLaunchKernelGGL(compact_alive_kernel, dim3(1), dim3(1024), 0, s, status, B, idx_out, count, budget, next_chunk);
+}
+
+// planners/RRT.py:149-152 for a round: candidate b is visit number num_visit[parent] + (earlier candidates of the round with
+// the same parent) of its parent; its edge runs schedule[clip(visit)] chunks.  B^2 / 2 parent compares out of L2 (B <= 8192).
+struct ScheduleArg { int n; int chunks[16]; };
+__global__ void __launch_bounds__(256) chunk_budget_kernel(const int32_t* __restrict__ parent, int B,
+                                                           const int32_t* __restrict__ num_visit, ScheduleArg sc,
+                                                           int32_t* __restrict__ budget) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int p = parent[b];
+  int k = num_visit[p];
+  for (int q = 0; q < b; ++q) k += (parent[q] == p) ? 1 : 0;
+  k = k < 0 ? 0 : (k > sc.n - 1 ? sc.n - 1 : k);
+  budget[b] = sc.chunks[k];
+}
+void launch_chunk_budget(const int32_t* parent, int B, const int32_t* num_visit, const int32_t* chunks, int n,
+                         int32_t* budget, hipStream_t s) {
+  ScheduleArg sc{};
+  sc.n = n;
+  for (int i = 0; i < n && i < 16; ++i) sc.chunks[i] = chunks[i];
+  hipLaunchKernelGGL(chunk_budget_kernel, dim3((B + 255) / 256), dim3(256), 0, s, parent, B, num_visit, sc, budget);
 }
 
 // rows of a strided f32 matrix gathered by candidate index (the chunk's noise for the alive candidates)

@@ -148,9 +148,14 @@ class ExpansionEngine:
     def __init__(self, ctx: Context, maze, start_state, goal_state, edge_length=64, action_horizon=8,
                  pred_horizon=64, local_map_size=20, local_map_scale=0.2, s_global=1.0, batch=1024,
                  capacity=65536, k_steps=1, emulate_sticky_done=True, norm=CAR_NORM, rank=0, world_size=1,
-                 process_group=None, early_exit=False, run_type=0, goal_scale=None):
+                 process_group=None, early_exit=False, run_type=0, goal_scale=None, prop_duration=None):
         self.ctx = ctx
         self.maze = np.asarray(maze, dtype=np.float32)
+        # planners/RRT.py:26,149-152: per-visit edge lengths; the tree's edge capacity is the longest entry
+        self.schedule = [int(edge_length)] if prop_duration is None else [int(v) for v in prop_duration]
+        if not self.schedule or any(v < action_horizon or v % action_horizon for v in self.schedule) or len(self.schedule) > 16:
+            raise ValueError("prop_duration: 1..16 edge lengths, each a positive multiple of action_horizon")
+        edge_length = max(self.schedule)
         self.H, self.A, self.P = edge_length, action_horizon, pred_horizon
         self.n_chunks = edge_length // action_horizon
         self.lm_n, self.lm_scale, self.s_global = local_map_size, local_map_scale, s_global
@@ -167,6 +172,11 @@ class ExpansionEngine:
         self.init_main_path = None          # (P, >=2) reference path of an earlier plan (run_type > 0)
         self.tree = DeviceTree(ctx, capacity, self.n_chunks, self.A, track_obstacle_ahead=self.run_type > 0)
         self.rb = RoundBuffers(ctx, batch, self.n_chunks, self.A)
+        self._budget = self._budget_parent = None
+        if len(self.schedule) > 1:
+            self._budget = torch.zeros(batch, dtype=torch.int32, device=ctx.device)
+            self._budget_parent = torch.zeros(batch, dtype=torch.int32, device=ctx.device)
+            self._sched_chunks = (C.c_int32 * len(self.schedule))(*[v // action_horizon for v in self.schedule])
         self.axis = local_axis(local_map_size, local_map_scale)
         from .common.fm_utils import get_timesteps
         t0, dt = get_timesteps("exp", k_steps, 4.0)
@@ -227,6 +237,14 @@ class ExpansionEngine:
             setattr(rp, name, p)
         rp.lm_n, rp.lm_size, rp.s_global = self.lm_n, self.goal_scale, float(self.s_global)
         rp.early_exit = self.early_exit
+        rp.chunk_budget = None
+        if self._budget is not None:
+            # every rank derives the budgets of the WHOLE round (a candidate's place in its parent's visit order is global)
+            check(self.ctx._h, lib().ditree_chunk_budget(self.ctx._h, C.byref(self.tree.desc), samples.data_ptr(), B,
+                                                          self.tree.n_nodes_host, self._sched_chunks, len(self.schedule),
+                                                          self._budget_parent.data_ptr(), self._budget.data_ptr(),
+                                                          self.ctx.stream), "chunk_budget")
+            rp.chunk_budget = self._budget[lo:hi].data_ptr() if n else None
         if n > 0:
             rd = self.rb.desc(lo, n)
             check(self.ctx._h, lib().ditree_expand_round(self.ctx._h, C.byref(self.tree.desc), C.byref(rd),

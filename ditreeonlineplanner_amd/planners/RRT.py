@@ -6,8 +6,8 @@ Constructor kwargs, ``plan() -> (path f32 (P,6)|None, actions f32 (A,2)|None)``,
   ``max_candidates``   deterministic budget instead of / in addition to the wall-clock budget,
   ``early_exit``       (default True) later chunks of collided / finished candidates are skipped, as the
                        reference abandons a collided edge; results are identical either way,
-  ``edge_length``      = prop_duration[0] (the reference's per-visit schedule needs sequential
-                       visits; a schedule with more than one entry raises NotImplementedError).
+  ``prop_duration``    the reference's per-visit edge-length schedule (RRT.py:26,149-152): in a round the candidates of
+                       one parent are its visits in candidate order.
 All of the reference's ``run_type`` values: 0 "Original"; 1 "Original+Ref" (obstacle-ahead flags per node, sampling
 biased to the part of ``init_main_path`` behind the obstacle, furthest-along-path fallback); 2 "OM+Ref" (sample
 positions drawn from the EDT prior); 3 "OM+LB+Ref" (prior log-blended with the start -> goal Gaussian, refreshed at
@@ -31,9 +31,7 @@ class RRT_Planner(BasePlanner):
         self.kd_tree_dim = 2
         self.goal_sample_rate = 0.15
         self.goal_conditioning_bias = kwargs.get("goal_conditioning_bias", 0.85)
-        self.prop_duration_schedule = kwargs.get("prop_duration", [64])
-        if len(self.prop_duration_schedule) != 1:
-            raise NotImplementedError("prop_duration schedules with more than one length need sequential visits")
+        self.prop_duration_schedule = list(kwargs.get("prop_duration", [64]))
         # plan() runs the fused flow-matching rounds (ditree_expand_round: K Euler steps inside the library).  A sampler
         # built for policy='diffusion' needs its scheduler's step between network calls (fm_policy.py:164-182): that loop
         # lives in DiffusionSampler.forward, not in the round kernel -- refuse instead of sampling with the wrong rule.
@@ -50,7 +48,8 @@ class RRT_Planner(BasePlanner):
         self.capacity = int(kwargs.get("capacity", 65536))
         lm = self.local_map_size if isinstance(self.local_map_size, (int, float)) else self.local_map_size[0]
         self._engine = ExpansionEngine(
-            self.ctx, self.maze, self.start_node.state, self.goal_state, edge_length=self.prop_duration_schedule[0],
+            self.ctx, self.maze, self.start_node.state, self.goal_state, edge_length=max(self.prop_duration_schedule),
+            prop_duration=self.prop_duration_schedule,
             action_horizon=self.action_horizon, pred_horizon=getattr(sampler, "pred_horizon", 64),
             local_map_size=int(lm), local_map_scale=self.local_map_scale, s_global=self.s_global, batch=self.batch,
             capacity=self.capacity, k_steps=getattr(sampler, "num_diffusion_iters", 1),

@@ -292,7 +292,18 @@ typedef struct {
   double lm_size;                /* the divisor of the goal conditioning (local_map_size) */
   double s_global;
   int32_t early_exit;            /* != 0: compact the alive candidates after every chunk (RRT.py:179-184) */
+  const int32_t* chunk_budget;   /* [dev] (B,) chunks each candidate may run (ditree_chunk_budget), or NULL = all n_chunks */
 } ditree_round_params;
+
+/* planners/RRT.py:26,149-152: `edge_length = prop_duration[clip(curr_node.num_visit)]; curr_node.num_visit += 1`.
+ * For a round expanded against one tree snapshot the candidates of a parent are its visits in candidate order:
+ * budget[b] = schedule[clip(num_visit[parent(b)] + #{b' < b : parent(b') == parent(b)})], in chunks of action_horizon steps.
+ *   samples [dev] (B, 6): ALL candidates of the round (every rank computes the whole round's budgets: the rank inside a
+ *   parent's visit order is a global property); schedule_chunks [host] n_schedule ints, each <= tree->n_chunks;
+ *   parent_scratch [dev] (B,) i32 workspace (the nearest nodes); budget_out [dev] (B,) i32. */
+int32_t ditree_chunk_budget(ditree_ctx* ctx, const ditree_tree* tree, const double* samples, int32_t B, int32_t n_nodes,
+                            const int32_t* schedule_chunks, int32_t n_schedule, int32_t* parent_scratch,
+                            int32_t* budget_out, void* stream);
 
 int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
                             const ditree_round_params* p, void* stream);

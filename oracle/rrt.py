@@ -136,13 +136,19 @@ class OraclePlanner:
 
     def __init__(self, maze, start_state, goal_state, sampler, edge_length=64, action_horizon=8,
                  local_map_size=20, local_map_scale=0.2, s_global=1.0, goal_sample_rate=0.15,
-                 goal_conditioning_bias=0.85, emulate_sticky_done=True, run_type=0, init_main_path=None):
+                 goal_conditioning_bias=0.85, emulate_sticky_done=True, run_type=0, init_main_path=None,
+                 prop_duration=None):
         self.maze = np.asarray(maze, dtype=np.float32)
         self.start_state = np.asarray(start_state, dtype=np.float64)
         self.goal_state = np.asarray(goal_state, dtype=np.float64)
         # planner.reset -> env.reset(options): goal = centre of the goal cell (car_env.py:225-226)
         self.env_goal = G.cell_rowcol_to_xy(G.cell_xy_to_rowcol(self.goal_state[:2], self.maze), self.maze)
         self.sampler = sampler
+        # planners/RRT.py:26,149-152: the edge length of a visit is prop_duration[clip(parent.num_visit)], and every visit
+        # increments parent.num_visit.  In a round the candidates of one parent are visits in candidate order: candidate b
+        # sees num_visit + (number of earlier candidates of the round with the same parent).
+        self.schedule = [int(edge_length)] if prop_duration is None else [int(v) for v in prop_duration]
+        edge_length = max(self.schedule)
         self.H = edge_length
         self.A = action_horizon
         self.n_chunks = edge_length // action_horizon
@@ -177,6 +183,13 @@ class OraclePlanner:
         chunk_status = np.full((B, nC), -1, dtype=np.int32)       # -1 = chunk not run
         chunk_steps = np.zeros((B, nC), dtype=np.int32)
         alive = np.ones(B, dtype=bool)
+        budget = np.full(B, nC, dtype=np.int32)
+        if len(self.schedule) > 1:
+            seen = {}
+            for b in range(B):
+                k = t.num_visit[parent[b]] + seen.get(int(parent[b]), 0)
+                seen[int(parent[b])] = seen.get(int(parent[b]), 0) + 1
+                budget[b] = self.schedule[min(max(k, 0), len(self.schedule) - 1)] // A
         final_status = np.zeros(B, dtype=np.int32)
         g_at_c = np.zeros(B, dtype=bool)
         chunks_run = np.zeros(B, dtype=np.int32)
@@ -201,7 +214,7 @@ class OraclePlanner:
             # prev_actions = curr_action_seq -> last row (RRT.py:188); only continuing candidates matter
             prev_a[idx[ok]] = r["actions"][ok, A - 1]
             has_prev[idx[ok]] = True
-            alive[idx] = ok
+            alive[idx] = ok & (j + 1 < budget[idx])
         # ---------------------------------------------------------- accept in candidate order
         accepted = []
         for b in range(B):

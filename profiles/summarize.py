@@ -1,6 +1,7 @@
 """Turn the rocprofv3 outputs of profiles/run_profiles.sh (rocpd sqlite or csv) into the committed summaries:
   <tag>_bench_kernel_stats.csv   per-kernel calls / total / average duration of the bench command
   <tag>_pmc_traffic.json         per-kernel HBM traffic per launch from the FETCH_SIZE / WRITE_SIZE passes
+  <tag>_pmc_sq.json              per-kernel SQ counters per launch (MFMA busy, LDS bank conflicts, wave / wait cycles)
 FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B, so reads are
 doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-B-per-lane stores.
 usage: python profiles/summarize.py gpurun_out/prof_r01d r01"""
@@ -32,8 +33,9 @@ def counter_rows(path, counter):
 
 
 def short(name):
-    for k in ("conv3_halo16_kernel", "conv3_halo_kernel", "gemm16_kernel", "conv_gemm_kernel<0, 0, true>", "conv_gemm_kernel<0, 0, false>", "gn2d_kernel",
-              "final_proj_flow_kernel", "car_rollout_kernel", "im2col2d_kernel", "maxpool2d_kernel"):
+    for k in ("conv3_halo16_kernel", "gemm16_kernel", "conv2d_small_kernel", "conv_gemm_kernel", "gn2d_kernel", "gn1d_kernel",
+              "final_proj_flow_kernel", "car_rollout_kernel", "lidar_scan_kernel", "nn_argmin_kernel", "local_map_kernel",
+              "im2col2d_kernel", "maxpool2d_kernel", "encoder_stem_kernel"):
         if k in name:
             return k
     return name.split("(")[0][:60]
@@ -67,6 +69,33 @@ def main(root, tag):
         json.dump(out, f, indent=1)
     for n in list(out["kernels"])[:6]:
         print(n, {k: round(v / 1e6, 2) if "bytes" in k else v for k, v in out["kernels"][n].items()})
+    # SQ pass: per kernel and launch, every counter the pass collected
+    sqdir = os.path.join(root, "pmc_sq")
+    if os.path.isdir(sqdir) and (glob.glob(os.path.join(sqdir, "*.db")) or glob.glob(os.path.join(sqdir, "*counter_collection.csv"))):
+        f = glob.glob(os.path.join(sqdir, "*counter_collection.csv"))
+        rows = []
+        if f:
+            rows = [(r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])) for r in csv.DictReader(open(f[0]))]
+        else:
+            c = sqlite3.connect(glob.glob(os.path.join(sqdir, "*.db"))[0])
+            rows = list(c.execute("select kernel_name, counter_name, value from counters_collection"))
+        per = collections.defaultdict(lambda: collections.defaultdict(list))
+        for n, cn, v in rows:
+            per[short(n)][cn].append(v)
+        sq = {}
+        for n, d in per.items():
+            e = {cn: sum(v) / len(v) for cn, v in d.items()}
+            e["launches"] = max(len(v) for v in d.values())
+            if e.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in e:
+                e["mfma_busy_over_sq_busy"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / e["SQ_BUSY_CYCLES"]
+            if e.get("SQ_LDS_IDX_ACTIVE") and "SQ_LDS_BANK_CONFLICT" in e:
+                e["lds_conflict_share"] = e["SQ_LDS_BANK_CONFLICT"] / e["SQ_LDS_IDX_ACTIVE"]
+            sq[n] = e
+        with open(os.path.join(here, f"{tag}_pmc_sq.json"), "w") as fo:
+            json.dump({"source": "rocprofv3 --kernel-trace --pmc SQ_* (own pass); averages per launch, summed over the chip as rocprofv3 reports them",
+                       "kernels": dict(sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0) * kv[1]["launches"]))}, fo, indent=1)
+        for n in list(sq)[:4]:
+            print("SQ", n, {k: (round(v, 3) if isinstance(v, float) and v < 10 else v) for k, v in sq[n].items()})
 
 
 if __name__ == "__main__":

@@ -363,7 +363,7 @@ class _TapeSampler(torch.nn.Module):
         return a
 
 
-def run_reference_planner(scn, n_candidates, tape_seed):
+def run_reference_planner(scn, n_candidates, tape_seed, prop_duration=(64,)):
     name, maze_name, sr, sc, sdeg, gr, gc = scn
     maze = load_maze(maze_name)
     env = ORRT.OracleCarEnv(maze_map=maze, collision_checking=False)
@@ -380,7 +380,7 @@ def run_reference_planner(scn, n_candidates, tape_seed):
     planner = ref_rrt.RRT_Planner(start, goal, env_id="carmaze", environment=env, sampler=smp,
                                   prediction_type="actions", action_horizon=8, local_map_size=20,
                                   local_map_scale=0.2, global_map_scale=1.0, goal_conditioning_bias=0.85,
-                                  prop_duration=[64], time_budget=n_candidates, max_iter=300, verbose=False)
+                                  prop_duration=list(prop_duration), time_budget=n_candidates, max_iter=300, verbose=False)
     planner.device = "cpu"
     orig_sample = planner.random_node_sample
 
@@ -504,6 +504,33 @@ def gen_traces_run_type1(out):
                rt1_has_path2=np.array(path2 is not None))
     print(f"run_type 1: stage 1 {len(par1)} nodes, stage 2 {len(par2)} nodes, path2={'yes' if path2 is not None else 'none'}; "
           f"oracle planner == reference planner; obstacle-ahead {ahead.mean():.2f} true on {len(poses)} poses")
+
+
+def gen_trace_schedule(out):
+    """planners/RRT.py:149-152 with a three-entry prop_duration: the edge length of a visit follows the parent's visit
+    count.  Reference planner (B = 1) on boxes; the oracle planner with the same schedule must build the same tree."""
+    scn = ("boxes", "boxes", 17, 2, 45, 2, 17)
+    sched = (128, 64, 32)
+    n = 400
+    ref = run_reference_planner(scn, n, tape_seed=29, prop_duration=sched)
+    pl = ORRT.OraclePlanner(ref["maze"], ref["start"], ref["goal"], ActionTape(29).sampler(), prop_duration=list(sched))
+    reached, path, actions = pl.plan(ORRT.RandomTape(42), n, batch=1)
+    assert not pl.sticky_triggered
+    assert np.array_equal(np.array(pl.tree.parents, dtype=np.int32), ref["parents"]), "schedule trace: parents"
+    assert np.array_equal(np.array(pl.tree.states), ref["states"])
+    assert reached == ref["reached"] and pl.iterations == ref["iterations"]
+    assert (path is None) == (ref["path"] is None)
+    if path is not None:
+        assert np.array_equal(path, ref["path"]) and np.array_equal(actions, ref["actions"])
+    lens = np.array([0 if e is None else len(e) for e in pl.tree.edge_actions])
+    assert len(set(lens[1:].tolist())) > 1, "the schedule never changed the edge length: pick another seed"
+    out.update(sched_schedule=np.array(sched), sched_seed=np.array(29), sched_budget=np.array(n), sched_start=ref["start"],
+               sched_goal=ref["goal"], sched_parents=ref["parents"], sched_states=ref["states"], sched_reached=np.array(ref["reached"]),
+               sched_iterations=np.array(ref["iterations"]), sched_edge_actions=lens,
+               sched_path=np.zeros((0, 6), np.float32) if ref["path"] is None else ref["path"],
+               sched_actions=np.zeros((0, 2), np.float32) if ref["actions"] is None else ref["actions"])
+    print(f"prop_duration {sched}: {len(ref['parents'])} nodes, edge lengths {sorted(set(lens[1:].tolist()))}, "
+          f"reached {ref['reached']}; oracle planner == reference planner")
 
 
 def gen_traces(out):
@@ -779,6 +806,11 @@ def main():
         gen_sampler_ant(net)
         np.savez_compressed(os.path.join(HERE, "network.npz"), **net)
         return
+    if sys.argv[1:] == ["schedule"]:          # add the prop_duration-schedule trace to traces.npz (other entries kept)
+        tr = dict(np.load(os.path.join(HERE, "traces.npz"), allow_pickle=False))
+        gen_trace_schedule(tr)
+        np.savez_compressed(os.path.join(HERE, "traces.npz"), **tr)
+        return
     if sys.argv[1:] == ["online"]:
         online = {}
         gen_online(online)
@@ -797,6 +829,7 @@ def main():
     gen_traces(traces)
     gen_traces_run_type1(traces)
     gen_traces_run_type23(traces)
+    gen_trace_schedule(traces)
     gen_prob_maps(geo)
     np.savez_compressed(os.path.join(HERE, "geometry.npz"), **geo)
     np.savez_compressed(os.path.join(HERE, "network.npz"), **net)

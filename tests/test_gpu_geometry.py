@@ -205,3 +205,59 @@ def test_engine_rounds_vs_oracle_rounds(ctx, batch, early_exit):
     assert int(snap["counters"][3]) == pl.iterations and int(snap["counters"][4]) == pl.candidates
     nv = eng.tree.num_visit[: len(pl.tree)].cpu().numpy()
     assert np.array_equal(nv, np.array(pl.tree.num_visit))
+
+
+def _run_engine_sched(ctx, maze, start, goal, tape_seed, budget, batch, sched, early_exit=False):
+    from ditreeonlineplanner_amd.engine import ExpansionEngine
+    eng = ExpansionEngine(ctx, maze, start, goal, batch=batch, capacity=4096, early_exit=early_exit, prop_duration=list(sched))
+    rt = ORRT.RandomTape(42)
+    at = ActionTape(tape_seed)
+    done = 0
+    while eng.goal_node is None and done < budget:
+        B = min(batch, budget - done)
+        s, c = rt.draw_round(B, maze.shape[1], maze.shape[0], goal)
+        acts = np.stack([at.actions(np.arange(done, done + B), j) for j in range(eng.n_chunks)], axis=1)
+        eng.expand_round(dev(s), dev(c), inject_actions=dev(acts))
+        done += B
+    return eng
+
+
+def test_prop_duration_schedule_b1_reproduces_reference_trace(ctx):
+    """planners/RRT.py:149-152 with prop_duration = [128, 64, 32]: the edge length of a visit follows the parent's visit
+    count.  B = 1 rounds = the reference planner (golden `sched_*` from its own run)."""
+    g = golden("traces")
+    maze = load_maze("boxes")
+    sched = [int(v) for v in g["sched_schedule"]]
+    eng = _run_engine_sched(ctx, maze, g["sched_start"], g["sched_goal"], int(g["sched_seed"]), int(g["sched_budget"]), 1, sched)
+    snap = eng.tree_snapshot()
+    assert np.array_equal(snap["parents"], g["sched_parents"])
+    assert np.abs(snap["states"] - g["sched_states"]).max() < 1e-9
+    assert (eng.goal_node is not None) == bool(g["sched_reached"])
+    assert int(snap["counters"][3]) == int(g["sched_iterations"])
+    na = eng.tree.edge_nactions[: len(g["sched_parents"])].cpu().numpy()
+    assert np.array_equal(na[1:], g["sched_edge_actions"][1:]) and len(set(na[1:].tolist())) > 1
+    node = eng.goal_node if eng.goal_node is not None else eng.fallback_node()
+    path, actions = eng.path_to(node)
+    assert np.abs(path - g["sched_path"]).max() < 1e-5 and np.array_equal(actions, g["sched_actions"])
+
+
+@pytest.mark.parametrize("batch", [16, 128])
+@pytest.mark.parametrize("early_exit", [False, True])
+def test_prop_duration_schedule_rounds_vs_oracle(ctx, batch, early_exit):
+    """Rounds of B > 1: the candidates of one parent are its visits in candidate order (oracle round semantics)."""
+    maze = load_maze("boxes")
+    start = np.array([*G.cell_rowcol_to_xy([17, 2], maze), np.deg2rad(45.0), 0, 0, 0])
+    goal = np.array([*G.cell_rowcol_to_xy([2, 17], maze), 0, 0, 0, 0])
+    sched = [96, 64, 32, 16]
+    budget = batch * 5
+    pl = ORRT.OraclePlanner(maze, start, goal, ActionTape(31).sampler(), prop_duration=sched)
+    reached, path, actions = pl.plan(ORRT.RandomTape(42), budget, batch=batch)
+    eng = _run_engine_sched(ctx, maze, start, goal, 31, budget, batch, sched, early_exit)
+    snap = eng.tree_snapshot()
+    assert np.array_equal(snap["parents"], np.array(pl.tree.parents))
+    assert np.abs(snap["states"] - np.array(pl.tree.states)).max() < 1e-9
+    assert (eng.goal_node is not None) == reached
+    assert int(snap["counters"][3]) == pl.iterations and int(snap["counters"][4]) == pl.candidates
+    assert np.array_equal(eng.tree.num_visit[: len(pl.tree)].cpu().numpy(), np.array(pl.tree.num_visit))
+    lens = np.array([0 if e is None else len(e) for e in pl.tree.edge_actions])
+    assert np.array_equal(eng.tree.edge_nactions[: len(pl.tree)].cpu().numpy()[1:], lens[1:])
