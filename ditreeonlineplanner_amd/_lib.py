@@ -32,13 +32,18 @@ class Tree(C.Structure):
                 ("last_action", C.c_void_p), ("has_prev", C.c_void_p), ("num_visit", C.c_void_p),
                 ("edge_states", C.c_void_p), ("edge_actions", C.c_void_p),
                 ("edge_nstates", C.c_void_p), ("edge_nactions", C.c_void_p), ("obstacle_ahead", C.c_void_p),
-                ("counters", C.c_void_p)]
+                ("edge_owner", C.c_void_p), ("counters", C.c_void_p)]
 
 
 class Round(C.Structure):
     _fields_ = [("B", C.c_int32), ("parent", C.c_void_p), ("status", C.c_void_p),
                 ("chunks_run", C.c_void_p), ("end_state", C.c_void_p), ("states", C.c_void_p),
-                ("actions", C.c_void_p), ("chunk_steps", C.c_void_p), ("node_id", C.c_void_p)]
+                ("actions", C.c_void_p), ("chunk_steps", C.c_void_p), ("node_id", C.c_void_p),
+                ("last_action", C.c_void_p), ("first_action", C.c_void_p),
+                ("own_lo", C.c_int32), ("own_n", C.c_int32), ("shard", C.c_int32)]
+
+
+RECORD_DOUBLES = 12          # include/ditree.h DITREE_RECORD_DOUBLES
 
 
 class RoundParams(C.Structure):
@@ -72,6 +77,12 @@ SIGNATURES = {
     "ditree_fallback_select": (_i32, [_vp, C.POINTER(Tree), _i32, _pd, _pd, _i32, _vp, _vp]),
     "ditree_follow_plan": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _pd, _f64, _f64, _vp, _vp, _vp]),
     "ditree_accept": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), _i32, _vp]),
+    "ditree_round_pack": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), _vp, _vp]),
+    "ditree_round_unpack": (_i32, [_vp, C.POINTER(Round), _vp, _vp]),
+    "ditree_comm_unique_id": (_i32, [_vp, _vp]),
+    "ditree_comm_init": (_i32, [_vp, _i32, _i32, _vp]),
+    "ditree_allgather_nodes": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "ditree_comm_destroy": (_i32, [_vp]),
     "ditree_load_weights": (_i32, [_vp, _vp, _i64, C.c_char_p, _vp]),
     "ditree_denoise_reserve": (_i32, [_vp, _i32, _i32]),
     "ditree_denoise": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _pf, _pf, _pd, _vp, _vp, _vp]),

@@ -1,5 +1,7 @@
 // C-ABI entry points of libditree_hip.so (see include/ditree.h for the contract and the
 // reference call sites each entry point replaces).
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstring>
 
@@ -41,6 +43,7 @@ int32_t ditree_ctx_create(int32_t device, ditree_ctx** out) {
 void ditree_ctx_destroy(ditree_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
+  ditree_comm_destroy(ctx);
   denoise_destroy(ctx);
   if (ctx->maze) hipFree(ctx->maze);
   if (ctx->cur_state) hipFree(ctx->cur_state);
@@ -287,6 +290,111 @@ int32_t ditree_accept(ditree_ctx* ctx, const ditree_tree* tree, const ditree_rou
   const AheadArg ts = ahead_samples();
   launch_accept(*tree, *round, emulate_sticky, ctx->maze, ctx->rows, ctx->cols, ts, (hipStream_t)stream);
   HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+int32_t ditree_round_pack(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round, double* records_out,
+                          void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  int rc = check_tree(ctx, tree);
+  if (rc) return rc;
+  rc = check_round(ctx, round);
+  if (rc) return rc;
+  if (round->B == 0) return DITREE_OK;
+  if (!records_out) return set_err(ctx, DITREE_E_ARG, "round_pack: no output");
+  launch_round_pack(*tree, *round, records_out, (hipStream_t)stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+int32_t ditree_round_unpack(ditree_ctx* ctx, const ditree_round* round, const double* records, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  int rc = check_round(ctx, round);
+  if (rc) return rc;
+  if (round->B == 0) return DITREE_OK;
+  if (!records || !round->last_action || !round->first_action)
+    return set_err(ctx, DITREE_E_ARG, "round_unpack: records and the round's last_action / first_action arrays are required");
+  launch_round_unpack(*round, records, (hipStream_t)stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+// ---- RCCL communicator inside the ctx.  librccl is opened at run time (a host that already maps one -- torch does --
+// keeps using that copy), so the library has no link-time dependency on it.
+namespace {
+struct RcclUniqueId { char internal[128]; };
+using fn_get_id = int (*)(RcclUniqueId*);
+using fn_init_rank = int (*)(void**, int, RcclUniqueId, int);
+using fn_allgather = int (*)(const void*, void*, size_t, int, void*, hipStream_t);
+using fn_destroy = int (*)(void*);
+using fn_errstr = const char* (*)(int);
+void* rccl_open(ditree_ctx* ctx) {
+  if (ctx->rccl_lib) return ctx->rccl_lib;
+  const char* names[] = {"librccl.so.1", "librccl.so"};
+  for (const char* n : names)
+    if ((ctx->rccl_lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) return ctx->rccl_lib;       // already mapped by the host
+  for (const char* n : names)
+    if ((ctx->rccl_lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) return ctx->rccl_lib;
+  const char* rocm[] = {"/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : rocm)
+    if ((ctx->rccl_lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) return ctx->rccl_lib;
+  return nullptr;
+}
+int rccl_fail(ditree_ctx* ctx, const char* what, int rc) {
+  fn_errstr es = (fn_errstr)dlsym(ctx->rccl_lib, "ncclGetErrorString");
+  return set_err(ctx, DITREE_E_HIP, std::string(what) + ": " + (es ? es(rc) : "rccl error") + " (" + std::to_string(rc) + ")");
+}
+}  // namespace
+
+int32_t ditree_comm_unique_id(ditree_ctx* ctx, uint8_t* id128) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!id128) return set_err(ctx, DITREE_E_ARG, "comm_unique_id: no output");
+  if (!rccl_open(ctx)) return set_err(ctx, DITREE_E_STATE, std::string("comm: cannot open librccl: ") + dlerror());
+  fn_get_id f = (fn_get_id)dlsym(ctx->rccl_lib, "ncclGetUniqueId");
+  if (!f) return set_err(ctx, DITREE_E_STATE, "comm: ncclGetUniqueId not found");
+  RcclUniqueId id;
+  const int rc = f(&id);
+  if (rc) return rccl_fail(ctx, "ncclGetUniqueId", rc);
+  std::memcpy(id128, id.internal, 128);
+  return DITREE_OK;
+}
+
+int32_t ditree_comm_init(ditree_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id128) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!id128 || world < 1 || rank < 0 || rank >= world) return set_err(ctx, DITREE_E_ARG, "comm_init: bad argument");
+  if (ctx->comm) return set_err(ctx, DITREE_E_STATE, "comm_init: communicator already exists");
+  if (!rccl_open(ctx)) return set_err(ctx, DITREE_E_STATE, std::string("comm: cannot open librccl: ") + dlerror());
+  fn_init_rank f = (fn_init_rank)dlsym(ctx->rccl_lib, "ncclCommInitRank");
+  if (!f) return set_err(ctx, DITREE_E_STATE, "comm: ncclCommInitRank not found");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  RcclUniqueId id;
+  std::memcpy(id.internal, id128, 128);
+  const int rc = f(&ctx->comm, world, id, rank);
+  if (rc) { ctx->comm = nullptr; return rccl_fail(ctx, "ncclCommInitRank", rc); }
+  ctx->comm_rank = rank;
+  ctx->comm_world = world;
+  return DITREE_OK;
+}
+
+int32_t ditree_allgather_nodes(ditree_ctx* ctx, const double* send, double* recv, int64_t count_doubles, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!ctx->comm) return set_err(ctx, DITREE_E_STATE, "allgather_nodes: call ditree_comm_init first");
+  if (!send || !recv || count_doubles < 0) return set_err(ctx, DITREE_E_ARG, "allgather_nodes: bad argument");
+  if (count_doubles == 0) return DITREE_OK;
+  fn_allgather f = (fn_allgather)dlsym(ctx->rccl_lib, "ncclAllGather");
+  if (!f) return set_err(ctx, DITREE_E_STATE, "comm: ncclAllGather not found");
+  const int rc = f(send, recv, (size_t)count_doubles, 8 /* ncclDouble */, ctx->comm, (hipStream_t)stream);
+  if (rc) return rccl_fail(ctx, "ncclAllGather", rc);
+  return DITREE_OK;
+}
+
+int32_t ditree_comm_destroy(ditree_ctx* ctx) {
+  if (!ctx) return DITREE_E_ARG;
+  if (ctx->comm) {
+    fn_destroy f = (fn_destroy)dlsym(ctx->rccl_lib, "ncclCommDestroy");
+    if (f) f(ctx->comm);
+    ctx->comm = nullptr;
+  }
   return DITREE_OK;
 }
 

@@ -46,6 +46,10 @@ struct ditree_ctx {
   double* path_dev = nullptr;       // reference path xy for the fallback selection
   int path_cap = 0;
   DenoiserState* dn = nullptr;
+  // optional RCCL communicator (ditree_comm_*): librccl opened at run time
+  void* rccl_lib = nullptr;
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
 };
 
 int set_err(ditree_ctx* ctx, int code, const std::string& msg);
@@ -87,6 +91,8 @@ void launch_round_begin(int32_t* status, int32_t* chunks_run, int32_t* chunk_ste
                         hipStream_t s);
 void launch_round_chunk_end(const int32_t* chunk_status_in, int32_t* status, int32_t* chunks_run,
                             const double* cur_state, double* end_state, int B, hipStream_t s);
+void launch_round_pack(const ditree_tree& t, const ditree_round& r, double* rec, hipStream_t s);
+void launch_round_unpack(const ditree_round& r, const double* rec, hipStream_t s);
 struct AheadArg { double t[30]; };
 void launch_accept(const ditree_tree& t, const ditree_round& r, int emulate_sticky, const unsigned char* maze, int rows,
                    int cols, const AheadArg& ts, hipStream_t s);

@@ -296,8 +296,18 @@ __device__ __forceinline__ void car_euler_step(double* s, double a0r, double a1r
 }
 
 // ------------------------------------------------------------------------- rollout
-// One thread per candidate: A Euler steps, each with goal + collision test, early exit.
-__global__ void __launch_bounds__(256)
+// planners/base_planner.py:257-320 + car_env.py:240-282,341-396 + common/map_utils.py:103-115 for a batch of candidates.
+// One wave (64-thread work-group) per 64 candidates, one lane per candidate for the sequential part (A Euler steps,
+// each with goal + two-ball collision test, early exit), so 1024 candidates already spread over 16 CUs and 65 536 over
+// all of them.  Global traffic is moved by the WAVE, not by the lane: a lane's action row and (A + 1, 6) state rows are
+// 16..50-byte fragments at a stride of hundreds of bytes, so per-lane loads / stores touch a line per fragment (measured
+// on the first version: 227 MB moved for 71 MB of algorithmic bytes, 38 % of the wave time in s_waitcnt).  Per chunk of
+// RO_S steps the wave loads the 64 x RO_S x 2 action block with consecutive lanes on consecutive doubles into LDS, the
+// lanes step out of LDS, write their states back into LDS, and the wave flushes 64 x rows x 6 doubles the same way:
+// every candidate's rows of a chunk are one contiguous 200..250-byte run in memory.
+//   LDS per wave: maze + 64 x (2 RO_S + 1) + 64 x (6 (RO_S + 1) + 1) doubles (odd strides: conflict-free b64 access).
+#define RO_S 4
+__global__ void __launch_bounds__(64)
 car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, double* __restrict__ state_io,
                    const double* __restrict__ actions, int64_t act_stride, int32_t* __restrict__ status_io, int B,
                    int A, double gx, double gy, double* __restrict__ states_out, int64_t states_stride,
@@ -306,64 +316,94 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
                    uint8_t* __restrict__ has_prev_io, const int32_t* __restrict__ idx, int act_dense,
                    const int32_t* __restrict__ budget, int chunk_j) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int AS = 2 * RO_S + 1, SS = 6 * (RO_S + 1) + 1;          // doubles per lane in the action / state stage
+  const int maze_bytes = (rows * cols + 15) & ~15;
+  double* st_a = (double*)(lds + maze_bytes);                       // [64][AS]
+  double* st_s = st_a + 64 * AS;                                    // [64][SS]
+  long long* rowb = (long long*)(st_s + 64 * SS);                   // [64] candidate index of each lane (-1: not running)
   stage_maze(lds, maze, rows * cols);
-  const int ob = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ob >= B) return;
-  const int b = idx ? idx[ob] : ob;                 // compacted rounds: actions are dense (row ob), the rest per candidate
-  if (status_io[b] != DITREE_ST_OK) return;
-  if (budget != nullptr && chunk_j >= budget[b]) return;      // this visit's edge is shorter (prop_duration schedule)
-  double s[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) s[k] = state_io[(size_t)b * 6 + k];
-  const double* act = actions + (size_t)(act_dense ? ob : b) * act_stride;
-  double* so = states_out ? states_out + (size_t)b * states_stride : nullptr;
-  double* ao = actions_out ? actions_out + (size_t)b * actout_stride : nullptr;
-  if (so) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) so[k] = s[k];                                   // states_sequence[0] = state
+  const int lane = threadIdx.x;
+  const int ob = blockIdx.x * 64 + lane;
+  int b = -1;
+  if (ob < B) {
+    b = idx ? idx[ob] : ob;                         // compacted rounds: actions are dense (row ob), the rest per candidate
+    if (status_io[b] != DITREE_ST_OK) b = -1;
+    else if (budget != nullptr && chunk_j >= budget[b]) b = -1;      // this visit's edge is shorter (prop_duration schedule)
   }
-  int status = DITREE_ST_OK;
-  int steps = 0;
+  const bool run = b >= 0;
+  // action row (act_dense: row ob) and output rows of every lane, for the wave-wide copies
+  long long* arow = rowb + 64;                                       // [64] action row index
+  rowb[lane] = run ? (long long)b : -1;
+  arow[lane] = run ? (long long)(act_dense ? ob : b) : -1;
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  if (run) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] = state_io[(size_t)b * 6 + k];
+  }
+  int status = DITREE_ST_OK, steps = 0, ended = 0;                   // ended: no further step (goal / collision)
   double la0 = 0.0, la1 = 0.0;
-  int i = 0;
-  for (; i < A; ++i) {
-    const double a0r = act[2 * i], a1r = act[2 * i + 1];
-    car_euler_step(s, a0r, a1r);
-    steps = i + 1;
-    if (so) {
+  __syncthreads();
+  for (int s0 = 0; s0 < A; s0 += RO_S) {
+    const int ns = min(RO_S, A - s0);
+    // ---- wave load of the action block: element e -> (candidate lane c, double k of its ns x 2 run)
+    for (int e = lane; e < 64 * ns * 2; e += 64) {
+      const int c = e / (ns * 2), k = e - c * (ns * 2);
+      const long long ar = arow[c];
+      if (ar >= 0) st_a[c * AS + k] = actions[(size_t)ar * act_stride + 2 * s0 + k];
+    }
+    __syncthreads();
+    // ---- the lane's steps of this chunk; state rows into LDS (row 0 of the first chunk = the start state)
+    const int r0 = (s0 == 0) ? 0 : 1;                                // first staged row index that is flushed
+    if (run) {
+      double* ms = st_s + lane * SS;
+      double* ma = st_a + lane * AS;
+      if (s0 == 0) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) so[(size_t)(i + 1) * 6 + k] = s[k];
-    }
-    if (ao) { ao[2 * i] = a0r; ao[2 * i + 1] = a1r; }
-    la0 = a0r; la1 = a1r;
-    double ex = s[0] - gx, ey = s[1] - gy;
-    bool done = sqrt(fma(ey, ey, ex * ex)) < 0.5;   // np.linalg.norm (ddot rounds as one fma), car_env.py:346-351
-    bool coll = car_collides(s[0], s[1], s[2], lds, rows, cols);                 // base_planner.py:306
-    if (coll) {
-      status = DITREE_ST_COLLIDED | (done ? DITREE_ST_FLAG_GOAL_AT_COLLISION : 0);
-      ++i;
-      break;
-    }
-    if (done) {                                                                   // :314-317
-      status = DITREE_ST_GOAL;
-      ++i;
-      break;
-    }
-  }
-  // rows after the last executed step stay zero (states :282; actions zeroed :315)
-  for (int r = i; r < A; ++r) {
-    if (so) {
+        for (int k = 0; k < 6; ++k) ms[k] = s[k];                     // states_sequence[0] = state
+      }
+      for (int i = 0; i < ns; ++i) {
+        double* row = ms + (size_t)(i + 1) * 6;
+        if (ended) {
+          // rows after the last executed step stay zero (states :282); only the goal branch zeroes the remaining actions
+          // (:314-317) -- a collided edge is discarded by the caller, its untouched tail is copied through
 #pragma unroll
-      for (int k = 0; k < 6; ++k) so[(size_t)(r + 1) * 6 + k] = 0.0;
+          for (int k = 0; k < 6; ++k) row[k] = 0.0;
+          if (status == DITREE_ST_GOAL) { ma[2 * i] = 0.0; ma[2 * i + 1] = 0.0; }
+          continue;
+        }
+        const double a0r = ma[2 * i], a1r = ma[2 * i + 1];
+        car_euler_step(s, a0r, a1r);
+        steps = s0 + i + 1;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) row[k] = s[k];
+        la0 = a0r; la1 = a1r;
+        double ex = s[0] - gx, ey = s[1] - gy;
+        bool done = sqrt(fma(ey, ey, ex * ex)) < 0.5;   // np.linalg.norm (ddot rounds as one fma), car_env.py:346-351
+        bool coll = car_collides(s[0], s[1], s[2], lds, rows, cols);                 // base_planner.py:306
+        if (coll) { status = DITREE_ST_COLLIDED | (done ? DITREE_ST_FLAG_GOAL_AT_COLLISION : 0); ended = 1; }
+        else if (done) { status = DITREE_ST_GOAL; ended = 1; }                        // :314-317
+      }
     }
-    if (ao) {
-      // only the goal branch zeroes the remaining actions (:314-317); a collided edge is discarded
-      // by the caller, its untouched tail is copied through like the reference's array
-      const bool z = (status == DITREE_ST_GOAL);
-      ao[2 * r] = z ? 0.0 : act[2 * r];
-      ao[2 * r + 1] = z ? 0.0 : act[2 * r + 1];
+    __syncthreads();
+    // ---- wave flush: states rows [s0 + r0, s0 + ns] and actions [s0, s0 + ns) of every running lane
+    if (states_out) {
+      const int nr = ns + 1 - r0;                                    // rows to write per candidate
+      for (int e = lane; e < 64 * nr * 6; e += 64) {
+        const int c = e / (nr * 6), k = e - c * (nr * 6);
+        const long long cb = rowb[c];
+        if (cb >= 0) states_out[(size_t)cb * states_stride + (size_t)(s0 + r0) * 6 + k] = st_s[c * SS + r0 * 6 + k];
+      }
     }
+    if (actions_out) {
+      for (int e = lane; e < 64 * ns * 2; e += 64) {
+        const int c = e / (ns * 2), k = e - c * (ns * 2);
+        const long long cb = rowb[c];
+        if (cb >= 0) actions_out[(size_t)cb * actout_stride + 2 * s0 + k] = st_a[c * AS + k];
+      }
+    }
+    __syncthreads();
   }
+  if (!run) return;
 #pragma unroll
   for (int k = 0; k < 6; ++k) state_io[(size_t)b * 6 + k] = s[k];
   status_io[b] = status;
@@ -381,8 +421,8 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
                            int32_t* steps_out, int64_t steps_stride, int32_t* chunks_run, double* prev_action_io,
                            uint8_t* has_prev_io, const int32_t* idx, int act_dense, hipStream_t s, const int32_t* budget,
                            int chunk_j) {
-  size_t lds = ((size_t)rows * cols + 15) & ~(size_t)15;
-  hipLaunchKernelGGL(car_rollout_kernel, dim3((B + 255) / 256), dim3(256), lds, s, maze, rows, cols, state_io,
+  size_t lds = (((size_t)rows * cols + 15) & ~(size_t)15) + (size_t)64 * ((2 * RO_S + 1) + (6 * (RO_S + 1) + 1) + 2) * 8;
+  hipLaunchKernelGGL(car_rollout_kernel, dim3((B + 63) / 64), dim3(64), lds, s, maze, rows, cols, state_io,
                      actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out,
                      actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense,
                      budget, chunk_j);
@@ -929,6 +969,10 @@ accept_commit_kernel(ditree_tree t, ditree_round r, const unsigned char* __restr
   const double* ca = r.actions + (size_t)b * ea_cap * 2;
   int ns = 0, na = 0;
   double endst[6];
+  // sharded rounds: the trajectories of candidates another rank expanded are not here -- their nodes get state, parent
+  // and last action from the exchanged record, the edge rows stay with the owner (edge_owner)
+  const bool own = r.shard == 0 || (b >= r.own_lo && b < r.own_lo + r.own_n);
+  int owner = -1;
   if (b == phantom) {
     // frozen env step (car_env.py:254): the edge is [s, s] and the first sampled action
     for (int k = 0; k < 6; ++k) endst[k] = t.state[(size_t)par * 6 + k];
@@ -938,12 +982,20 @@ accept_commit_kernel(ditree_tree t, ditree_round r, const unsigned char* __restr
       if (lane < 6) { es[lane] = endst[lane]; es[6 + lane] = endst[lane]; }
       ns = 2;
     }
-    if (!(ca[0] == 0.0 && ca[1] == 0.0)) {
-      if (lane < 2) ea[lane] = ca[lane];
+    const double fa0 = r.first_action ? r.first_action[(size_t)b * 2] : ca[0];
+    const double fa1 = r.first_action ? r.first_action[(size_t)b * 2 + 1] : ca[1];
+    if (!(fa0 == 0.0 && fa1 == 0.0)) {
+      if (lane == 0) { ea[0] = fa0; ea[1] = fa1; }
       na = 1;
     }
+  } else if (!own) {
+    for (int k = 0; k < 6; ++k) endst[k] = r.end_state[(size_t)b * 6 + k];
+    owner = r.shard > 0 ? b / r.shard : 0;
+    ns = -1;
+    na = -1;
   } else {
     for (int k = 0; k < 6; ++k) endst[k] = r.end_state[(size_t)b * 6 + k];
+    owner = r.shard > 0 ? b / r.shard : -1;
     const int run = r.chunks_run[b];
     const int rows_s = run * (A + 1), rows_a = run * A;
     // serial compaction per wave: rows are few (<= 72) and tiny
@@ -972,11 +1024,53 @@ accept_commit_kernel(ditree_tree t, ditree_round r, const unsigned char* __restr
     t.num_visit[id] = 0;
     t.edge_nstates[id] = ns;
     t.edge_nactions[id] = na;
+    if (t.edge_owner != nullptr) t.edge_owner[id] = owner;
     if (t.obstacle_ahead != nullptr)                                   // RRT.py:202-205 (run_type > 0)
       t.obstacle_ahead[id] = obstacle_ahead_dev(endst[0], endst[1], endst[2], maze, rows, cols, ts) ? 1 : 0;
   }
   __syncthreads();
-  if (lane < 2) t.last_action[(size_t)id * 2 + lane] = (na > 0) ? ea[(size_t)(na - 1) * 2 + lane] : 0.0;
+  if (lane < 2) {
+    double la;
+    if (r.last_action != nullptr && b != phantom) la = r.last_action[(size_t)b * 2 + lane];     // exchanged record
+    else la = (na > 0) ? ea[(size_t)(na - 1) * 2 + lane] : 0.0;
+    t.last_action[(size_t)id * 2 + lane] = la;
+  }
+}
+
+// ---- candidate records of a sharded round (include/ditree.h DITREE_RECORD_DOUBLES)
+__global__ void round_pack_kernel(ditree_tree t, ditree_round r, double* __restrict__ rec) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= r.B) return;
+  double* o = rec + (size_t)b * DITREE_RECORD_DOUBLES;
+  for (int k = 0; k < 6; ++k) o[k] = r.end_state[(size_t)b * 6 + k];
+  const int A = t.A, nC = t.n_chunks;
+  const double* ca = r.actions + (size_t)b * nC * A * 2;
+  // last kept (non-zero) action row of the chunks that ran: what accept_commit_kernel derives from the compacted edge
+  double l0 = 0.0, l1 = 0.0;
+  for (int row = r.chunks_run[b] * A - 1; row >= 0; --row) {
+    const double a0 = ca[(size_t)row * 2], a1 = ca[(size_t)row * 2 + 1];
+    if (!(a0 == 0.0 && a1 == 0.0)) { l0 = a0; l1 = a1; break; }
+  }
+  o[6] = l0; o[7] = l1;
+  o[8] = ca[0]; o[9] = ca[1];
+  int32_t* oi = (int32_t*)(o + 10);
+  oi[0] = r.parent[b]; oi[1] = r.status[b]; oi[2] = r.chunks_run[b]; oi[3] = 0;
+}
+__global__ void round_unpack_kernel(ditree_round r, const double* __restrict__ rec) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= r.B) return;
+  const double* o = rec + (size_t)b * DITREE_RECORD_DOUBLES;
+  for (int k = 0; k < 6; ++k) r.end_state[(size_t)b * 6 + k] = o[k];
+  r.last_action[(size_t)b * 2] = o[6]; r.last_action[(size_t)b * 2 + 1] = o[7];
+  r.first_action[(size_t)b * 2] = o[8]; r.first_action[(size_t)b * 2 + 1] = o[9];
+  const int32_t* oi = (const int32_t*)(o + 10);
+  r.parent[b] = oi[0]; r.status[b] = oi[1]; r.chunks_run[b] = oi[2];
+}
+void launch_round_pack(const ditree_tree& t, const ditree_round& r, double* rec, hipStream_t s) {
+  hipLaunchKernelGGL(round_pack_kernel, dim3((r.B + 127) / 128), dim3(128), 0, s, t, r, rec);
+}
+void launch_round_unpack(const ditree_round& r, const double* rec, hipStream_t s) {
+  hipLaunchKernelGGL(round_unpack_kernel, dim3((r.B + 127) / 128), dim3(128), 0, s, r, rec);
 }
 
 void launch_accept(const ditree_tree& t, const ditree_round& r, int emulate_sticky, const unsigned char* maze, int rows,

@@ -42,10 +42,12 @@ class DeviceTree:
         self.counters = torch.zeros(8, dtype=i32, device=dev)
         # RRT.py:202-205: per-node check_obstacle_ahead flag, kept only for run_type > 0
         self.obstacle_ahead = torch.zeros(capacity, dtype=u8, device=dev) if track_obstacle_ahead else None
+        # rank holding each node's edge rows (sharded rounds keep trajectories on the producing rank); -1 = every rank
+        self.edge_owner = torch.full((capacity,), -1, dtype=i32, device=dev)
         self.desc = Tree(capacity, n_chunks, A, *[None if t is None else t.data_ptr() for t in (
             self.state, self.xy, self.parent, self.last_action, self.has_prev, self.num_visit,
             self.edge_states, self.edge_actions, self.edge_nstates, self.edge_nactions, self.obstacle_ahead,
-            self.counters)])
+            self.edge_owner, self.counters)])
         self.n_nodes_host = 0
 
     def reset(self, start_state):
@@ -85,14 +87,30 @@ class RoundBuffers:
         self.actions = torch.zeros(B, n_chunks, A, 2, dtype=f64, device=dev)
         self.chunk_steps = torch.zeros(B, n_chunks, dtype=i32, device=dev)
         self.node_id = torch.full((B,), -1, dtype=i32, device=dev)
+        # sharded rounds only (allocated on first use): exchanged 96-byte records and what they carry beyond the SoA above
+        self.records = self.last_action = self.first_action = None
+
+    def ensure_exchange(self, rows):
+        if self.records is None or self.records.shape[0] < rows:
+            dev = self.parent.device
+            self.records = torch.zeros(rows, _lib.RECORD_DOUBLES, dtype=torch.float64, device=dev)
+            self.last_action = torch.zeros(max(rows, self.B), 2, dtype=torch.float64, device=dev)
+            self.first_action = torch.zeros(max(rows, self.B), 2, dtype=torch.float64, device=dev)
 
     def fields(self):
         return (self.parent, self.status, self.chunks_run, self.end_state, self.states, self.actions,
                 self.chunk_steps, self.node_id)
 
-    def desc(self, lo=0, n=None):
+    def desc(self, lo=0, n=None, own=None, shard=0):
+        """Round descriptor of rows [lo, lo + n).  ``own`` = (own_lo, own_n) in the descriptor's row numbering and
+        ``shard`` = candidates per rank for a sharded round (default: every row was produced here)."""
         n = self.B - lo if n is None else n
-        return Round(n, *[t[lo:lo + n].data_ptr() if n > 0 else t.data_ptr() for t in self.fields()])
+        ptrs = [t[lo:lo + n].data_ptr() if n > 0 else t.data_ptr() for t in self.fields()]
+        la = fa = None
+        if shard and self.last_action is not None:
+            la, fa = self.last_action[lo:].data_ptr(), self.first_action[lo:].data_ptr()
+        own_lo, own_n = (0, n) if own is None else own
+        return Round(n, *ptrs, la, fa, own_lo, own_n, shard)
 
 
 def allgather_round_fields(fields, per, rank, world, group=None):
@@ -256,11 +274,37 @@ class ExpansionEngine:
         return None
 
     def _allgather_round(self, B, per):
-        allgather_round_fields(self.rb.fields()[:-1], per, self.rank, self.world, self.pg)
+        """One collective per round: 96-byte candidate records (end state, last / first action, parent, status, chunks run;
+        SURVEY.md 8(e)).  The edge trajectories stay on the rank that produced them (tree.edge_owner) and are only moved
+        by ``path_to``.  DITREE_GATHER_EDGES=1 restores the round-1 behaviour (every field incl. trajectories)."""
+        import os
+        if os.environ.get("DITREE_GATHER_EDGES", "0") == "1":
+            self._sharded = False
+            allgather_round_fields(self.rb.fields()[:-1], per, self.rank, self.world, self.pg)
+            return
+        self._sharded = True
+        rows = per * self.world
+        rb = self.rb
+        rb.ensure_exchange(rows)
+        lo, hi, _ = self.shard(B)
+        n = hi - lo
+        mine = rb.records[self.rank * per:(self.rank + 1) * per]
+        if n > 0:
+            rd = rb.desc(lo, n)
+            check(self.ctx._h, lib().ditree_round_pack(self.ctx._h, C.byref(self.tree.desc), C.byref(rd), mine.data_ptr(),
+                                                        self.ctx.stream), "round_pack")
+        allgather_round_fields([rb.records], per, self.rank, self.world, self.pg)
+        rd = rb.desc(0, B, shard=per)
+        check(self.ctx._h, lib().ditree_round_unpack(self.ctx._h, C.byref(rd), rb.records.data_ptr(), self.ctx.stream),
+              "round_unpack")
 
     def accept(self, B):
         self.ensure_maze()                        # run_type > 0: the commit kernel evaluates check_obstacle_ahead
-        rd = self.rb.desc(0, B)
+        if getattr(self, "_sharded", False) and (self.world > 1 or self.force_allgather):
+            lo, hi, per = self.shard(B)
+            rd = self.rb.desc(0, B, own=(lo, hi - lo), shard=per)
+        else:
+            rd = self.rb.desc(0, B)
         check(self.ctx._h, lib().ditree_accept(self.ctx._h, C.byref(self.tree.desc), C.byref(rd), self.sticky,
                                                 self.ctx.stream), "accept")
         return self.tree.read_counters()          # one small D2H per round: n_nodes / goal
@@ -307,10 +351,28 @@ class ExpansionEngine:
         chain = chain[::-1]
         idx = torch.as_tensor(chain, device=t.state.device, dtype=torch.long)
         st = t.state[idx].cpu().numpy()
-        es = t.edge_states[idx].cpu().numpy()
-        ea = t.edge_actions[idx].cpu().numpy()
-        ns = t.edge_nstates[idx].cpu().numpy()
-        na = t.edge_nactions[idx].cpu().numpy()
+        es_t, ea_t = t.edge_states[idx], t.edge_actions[idx]
+        ns_t, na_t = t.edge_nstates[idx], t.edge_nactions[idx]
+        if self.world > 1 and getattr(self, "_sharded", False):
+            # collective (every rank walks the same chain): each edge comes from the rank that expanded it; rows a rank
+            # does not hold are zeroed, the sum over ranks is then exact (x + 0 + ... + 0)
+            import torch.distributed as dist
+            owner = t.edge_owner[idx]
+            mine = (owner == self.rank) | ((owner < 0) & (self.rank == 0))
+            mask = mine.to(es_t.dtype)
+            es_t = es_t * mask[:, None, None]
+            ea_t = ea_t * mask[:, None, None]
+            ns_t = torch.where(mine, ns_t, torch.zeros_like(ns_t))
+            na_t = torch.where(mine, na_t, torch.zeros_like(na_t))
+            gloo = dist.get_backend(self.pg) == "gloo"
+            bufs = []
+            for x in (es_t, ea_t, ns_t, na_t):
+                y = x.cpu() if gloo else x.contiguous()
+                dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.pg)
+                bufs.append(y)
+            es_t, ea_t, ns_t, na_t = bufs
+        es, ea = es_t.cpu().numpy(), ea_t.cpu().numpy()
+        ns, na = ns_t.cpu().numpy(), na_t.cpu().numpy()
         path, actions = [], []
         for k, nd in enumerate(chain):
             if nd != 0:

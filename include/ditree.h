@@ -147,6 +147,8 @@ typedef struct {
   int32_t* edge_nstates;     /* (cap,) rows kept */
   int32_t* edge_nactions;    /* (cap,) */
   uint8_t* obstacle_ahead;   /* (cap,) or NULL: planners/RRT.py:61-81 flag of every appended node (run_type > 0) */
+  int32_t* edge_owner;       /* (cap,) or NULL: rank that holds the node's edge rows (sharded rounds keep the trajectories
+                                on the producing rank); -1 = every rank (root, frozen-env edges) */
   int32_t* counters;         /* [0] n_nodes, [1] goal node (-1 none), [2] env.done latched
                                 (car_env.py:254,266 "sticky done"), [3] chunk iterations,
                                 [4] candidates processed, [5] sticky-done triggered */
@@ -164,7 +166,34 @@ typedef struct {
   double* actions;           /* (B, n_chunks, A, 2) */
   int32_t* chunk_steps;      /* (B, n_chunks) */
   int32_t* node_id;          /* (B,) out: assigned node index or -1 */
+  /* Sharded rounds (one process per GPU): only rows [own_lo, own_lo + own_n) of states / actions / chunk_steps were
+   * produced here; the other rows arrive as 96-byte records (ditree_round_pack / _unpack), whose last / first action
+   * land in the two arrays below.  Single rank: own_lo = 0, own_n = B, both arrays NULL. */
+  double* last_action;       /* (B, 2) or NULL: last kept action row of the candidate's edge */
+  double* first_action;      /* (B, 2) or NULL: actions[b, 0, 0, :] (the frozen-env edge of the sticky-done emulation) */
+  int32_t own_lo, own_n;
+  int32_t shard;             /* candidates per rank: owner of candidate b = b / shard (0 = single rank) */
 } ditree_round;
+
+/* Candidate record exchanged between ranks once per round: 12 doubles = 96 bytes,
+ * [end_state 6 | last_action 2 | first_action 2 | (parent, status) as two i32 | (chunks_run, 0) as two i32].
+ * Edge trajectories stay on the producing rank.  pack: rows of `round` (this rank's slice) -> records_out (round->B, 12);
+ * unpack: records (B, 12) of ALL candidates -> parent / status / chunks_run / end_state / last_action / first_action. */
+#define DITREE_RECORD_DOUBLES 12
+int32_t ditree_round_pack(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round, double* records_out,
+                          void* stream);
+int32_t ditree_round_unpack(ditree_ctx* ctx, const ditree_round* round, const double* records, void* stream);
+
+/* The per-round exchange for hosts without torch.distributed: an RCCL communicator inside the ctx (librccl is opened at
+ * run time; one process per GPU, ranks of ONE node over xGMI).
+ *   ditree_comm_unique_id: rank 0 fills a 128-byte id and hands it to the other ranks (file, pipe, MPI ...);
+ *   ditree_comm_init:      every rank, collective;
+ *   ditree_allgather_nodes: recv (world * count_doubles) <- every rank's send (count_doubles), in rank order, on `stream`
+ *                           (in place when send == recv + rank * count_doubles). */
+int32_t ditree_comm_unique_id(ditree_ctx* ctx, uint8_t* id128);
+int32_t ditree_comm_init(ditree_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id128);
+int32_t ditree_allgather_nodes(ditree_ctx* ctx, const double* send, double* recv, int64_t count_doubles, void* stream);
+int32_t ditree_comm_destroy(ditree_ctx* ctx);
 
 /* planners/RRT.py:179-217: accept candidates in index order (collided edges dropped,
  * lowest goal-reaching accepted index ends the plan, later candidates dropped),

@@ -77,7 +77,12 @@ def _gpu_worker(rank, world, port, out_path):
         eng.expand_round(torch.as_tensor(s).cuda(), torch.as_tensor(c).cuda(), inject_actions=torch.as_tensor(acts).cuda())
         done += B
     snap = eng.tree_snapshot()
-    np.savez(out_path.format(rank=rank), parents=snap["parents"], states=snap["states"], counters=snap["counters"])
+    # the path walk is a collective in sharded mode: edges come from the ranks that expanded them
+    node = eng.goal_node if eng.goal_node is not None else eng.fallback_node()
+    path, actions = eng.path_to(node)
+    owner = eng.tree.edge_owner[: len(snap["parents"])].cpu().numpy()
+    np.savez(out_path.format(rank=rank), parents=snap["parents"], states=snap["states"], counters=snap["counters"],
+             path=path, actions=actions, owner=owner, last_action=eng.tree.last_action[: len(snap["parents"])].cpu().numpy())
     dist.destroy_process_group()
 
 
@@ -92,4 +97,72 @@ def test_sharded_round_builds_identical_tree(tmp_path):
         assert np.array_equal(a["parents"], b["parents"])
         assert np.array_equal(a["states"], b["states"])          # same kernels, same inputs: bit-identical
         assert np.array_equal(a["counters"][:5], b["counters"][:5])
-    assert len(a["parents"]) > 50
+        assert np.array_equal(a["last_action"], b["last_action"])    # carried by the 96-byte records
+        assert np.array_equal(a["path"], b["path"]) and np.array_equal(a["actions"], b["actions"])
+        assert set(np.unique(b["owner"][1:]).tolist()) <= {0, 1} and len(np.unique(b["owner"][1:])) == 2
+    assert len(a["parents"]) > 50 and len(a["path"]) > 10
+
+
+def _gpu_denoiser_worker(rank, world, port, out_path):
+    """Sharded rounds with the real denoiser: every rank runs its sub-batch of candidates through the network."""
+    sys.path.insert(0, REPO)
+    _init(rank, world, port)
+    from ditreeonlineplanner_amd import _lib
+    from ditreeonlineplanner_amd.engine import ExpansionEngine
+    from ditreeonlineplanner_amd.model import NoisePredNet
+    from ditreeonlineplanner_amd.ops import Context
+    from oracle import geometry as G
+    from oracle import rrt as ORRT
+    maze = load_maze("boxes")
+    start = np.array([*G.cell_rowcol_to_xy([17, 2], maze), np.deg2rad(45.0), 0, 0, 0])
+    goal = np.array([*G.cell_rowcol_to_xy([2, 17], maze), 0, 0, 0, 0])
+    ctx = Context(0)
+    B = 48                                   # 24 per rank: ragged against the 16-row padding of the denoiser batch
+    net = NoisePredNet(seed=0)
+    net.bind(ctx, precision=_lib.PREC_F16X3, max_batch=B)
+    eng = ExpansionEngine(ctx, maze, start, goal, edge_length=32, batch=B, capacity=2048, rank=rank, world_size=world)
+    rt = ORRT.RandomTape(42)
+    g = torch.Generator().manual_seed(5)
+    for _ in range(3):
+        s, c = rt.draw_round(B, maze.shape[1], maze.shape[0], goal)
+        noise = torch.randn(B, eng.n_chunks, 64, 2, generator=g)
+        eng.expand_round(torch.as_tensor(s).cuda(), torch.as_tensor(c).cuda(), noise=noise.cuda())
+    snap = eng.tree_snapshot()
+    np.savez(out_path.format(rank=rank), parents=snap["parents"], states=snap["states"], counters=snap["counters"])
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_round_with_denoiser_builds_identical_tree(tmp_path):
+    out = str(tmp_path / "d{w}_r{rank}.npz")
+    mp.spawn(_gpu_denoiser_worker, args=(1, 29621, out.replace("{w}", "1")), nprocs=1, join=True)
+    mp.spawn(_gpu_denoiser_worker, args=(2, 29622, out.replace("{w}", "2")), nprocs=2, join=True)
+    a = np.load(out.replace("{w}", "1").format(rank=0))
+    for r in range(2):
+        b = np.load(out.replace("{w}", "2").format(rank=r))
+        assert np.array_equal(a["parents"], b["parents"])
+        # rows of a denoiser batch are independent of the batch they run in (tests/test_gpu_fullsize.py): bit-identical
+        assert np.array_equal(a["states"], b["states"])
+        assert np.array_equal(a["counters"][:5], b["counters"][:5])
+
+
+@pytest.mark.gpu
+def test_native_rccl_allgather_single_rank():
+    """The C-ABI communicator (ditree_comm_* / ditree_allgather_nodes) on one GPU: world 1 is the identity, but it opens
+    librccl, builds a communicator and runs the collective on the stream (what a host without torch.distributed binds)."""
+    import ctypes as C
+    sys.path.insert(0, REPO)
+    from ditreeonlineplanner_amd._lib import check, lib
+    from ditreeonlineplanner_amd.ops import Context
+    ctx = Context(0)
+    uid = (C.c_uint8 * 128)()
+    check(ctx._h, lib().ditree_comm_unique_id(ctx._h, uid), "comm_unique_id")
+    check(ctx._h, lib().ditree_comm_init(ctx._h, 0, 1, uid), "comm_init")
+    send = torch.arange(24, dtype=torch.float64, device="cuda") * 0.5
+    recv = torch.zeros(24, dtype=torch.float64, device="cuda")
+    check(ctx._h, lib().ditree_allgather_nodes(ctx._h, send.data_ptr(), recv.data_ptr(), 24, ctx.stream), "allgather_nodes")
+    torch.cuda.synchronize()
+    assert torch.equal(send, recv)
+    assert lib().ditree_comm_init(ctx._h, 0, 1, uid) != 0        # a second communicator on the same ctx is refused
+    check(ctx._h, lib().ditree_comm_destroy(ctx._h), "comm_destroy")
+    ctx.close()
