@@ -344,6 +344,88 @@ def gen_dynamics(out):
     print(f"dynamics known-answer: oracle vs independent evaluation max err {err:.2e} (self-referential)")
 
 
+def gen_dynamics_from_text(out):
+    """CarEnv._update_state / _check_done / step taken from the TEXT of the reference's car_env.py with `ast` (the module
+    itself cannot be imported: gymnasium, casadi) and executed with numpy; `MX.tanh` -- casadi's tanh applied to a numpy
+    float -- is bound to math.tanh.  The physical constants are the `self.X = <literal>` assignments of __init__, the action
+    bounds the `model.dthrottle_min ...` literals of bicycle_model().  This pins the EXPRESSION ORDER and the step / freeze
+    logic of the reference's own source text; it does not pin casadi's tanh (last-ulp), so a12 stays "parity unpinned"."""
+    import ast
+    import math
+    path = os.path.join(REF, "car_env.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "CarEnv"][0]
+    keep = {"_update_state", "_check_done", "step", "_calculate_reward", "_get_obs"}
+    funcs = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in keep]
+    ns = {"np": np, "MX": types.SimpleNamespace(tanh=math.tanh), "is_colliding_car": lambda st, mz: False}
+    exec(compile(ast.Module(body=funcs, type_ignores=[]), path, "exec"), ns)
+    consts = {}
+    init = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "__init__"][0]
+    for node in ast.walk(init):
+        if isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Attribute) \
+                and isinstance(node.targets[0].value, ast.Name) and node.targets[0].value.id == "self":
+            try:
+                consts[node.targets[0].attr] = ast.literal_eval(node.value)
+            except (ValueError, SyntaxError):
+                if ast.unparse(node.value).replace(" ", "") == "1.0/50.0":
+                    consts[node.targets[0].attr] = 1.0 / 50.0
+    bounds = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Attribute) \
+                and node.targets[0].attr in ("dthrottle_min", "dthrottle_max", "ddelta_min", "ddelta_max"):
+            bounds[node.targets[0].attr] = float(ast.literal_eval(node.value))
+    assert {"m", "C1", "C2", "Cm1", "Cm2", "Cr0", "Cr2", "dt"} <= set(consts), sorted(consts)
+    assert len(bounds) == 4, bounds
+
+    class Env:
+        pass
+    env = Env()
+    for k in ("m", "C1", "C2", "Cm1", "Cm2", "Cr0", "Cr2", "dt"):
+        setattr(env, k, consts[k])
+    env.action_space = types.SimpleNamespace(low=np.array([bounds["dthrottle_min"], bounds["ddelta_min"]], dtype=np.float32),
+                                             high=np.array([bounds["dthrottle_max"], bounds["ddelta_max"]], dtype=np.float32))
+    env.collision_checking = False
+    for name in keep:
+        setattr(Env, name, ns[name])
+    rng = np.random.default_rng(108)
+    n, T = 48, 64
+    S0 = np.stack([rng.uniform(-5, 5, n), rng.uniform(-5, 5, n), rng.uniform(-np.pi, np.pi, n),
+                   rng.uniform(-2, 5, n), rng.uniform(-1, 1, n), rng.uniform(-0.4, 0.4, n)], axis=1)
+    Aseq = np.stack([rng.uniform(-12, 12, (n, T)), rng.uniform(-3, 3, (n, T))], axis=2)
+    goals = S0[:, :2] + rng.uniform(-1.5, 1.5, (n, 2))          # near enough that some runs reach the 0.5 m radius and freeze
+    traj = np.zeros((n, T + 1, 6))
+    succ = np.zeros((n, T), dtype=bool)
+    for b in range(n):
+        env._state = S0[b].copy()
+        env.goal = goals[b].copy()
+        env.done = env.terminated = False
+        env.current_step = 0
+        traj[b, 0] = S0[b]
+        for i in range(T):
+            obs, rew, term, trunc, info = env.step(Aseq[b, i])
+            traj[b, i + 1] = env._state
+            succ[b, i] = bool(info["success"])
+    # the oracle: one Euler step + goal test, frozen once done (car_env.py:254)
+    mine = np.zeros_like(traj)
+    msucc = np.zeros_like(succ)
+    for b in range(n):
+        cur, done = S0[b].copy(), False
+        mine[b, 0] = cur
+        for i in range(T):
+            if not done:
+                cur = G.car_step(cur[None], Aseq[b, i][None])[0]
+                done = bool(G.goal_reached(cur, goals[b]))
+            mine[b, i + 1] = cur
+            msucc[b, i] = done
+    err = np.abs(mine - traj).max()
+    assert np.array_equal(msucc, succ), "goal / freeze logic differs from the reference text"
+    assert err == 0.0, err                       # same expressions, same numpy / libm: bit for bit
+    assert succ.any() and not succ.all()
+    out.update(dyntext_s0=S0, dyntext_actions=Aseq, dyntext_goals=goals, dyntext_traj_expected=traj, dyntext_success=succ)
+    print(f"dynamics from the reference's source text ({n} runs x {T} steps, {int(succ[:, -1].sum())} reach the goal and freeze): "
+          f"oracle == text, bit for bit")
+
+
 # --------------------------------------------------------------------------- planner traces
 class _TapeSampler(torch.nn.Module):
     """nn.Module so that BasePlanner keeps it (base_planner.py:56-57)."""
@@ -806,6 +888,11 @@ def main():
         gen_sampler_ant(net)
         np.savez_compressed(os.path.join(HERE, "network.npz"), **net)
         return
+    if sys.argv[1:] == ["dyntext"]:           # add the source-text dynamics vectors to geometry.npz (other entries kept)
+        geo = dict(np.load(os.path.join(HERE, "geometry.npz"), allow_pickle=False))
+        gen_dynamics_from_text(geo)
+        np.savez_compressed(os.path.join(HERE, "geometry.npz"), **geo)
+        return
     if sys.argv[1:] == ["schedule"]:          # add the prop_duration-schedule trace to traces.npz (other entries kept)
         tr = dict(np.load(os.path.join(HERE, "traces.npz"), allow_pickle=False))
         gen_trace_schedule(tr)
@@ -822,6 +909,7 @@ def main():
     gen_lidar(geo)
     gen_kdtree(geo)
     gen_dynamics(geo)
+    gen_dynamics_from_text(geo)
     gen_sampler(net)
     gen_sampler_ant(net)
     gen_timesteps(meta)

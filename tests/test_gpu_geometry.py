@@ -119,6 +119,29 @@ def test_dynamics_known_answers(ctx):
     assert np.array_equal(aout.cpu().numpy(), g["dyn_actions"])
 
 
+def test_dynamics_from_reference_source_text(ctx):
+    """The rollout kernel against trajectories produced by the TEXT of the reference's CarEnv.step / _update_state /
+    _check_done (golden dyntext_*): states to 1e-9 up to and including the step that reaches the goal, the goal flag at
+    exactly that step (the reference freezes afterwards, the kernel stops and zero-fills)."""
+    g = golden("geometry")
+    ctx.upload_maze(np.zeros((200, 200), dtype=np.float32))
+    S0, A, goals, traj, succ = (g[k] for k in ("dyntext_s0", "dyntext_actions", "dyntext_goals", "dyntext_traj_expected",
+                                               "dyntext_success"))
+    T = A.shape[1]
+    for b in range(len(S0)):                      # one goal per launch
+        state = dev(S0[b:b + 1])
+        status, states, aout, steps = ctx.car_rollout(state, dev(A[b:b + 1]), goals[b], A=T)
+        st, n = int(status.item()) & 0xFF, int(steps.item())
+        first = int(np.argmax(succ[b])) + 1 if succ[b].any() else None
+        if first is None:
+            assert st == 0 and n == T
+        else:
+            assert st == 1 and n == first, (b, st, n, first)
+        got = states.cpu().numpy()[0]
+        assert np.abs(got[: n + 1] - traj[b, : n + 1]).max() < 1e-9
+        assert np.array_equal(got[n + 1:], np.zeros_like(got[n + 1:]))
+
+
 @pytest.mark.parametrize("name", ["boxes", "Race_Track", "random_huge"])
 def test_rollout_chunk_vs_oracle(ctx, name):
     maze = load_maze(name)

@@ -70,6 +70,45 @@ def test_dynamics_known_answers():
     assert abs(n[0]) < 1e-15 and abs(n[1] - 0.04) < 1e-15 and n[2] == s[2]
 
 
+def test_dynamics_from_reference_source_text():
+    """Vectors produced by CarEnv.step / _update_state / _check_done taken from the TEXT of the reference's car_env.py
+    (ast, tests/golden/make_golden.py::gen_dynamics_from_text; MX.tanh bound to math.tanh): expression order, action
+    clipping, the goal radius and the frozen-after-success rule -- bit for bit."""
+    g = golden("geometry")
+    S0, A, goals = g["dyntext_s0"], g["dyntext_actions"], g["dyntext_goals"]
+    for b in range(len(S0)):
+        cur, done = S0[b].copy(), False
+        for i in range(A.shape[1]):
+            if not done:
+                cur = G.car_step(cur[None], A[b, i][None])[0]
+                done = bool(G.goal_reached(cur, goals[b]))
+            assert np.array_equal(cur, g["dyntext_traj_expected"][b, i + 1]), (b, i)
+            assert done == bool(g["dyntext_success"][b, i])
+
+
+def test_ant_sampler_preprocessing_matches_reference():
+    """oracle.sampler.ant_cond_vector == the reference's DiffusionSampler.forward (antmaze branch) on the recorded cases."""
+    g = golden("network")
+    nh = g["sampler_ant_n_hist"]
+    for i in range(len(nh)):
+        h = int(nh[i])
+        got = OS.ant_cond_vector(g["sampler_ant_obs"][i:i + 1, 3 - h:], g["sampler_ant_prev"][i:i + 1],
+                                 g["sampler_ant_has_prev"][i:i + 1], g["sampler_ant_goals"][i])
+        assert got.shape == (1, 97) and np.abs(got[0] - g["sampler_ant_cond_expected"][i]).max() < 2e-7
+
+
+def test_prop_duration_schedule_trace():
+    """The oracle planner with prop_duration = [128, 64, 32] rebuilds the reference planner's tree (golden sched_*)."""
+    g = golden("traces")
+    from tests.util import load_maze
+    pl = ORRT.OraclePlanner(load_maze("boxes"), g["sched_start"], g["sched_goal"], ActionTape(int(g["sched_seed"])).sampler(),
+                            prop_duration=[int(v) for v in g["sched_schedule"]])
+    pl.plan(ORRT.RandomTape(42), int(g["sched_budget"]), batch=1)
+    assert np.array_equal(np.array(pl.tree.parents, dtype=np.int32), g["sched_parents"])
+    assert np.array_equal(np.array(pl.tree.states), g["sched_states"])
+    assert pl.iterations == int(g["sched_iterations"])
+
+
 def test_sampler_pre_post_matches_reference():
     g = golden("network")
     cond = OS.car_cond_vector(g["sampler_states"], g["sampler_prev"], g["sampler_has_prev"], g["sampler_goals"])
