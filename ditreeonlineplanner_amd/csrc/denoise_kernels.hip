@@ -768,7 +768,7 @@ extern "C" int ditree_debug_halo_stamp(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_stamp), sizeof(g_halo_stamp));
 }
 #endif
-template <int ET, bool SPLIT>
+template <int ET, bool SPLIT, bool STAGGER>
 __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int A_BUF = 40960, W_BUF = 32768, W_BASE = 2 * A_BUF;
@@ -887,10 +887,16 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
   };
 
   // One K-step (chunk c, tap T); flags as in conv3_halo_kernel.  On entry af[0] = A(ks 0), bq[0] = B(ks 0, half 0).
-  auto step = [&](auto tT, auto tNext, auto tIW, auto tIA, auto tVM, int c) {
+  // LATE (STAGGER builds, waves 4..7 = the second wave of every SIMD): the wave issues its LDS-DMA pieces one and a half
+  // phases later than its SIMD partner -- the pieces of step s+1 in phase (0,1) of step s instead of those of step s+2 in
+  // phase (1,1) -- so the two waves of a SIMD are never both held in DMA issue while the matrix pipe idles
+  // (MI355X_MICROARCH.md, "Two waves per SIMD" item 9).  Same buffers, same barriers, same number of steps.
+  auto step = [&](auto tT, auto tNext, auto tIW, auto tIA, auto tVM, auto tLate, int c) {
     constexpr int T = decltype(tT)::value;
     constexpr bool HAS_NEXT = decltype(tNext)::value, ISSUE_W = decltype(tIW)::value, ISSUE_A = decltype(tIA)::value;
     constexpr int VM = decltype(tVM)::value;
+    constexpr bool LATE = decltype(tLate)::value;
+    constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? 5 : 0);
     asm volatile("" : "+v"(lrow0));    // keep the fragment-address arithmetic inside the step (hoisted it spills)
     // Each phase is its own scheduling region (sched_barrier), inside it the fragment reads for the NEXT phase
     // are issued first, then the 16 MFMAs: hipcc otherwise sinks the reads to the end of the phase and the next
@@ -902,9 +908,31 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
     __builtin_amdgcn_sched_barrier(0);
     rdA(1, c, T, 1);                    // phase (0,1)
     rdB(0, c, T, 1, 0);
-    mm16(0, 1, 1);
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    if constexpr (LATE && NV > 0) {
+      constexpr int T1 = (T + 1) % 3;
+      const int c1 = c + (T + 1) / 3;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          mm(0, 1, 1, mb, SNAKE ? ((mb & 1) ? 3 - jj : jj) : jj);
+          const int i = mb * 4 + jj;
+          const int d = (i & 1) ? -1 : (i >> 1);
+          if constexpr (ISSUE_W) { if (d >= 0 && d < 4) issue_w(c1, T1, d); }
+          if constexpr (ISSUE_A) { if (d >= 4 && d < 8) issue_a(c + 1, d - 4); if (i == 15) issue_a(c + 1, 4); }
+        }
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (!(i & 1) && (i >> 1) < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (i == 15 && NV == 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    } else {
+      mm16(0, 1, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     rdB(1, c, T, 1, 1);                 // phase (1,0)
     mm16(1, 0, 0);
@@ -931,16 +959,18 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
         // phase together: one issue behind every second MFMA (the ninth behind the last) instead of nine in a row
         // leaves the partner wave MFMAs to issue in between (-1.7 % kernel time).
         const int d = (i & 1) ? -1 : (i >> 1);
-        if constexpr (ISSUE_W) { if (d >= 0 && d < 4) issue_w(c2, T2, d); }
-        if constexpr (ISSUE_A) { if (d >= 4 && d < 8) issue_a(c + 2, d - 4); if (i == 15) issue_a(c + 2, 4); }
+        if constexpr (!LATE) {
+          if constexpr (ISSUE_W) { if (d >= 0 && d < 4) issue_w(c2, T2, d); }
+          if constexpr (ISSUE_A) { if (d >= 4 && d < 8) issue_a(c + 2, d - 4); if (i == 15) issue_a(c + 2, 4); }
+        }
       }
     if constexpr (HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);
-    constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? 5 : 0);
+    constexpr int NV3 = LATE ? 0 : NV;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-      if (!(i & 1) && (i >> 1) < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
-      if (i == 15 && NV == 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+      if (!(i & 1) && (i >> 1) < NV3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+      if (i == 15 && NV3 == 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -958,42 +988,67 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
   for (int q = 0; q < 4; ++q) issue_w(0, 0, q);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  const bool late = STAGGER && w >= 4;              // wave-uniform; the two branches below are complete copies of the K loop
+  if (!late) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) issue_w(0, 1, q);
+    for (int q = 0; q < 4; ++q) issue_w(0, 1, q);
 #pragma unroll
-  for (int i = 0; i < 5; ++i) issue_a(1, i);
+    for (int i = 0; i < 5; ++i) issue_a(1, i);
+  }
   rdA(0, 0, 0, 0);
   rdB(0, 0, 0, 0, 0);
 
 #ifdef HALO16_STAMP
   const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  for (int c = 0; c < nv - 2; ++c) {
-    step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, c);          // waits W(c,1); A(c+1) may stay in flight
-    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, c);
-    step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, c);          // stages W(c+1,1) then A(c+2)
-  }
+  if (!late) {
+    for (int c = 0; c < nv - 2; ++c) {
+      step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, Ff{}, c);          // waits W(c,1); A(c+1) may stay in flight
+      step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, Ff{}, c);
+      step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, Ff{}, c);          // stages W(c+1,1) then A(c+2)
+    }
 #ifdef HALO16_STAMP
-  if (blockIdx.x == 100 && tid == 0 && nv >= 32) {
-    g_halo_stamp[0] = __builtin_amdgcn_s_memtime() - st0;
-    g_halo_stamp[1] = __builtin_amdgcn_s_memrealtime() - rt0;
-    g_halo_stamp[2] = (unsigned long long)(nv - 2) * 3;
-  }
+    if (blockIdx.x == 100 && tid == 0 && nv >= 32) {
+      g_halo_stamp[0] = __builtin_amdgcn_s_memtime() - st0;
+      g_halo_stamp[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+      g_halo_stamp[2] = (unsigned long long)(nv - 2) * 3;
+    }
 #endif
-  // The counted wait (vmcnt(5)) is only used inside the loop above, whose body holds no other vector-memory
-  // operation.  The two tail chunks wait for everything: register spills the compiler may place here (scratch
-  // accesses count in vmcnt) must not take part in a counted wait.
-  {
-    const int c = nv - 2;
-    step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, c);
-    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, c);
-    step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, c);
-  }
-  {
-    const int c = nv - 1;
-    step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, c);
-    step(I1{}, Tt{}, Ff{}, Ff{}, I0{}, c);
-    step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, c);
+    // The counted wait (vmcnt(5)) is only used inside the loop above, whose body holds no other vector-memory
+    // operation.  The two tail chunks wait for everything: register spills the compiler may place here (scratch
+    // accesses count in vmcnt) must not take part in a counted wait.
+    {
+      const int c = nv - 2;
+      step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, Ff{}, c);
+      step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, Ff{}, c);
+      step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, Ff{}, c);
+    }
+    {
+      const int c = nv - 1;
+      step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, Ff{}, c);
+      step(I1{}, Tt{}, Ff{}, Ff{}, I0{}, Ff{}, c);
+      step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, Ff{}, c);
+    }
+  } else if constexpr (STAGGER) {
+    // late waves: in step (c, T) they stage W of the NEXT step, in (c, 1) also A(c + 1) behind it (counted wait: the five
+    // A pieces may stay in flight across that step's barrier, they are needed one step later)
+    for (int c = 0; c < nv - 2; ++c) {
+      step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, Tt{}, c);
+      step(I1{}, Tt{}, Tt{}, Tt{}, I5{}, Tt{}, c);
+      step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, Tt{}, c);
+    }
+    {
+      const int c = nv - 2;                         // A(nv - 1) is the last block: waited in full (no counted wait in the tail)
+      step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, Tt{}, c);
+      step(I1{}, Tt{}, Tt{}, Tt{}, I0{}, Tt{}, c);
+      step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, Tt{}, c);
+    }
+    {
+      const int c = nv - 1;
+      step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, Tt{}, c);
+      step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, Tt{}, c);
+      step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, Tt{}, c);
+    }
   }
   __syncthreads();
   gemm_epilogue16<ET, SPLIT>(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
@@ -1321,10 +1376,14 @@ static void ensure_lds_attrs() {
   hipFuncSetAttribute((const void*)conv_gemm_kernel<0, true>, at, 131072);
   hipFuncSetAttribute((const void*)conv_gemm_kernel<1, true>, at, 131072);
   hipFuncSetAttribute((const void*)conv_gemm_kernel<2, true>, at, 131072);
-  hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, false>, at, 147456);
-  hipFuncSetAttribute((const void*)conv3_halo16_kernel<1, false>, at, 147456);
-  hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, true>, at, 147456);
-  hipFuncSetAttribute((const void*)conv3_halo16_kernel<1, true>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, false, false>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16_kernel<1, false, false>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, true, false>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16_kernel<1, true, false>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, false, true>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16_kernel<1, false, true>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, true, true>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16_kernel<1, true, true>, at, 147456);
   hipFuncSetAttribute((const void*)gemm16_kernel<0, false>, at, 131072);
   hipFuncSetAttribute((const void*)gemm16_kernel<1, false>, at, 131072);
   hipFuncSetAttribute((const void*)gemm16_kernel<0, true>, at, 131072);
@@ -1338,12 +1397,25 @@ void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
   const int ntn = (p.N + 255) >> 8, ntm = (p.M + 255) >> 8;
   const dim3 grid(ntm * ntn), block(512);
   if (halo_eligible(p, fmt)) {
+    // DITREE_HALO_STAGGER=0/1: A/B switch of the late-wave DMA issue (both variants compute the same values)
+    static int stagger = -1;
+    if (stagger < 0) { const char* e = getenv("DITREE_HALO_STAGGER"); stagger = (e && atoi(e)) ? 1 : 0; }
+    if (stagger) {
+      if (split) {
+        if (f16) hipLaunchKernelGGL((conv3_halo16_kernel<1, true, true>), grid, block, 147456, s, p);
+        else hipLaunchKernelGGL((conv3_halo16_kernel<0, true, true>), grid, block, 147456, s, p);
+      } else {
+        if (f16) hipLaunchKernelGGL((conv3_halo16_kernel<1, false, true>), grid, block, 147456, s, p);
+        else hipLaunchKernelGGL((conv3_halo16_kernel<0, false, true>), grid, block, 147456, s, p);
+      }
+      return;
+    }
     if (split) {
-      if (f16) hipLaunchKernelGGL((conv3_halo16_kernel<1, true>), grid, block, 147456, s, p);
-      else hipLaunchKernelGGL((conv3_halo16_kernel<0, true>), grid, block, 147456, s, p);
+      if (f16) hipLaunchKernelGGL((conv3_halo16_kernel<1, true, false>), grid, block, 147456, s, p);
+      else hipLaunchKernelGGL((conv3_halo16_kernel<0, true, false>), grid, block, 147456, s, p);
     } else {
-      if (f16) hipLaunchKernelGGL((conv3_halo16_kernel<1, false>), grid, block, 147456, s, p);
-      else hipLaunchKernelGGL((conv3_halo16_kernel<0, false>), grid, block, 147456, s, p);
+      if (f16) hipLaunchKernelGGL((conv3_halo16_kernel<1, false, false>), grid, block, 147456, s, p);
+      else hipLaunchKernelGGL((conv3_halo16_kernel<0, false, false>), grid, block, 147456, s, p);
     }
     return;
   }

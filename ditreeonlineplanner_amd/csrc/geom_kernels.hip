@@ -297,15 +297,16 @@ __device__ __forceinline__ void car_euler_step(double* s, double a0r, double a1r
 
 // ------------------------------------------------------------------------- rollout
 // planners/base_planner.py:257-320 + car_env.py:240-282,341-396 + common/map_utils.py:103-115 for a batch of candidates.
-// One wave (64-thread work-group) per 64 candidates, one lane per candidate for the sequential part (A Euler steps,
-// each with goal + two-ball collision test, early exit), so 1024 candidates already spread over 16 CUs and 65 536 over
-// all of them.  Global traffic is moved by the WAVE, not by the lane: a lane's action row and (A + 1, 6) state rows are
-// 16..50-byte fragments at a stride of hundreds of bytes, so per-lane loads / stores touch a line per fragment (measured
-// on the first version: 227 MB moved for 71 MB of algorithmic bytes, 38 % of the wave time in s_waitcnt).  Per chunk of
-// RO_S steps the wave loads the 64 x RO_S x 2 action block with consecutive lanes on consecutive doubles into LDS, the
-// lanes step out of LDS, write their states back into LDS, and the wave flushes 64 x rows x 6 doubles the same way:
-// every candidate's rows of a chunk are one contiguous 200..250-byte run in memory.
-//   LDS per wave: maze + 64 x (2 RO_S + 1) + 64 x (6 (RO_S + 1) + 1) doubles (odd strides: conflict-free b64 access).
+// One lane per candidate (the A Euler steps with their goal + two-ball collision tests are a sequential FP64 chain of
+// ~1 200 instructions per step: 3 sin/cos pairs, tanh, 9 sqrt / hypot), 64-thread work-groups so that 1 024 candidates
+// already occupy 16 CUs and 65 536 all of them.  The actions of the next RO_S steps are requested (16-B loads into
+// registers) before the current RO_S steps are integrated, so the chain never waits for a load; states are stored per
+// lane as they are produced (stores do not stall the chain).
+//   Measured alternatives (MI355X, 65 536 x 16, profiles/r02_rollout_*): 256-thread groups without prefetch 68 us (38 % of
+//   the wave time in s_waitcnt); wave-cooperative LDS-staged loads and (A + 1, 6)-row stores (every candidate's rows
+//   leave as one contiguous run) 100 us -- with one wave per SIMD each of its 12 barriers exposes a full memory latency and
+//   the index arithmetic of the wave-wide copies adds a third to the instruction count.  The kernel is bound by the FP64
+//   chain, not by HBM (1.0 TB/s of algorithmic bytes = 13 % of peak): see DESIGN.md.
 #define RO_S 4
 __global__ void __launch_bounds__(64)
 car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, double* __restrict__ state_io,
@@ -316,94 +317,85 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
                    uint8_t* __restrict__ has_prev_io, const int32_t* __restrict__ idx, int act_dense,
                    const int32_t* __restrict__ budget, int chunk_j) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  constexpr int AS = 2 * RO_S + 1, SS = 6 * (RO_S + 1) + 1;          // doubles per lane in the action / state stage
-  const int maze_bytes = (rows * cols + 15) & ~15;
-  double* st_a = (double*)(lds + maze_bytes);                       // [64][AS]
-  double* st_s = st_a + 64 * AS;                                    // [64][SS]
-  long long* rowb = (long long*)(st_s + 64 * SS);                   // [64] candidate index of each lane (-1: not running)
   stage_maze(lds, maze, rows * cols);
-  const int lane = threadIdx.x;
-  const int ob = blockIdx.x * 64 + lane;
-  int b = -1;
-  if (ob < B) {
-    b = idx ? idx[ob] : ob;                         // compacted rounds: actions are dense (row ob), the rest per candidate
-    if (status_io[b] != DITREE_ST_OK) b = -1;
-    else if (budget != nullptr && chunk_j >= budget[b]) b = -1;      // this visit's edge is shorter (prop_duration schedule)
-  }
-  const bool run = b >= 0;
-  // action row (act_dense: row ob) and output rows of every lane, for the wave-wide copies
-  long long* arow = rowb + 64;                                       // [64] action row index
-  rowb[lane] = run ? (long long)b : -1;
-  arow[lane] = run ? (long long)(act_dense ? ob : b) : -1;
-  double s[6] = {0, 0, 0, 0, 0, 0};
-  if (run) {
+  const int ob = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ob >= B) return;
+  const int b = idx ? idx[ob] : ob;                 // compacted rounds: actions are dense (row ob), the rest per candidate
+  if (status_io[b] != DITREE_ST_OK) return;
+  if (budget != nullptr && chunk_j >= budget[b]) return;      // this visit's edge is shorter (prop_duration schedule)
+  double s[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) s[k] = state_io[(size_t)b * 6 + k];
+  for (int k = 0; k < 6; ++k) s[k] = state_io[(size_t)b * 6 + k];
+  const double* act = actions + (size_t)(act_dense ? ob : b) * act_stride;
+  double* so = states_out ? states_out + (size_t)b * states_stride : nullptr;
+  double* ao = actions_out ? actions_out + (size_t)b * actout_stride : nullptr;
+  if (so) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) so[k] = s[k];                                   // states_sequence[0] = state
   }
-  int status = DITREE_ST_OK, steps = 0, ended = 0;                   // ended: no further step (goal / collision)
+  int status = DITREE_ST_OK;
+  int steps = 0;
   double la0 = 0.0, la1 = 0.0;
-  __syncthreads();
-  for (int s0 = 0; s0 < A; s0 += RO_S) {
-    const int ns = min(RO_S, A - s0);
-    // ---- wave load of the action block: element e -> (candidate lane c, double k of its ns x 2 run)
-    for (int e = lane; e < 64 * ns * 2; e += 64) {
-      const int c = e / (ns * 2), k = e - c * (ns * 2);
-      const long long ar = arow[c];
-      if (ar >= 0) st_a[c * AS + k] = actions[(size_t)ar * act_stride + 2 * s0 + k];
-    }
-    __syncthreads();
-    // ---- the lane's steps of this chunk; state rows into LDS (row 0 of the first chunk = the start state)
-    const int r0 = (s0 == 0) ? 0 : 1;                                // first staged row index that is flushed
-    if (run) {
-      double* ms = st_s + lane * SS;
-      double* ma = st_a + lane * AS;
-      if (s0 == 0) {
+  int i = 0;
+  const bool al16 = ((((uintptr_t)act) & 15) == 0);
+  double2 cur[RO_S], nxt[RO_S];
+  auto fetch = [&](double2 (&dst)[RO_S], int s0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) ms[k] = s[k];                     // states_sequence[0] = state
+    for (int j = 0; j < RO_S; ++j) {
+      const int t = s0 + j;
+      if (t < A) {
+        if (al16) dst[j] = *(const double2*)(act + 2 * t);
+        else dst[j] = double2{act[2 * t], act[2 * t + 1]};
+      } else {
+        dst[j] = double2{0.0, 0.0};
       }
-      for (int i = 0; i < ns; ++i) {
-        double* row = ms + (size_t)(i + 1) * 6;
-        if (ended) {
-          // rows after the last executed step stay zero (states :282); only the goal branch zeroes the remaining actions
-          // (:314-317) -- a collided edge is discarded by the caller, its untouched tail is copied through
+    }
+  };
+  fetch(cur, 0);
+  bool ended = false;
+  for (int s0 = 0; s0 < A && !ended; s0 += RO_S) {
+    fetch(nxt, s0 + RO_S);                           // in flight while this chunk integrates
 #pragma unroll
-          for (int k = 0; k < 6; ++k) row[k] = 0.0;
-          if (status == DITREE_ST_GOAL) { ma[2 * i] = 0.0; ma[2 * i + 1] = 0.0; }
-          continue;
-        }
-        const double a0r = ma[2 * i], a1r = ma[2 * i + 1];
-        car_euler_step(s, a0r, a1r);
-        steps = s0 + i + 1;
+    for (int j = 0; j < RO_S; ++j) {
+      if (ended || s0 + j >= A) break;
+      i = s0 + j;
+      const double a0r = cur[j].x, a1r = cur[j].y;
+      car_euler_step(s, a0r, a1r);
+      steps = i + 1;
+      if (so) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) row[k] = s[k];
-        la0 = a0r; la1 = a1r;
-        double ex = s[0] - gx, ey = s[1] - gy;
-        bool done = sqrt(fma(ey, ey, ex * ex)) < 0.5;   // np.linalg.norm (ddot rounds as one fma), car_env.py:346-351
-        bool coll = car_collides(s[0], s[1], s[2], lds, rows, cols);                 // base_planner.py:306
-        if (coll) { status = DITREE_ST_COLLIDED | (done ? DITREE_ST_FLAG_GOAL_AT_COLLISION : 0); ended = 1; }
-        else if (done) { status = DITREE_ST_GOAL; ended = 1; }                        // :314-317
+        for (int k = 0; k < 6; ++k) so[(size_t)(i + 1) * 6 + k] = s[k];
+      }
+      if (ao) { ao[2 * i] = a0r; ao[2 * i + 1] = a1r; }
+      la0 = a0r; la1 = a1r;
+      double ex = s[0] - gx, ey = s[1] - gy;
+      bool done = sqrt(fma(ey, ey, ex * ex)) < 0.5;   // np.linalg.norm (ddot rounds as one fma), car_env.py:346-351
+      bool coll = car_collides(s[0], s[1], s[2], lds, rows, cols);                 // base_planner.py:306
+      if (coll) {
+        status = DITREE_ST_COLLIDED | (done ? DITREE_ST_FLAG_GOAL_AT_COLLISION : 0);
+        ended = true;
+      } else if (done) {                                                          // :314-317
+        status = DITREE_ST_GOAL;
+        ended = true;
       }
     }
-    __syncthreads();
-    // ---- wave flush: states rows [s0 + r0, s0 + ns] and actions [s0, s0 + ns) of every running lane
-    if (states_out) {
-      const int nr = ns + 1 - r0;                                    // rows to write per candidate
-      for (int e = lane; e < 64 * nr * 6; e += 64) {
-        const int c = e / (nr * 6), k = e - c * (nr * 6);
-        const long long cb = rowb[c];
-        if (cb >= 0) states_out[(size_t)cb * states_stride + (size_t)(s0 + r0) * 6 + k] = st_s[c * SS + r0 * 6 + k];
-      }
-    }
-    if (actions_out) {
-      for (int e = lane; e < 64 * ns * 2; e += 64) {
-        const int c = e / (ns * 2), k = e - c * (ns * 2);
-        const long long cb = rowb[c];
-        if (cb >= 0) actions_out[(size_t)cb * actout_stride + 2 * s0 + k] = st_a[c * AS + k];
-      }
-    }
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RO_S; ++j) cur[j] = nxt[j];
   }
-  if (!run) return;
+  // rows after the last executed step stay zero (states :282; actions zeroed :315)
+  for (int r = steps; r < A; ++r) {
+    if (so) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) so[(size_t)(r + 1) * 6 + k] = 0.0;
+    }
+    if (ao) {
+      // only the goal branch zeroes the remaining actions (:314-317); a collided edge is discarded
+      // by the caller, its untouched tail is copied through like the reference's array
+      const bool z = (status == DITREE_ST_GOAL);
+      ao[2 * r] = z ? 0.0 : act[2 * r];
+      ao[2 * r + 1] = z ? 0.0 : act[2 * r + 1];
+    }
+  }
 #pragma unroll
   for (int k = 0; k < 6; ++k) state_io[(size_t)b * 6 + k] = s[k];
   status_io[b] = status;
@@ -421,7 +413,7 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
                            int32_t* steps_out, int64_t steps_stride, int32_t* chunks_run, double* prev_action_io,
                            uint8_t* has_prev_io, const int32_t* idx, int act_dense, hipStream_t s, const int32_t* budget,
                            int chunk_j) {
-  size_t lds = (((size_t)rows * cols + 15) & ~(size_t)15) + (size_t)64 * ((2 * RO_S + 1) + (6 * (RO_S + 1) + 1) + 2) * 8;
+  size_t lds = ((size_t)rows * cols + 15) & ~(size_t)15;
   hipLaunchKernelGGL(car_rollout_kernel, dim3((B + 63) / 64), dim3(64), lds, s, maze, rows, cols, state_io,
                      actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out,
                      actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense,

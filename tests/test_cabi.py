@@ -52,7 +52,7 @@ def test_halo_kernel_loop_has_no_scratch_traffic(tmp_path):
     # every instantiation: <element type 0 bf16 / 1 f16, split 0 / 1>; the split ones spill in their (exact-Mish) epilogue,
     # which is fine -- but never inside the counted-wait loop
     for et, split, mfma in ((0, 0, "bf16"), (1, 0, "f16"), (0, 1, "bf16"), (1, 1, "f16")):
-        start = text.index(f"_Z19conv3_halo16_kernelILi{et}ELb{split}EEv14ConvGemmParams:")
+        start = text.index(f"_Z19conv3_halo16_kernelILi{et}ELb{split}ELb0EEv14ConvGemmParams:")
         body = text[start:text.index(".Lfunc_end", start)].splitlines()
         headers = [n for n, l in enumerate(body) if "Loop Header" in l]
         assert len(headers) == 1, "expected exactly one loop (the chunk loop) in the halo kernel"

@@ -106,3 +106,86 @@ def test_denoise_argument_checks(ctx):
     ctx.denoise_reserve(32, 0)                                            # growing the workspace is allowed
     out = ctx.denoise(n, torch.zeros(32, 20, 20, device="cuda"), torch.zeros(32, 7, device="cuda"), want_actions=False)
     assert torch.isfinite(out).all()
+
+
+def test_round_rejects_mismatched_horizon_and_map(ctx):
+    """ditree_expand_round sizes its scratch from the caller's pred_horizon / local-map size while the denoiser strides
+    them by ITS dimensions: a mismatch is a clean DITREE_E_ARG, never an out-of-bounds write."""
+    from ditreeonlineplanner_amd._lib import DitreeError
+    from ditreeonlineplanner_amd.engine import ExpansionEngine
+    from ditreeonlineplanner_amd.model import NoisePredNet
+    maze = load_maze("boxes")
+    start = np.array([*G.cell_rowcol_to_xy([17, 2], maze), 0.7, 0, 0, 0])
+    goal = np.array([*G.cell_rowcol_to_xy([2, 17], maze), 0, 0, 0, 0])
+    net = NoisePredNet(seed=1)
+    net.bind(ctx, precision=0, max_batch=16)
+    s = torch.zeros(8, 6, dtype=torch.float64, device="cuda")
+    c = torch.zeros(8, 2, dtype=torch.float64, device="cuda")
+    eng = ExpansionEngine(ctx, maze, start, goal, edge_length=32, pred_horizon=32, batch=8, capacity=64)
+    with pytest.raises(DitreeError, match="pred_horizon 32"):
+        eng.expand_round(s, c, noise=torch.zeros(8, 4, 32, 2, device="cuda"))
+    eng = ExpansionEngine(ctx, maze, start, goal, edge_length=32, local_map_size=16, batch=8, capacity=64)
+    with pytest.raises(DitreeError, match="local map 16"):
+        eng.expand_round(s, c, noise=torch.zeros(8, 4, 64, 2, device="cuda"))
+    # tensors of the wrong shape never reach the library
+    with pytest.raises(ValueError):
+        ctx.denoise(torch.zeros(8, 32, 2, device="cuda"), torch.zeros(8, 20, 20, device="cuda"), torch.zeros(8, 7, device="cuda"))
+    with pytest.raises(ValueError):
+        ctx.denoise(torch.zeros(8, 64, 2, device="cuda"), torch.zeros(8, 16, 16, device="cuda"), torch.zeros(8, 7, device="cuda"))
+
+
+def test_weight_blob_checksum_is_verified(ctx):
+    from ditreeonlineplanner_amd._lib import DitreeError
+    from ditreeonlineplanner_amd.model import NoisePredNet
+    from ditreeonlineplanner_amd.weights import pack_state_dict
+    net = NoisePredNet(seed=2)
+    blob, manifest = pack_state_dict(net.state_dict(), pred_horizon=64, local_map_size=20)
+    assert "#checksum" in manifest and "#config pred_horizon 64 local_map_size 20" in manifest
+    bad = blob.copy()
+    bad[12345] += 1.0
+    with pytest.raises(DitreeError, match="checksum"):
+        ctx.load_weights(bad, manifest)
+    ctx.load_weights(blob, manifest)
+
+
+def test_shared_context_keeps_each_planners_maze_and_each_nets_weights(ctx):
+    """Two engines with different mazes and two nets share one ctx (what the facades' default_context does): every launch
+    re-uploads its owner's maze / weights when somebody else used the ctx in between."""
+    from ditreeonlineplanner_amd.engine import ExpansionEngine
+    from ditreeonlineplanner_amd.model import NoisePredNet
+    m1, m2 = load_maze("boxes"), load_maze("random_huge")
+
+    def mk(maze, rc0, rc1):
+        start = np.array([*G.cell_rowcol_to_xy(rc0, maze), 0.7, 0, 0, 0])
+        goal = np.array([*G.cell_rowcol_to_xy(rc1, maze), 0, 0, 0, 0])
+        return ExpansionEngine(ctx, maze, start, goal, edge_length=32, batch=64, capacity=1024), start, goal
+    e1, s1, g1 = mk(m1, [17, 2], [2, 17])
+    rt, at = ORRT.RandomTape(42), ActionTape(5)
+    s, c = rt.draw_round(64, m1.shape[1], m1.shape[0], g1)
+    acts = np.stack([at.actions(np.arange(64), j) for j in range(e1.n_chunks)], axis=1)
+    args = (torch.as_tensor(s).cuda(), torch.as_tensor(c).cuda())
+    e1.expand_round(*args, inject_actions=torch.as_tensor(acts).cuda())
+    ref = e1.tree_snapshot()
+    e1b, _, _ = mk(m1, [17, 2], [2, 17])
+    e2, _, _ = mk(m2, [1, 1], [29, 29])                  # uploads ANOTHER maze into the shared ctx
+    assert ctx.maze_owner is e2
+    e1b.expand_round(*args, inject_actions=torch.as_tensor(acts).cuda())
+    assert ctx.maze_owner is e1b
+    again = e1b.tree_snapshot()
+    assert np.array_equal(ref["parents"], again["parents"]) and np.array_equal(ref["states"], again["states"])
+    # weights: the second bind replaces the first net's device copy; the first net notices and re-binds
+    n1, n2 = NoisePredNet(seed=1), NoisePredNet(seed=2)
+    x = torch.randn(4, 64, 2)
+    lm = torch.zeros(4, 20, 20)
+    cd = torch.zeros(4, 7)
+    n1.bind(ctx, precision=0, max_batch=16)
+    y1 = n1(x, lm, torch.zeros(4), cd).cpu()
+    n2.bind(ctx, precision=0, max_batch=16)
+    y2 = n2(x, lm, torch.zeros(4), cd).cpu()
+    assert not torch.equal(y1, y2) and not n1.is_current(ctx)
+    assert torch.equal(n1(x, lm, torch.zeros(4), cd).cpu(), y1)
+    # in-place parameter updates after bind are picked up too
+    with torch.no_grad():
+        next(iter(n1.parameters())).mul_(1.5)
+    assert not n1.is_current(ctx)
+    assert not torch.equal(n1(x, lm, torch.zeros(4), cd).cpu(), y1)
