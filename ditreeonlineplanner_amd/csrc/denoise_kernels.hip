@@ -768,7 +768,7 @@ extern "C" int ditree_debug_halo_stamp(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_stamp), sizeof(g_halo_stamp));
 }
 #endif
-template <int ET, bool SPLIT, bool STAGGER>
+template <int ET, bool SPLIT>
 __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int A_BUF = 40960, W_BUF = 32768, W_BASE = 2 * A_BUF;
@@ -887,15 +887,10 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
   };
 
   // One K-step (chunk c, tap T); flags as in conv3_halo_kernel.  On entry af[0] = A(ks 0), bq[0] = B(ks 0, half 0).
-  // LATE (STAGGER builds, waves 4..7 = the second wave of every SIMD): the wave issues its LDS-DMA pieces one and a half
-  // phases later than its SIMD partner -- the pieces of step s+1 in phase (0,1) of step s instead of those of step s+2 in
-  // phase (1,1) -- so the two waves of a SIMD are never both held in DMA issue while the matrix pipe idles
-  // (MI355X_MICROARCH.md, "Two waves per SIMD" item 9).  Same buffers, same barriers, same number of steps.
-  auto step = [&](auto tT, auto tNext, auto tIW, auto tIA, auto tVM, auto tLate, int c) {
+  auto step = [&](auto tT, auto tNext, auto tIW, auto tIA, auto tVM, int c) {
     constexpr int T = decltype(tT)::value;
     constexpr bool HAS_NEXT = decltype(tNext)::value, ISSUE_W = decltype(tIW)::value, ISSUE_A = decltype(tIA)::value;
     constexpr int VM = decltype(tVM)::value;
-    constexpr bool LATE = decltype(tLate)::value;
     constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? 5 : 0);
     asm volatile("" : "+v"(lrow0));    // keep the fragment-address arithmetic inside the step (hoisted it spills)
     // Each phase is its own scheduling region (sched_barrier), inside it the fragment reads for the NEXT phase
@@ -908,31 +903,9 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
     __builtin_amdgcn_sched_barrier(0);
     rdA(1, c, T, 1);                    // phase (0,1)
     rdB(0, c, T, 1, 0);
-    if constexpr (LATE && NV > 0) {
-      constexpr int T1 = (T + 1) % 3;
-      const int c1 = c + (T + 1) / 3;
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          mm(0, 1, 1, mb, SNAKE ? ((mb & 1) ? 3 - jj : jj) : jj);
-          const int i = mb * 4 + jj;
-          const int d = (i & 1) ? -1 : (i >> 1);
-          if constexpr (ISSUE_W) { if (d >= 0 && d < 4) issue_w(c1, T1, d); }
-          if constexpr (ISSUE_A) { if (d >= 4 && d < 8) issue_a(c + 1, d - 4); if (i == 15) issue_a(c + 1, 4); }
-        }
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (!(i & 1) && (i >> 1) < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        if (i == 15 && NV == 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-    } else {
-      mm16(0, 1, 1);
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-    }
+    mm16(0, 1, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     __builtin_amdgcn_sched_barrier(0);
     rdB(1, c, T, 1, 1);                 // phase (1,0)
     mm16(1, 0, 0);
@@ -959,18 +932,15 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
         // phase together: one issue behind every second MFMA (the ninth behind the last) instead of nine in a row
         // leaves the partner wave MFMAs to issue in between (-1.7 % kernel time).
         const int d = (i & 1) ? -1 : (i >> 1);
-        if constexpr (!LATE) {
-          if constexpr (ISSUE_W) { if (d >= 0 && d < 4) issue_w(c2, T2, d); }
-          if constexpr (ISSUE_A) { if (d >= 4 && d < 8) issue_a(c + 2, d - 4); if (i == 15) issue_a(c + 2, 4); }
-        }
+        if constexpr (ISSUE_W) { if (d >= 0 && d < 4) issue_w(c2, T2, d); }
+        if constexpr (ISSUE_A) { if (d >= 4 && d < 8) issue_a(c + 2, d - 4); if (i == 15) issue_a(c + 2, 4); }
       }
     if constexpr (HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);
-    constexpr int NV3 = LATE ? 0 : NV;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-      if (!(i & 1) && (i >> 1) < NV3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
-      if (i == 15 && NV3 == 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+      if (!(i & 1) && (i >> 1) < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+      if (i == 15 && NV == 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -988,70 +958,260 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
   for (int q = 0; q < 4; ++q) issue_w(0, 0, q);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  const bool late = STAGGER && w >= 4;              // wave-uniform; the two branches below are complete copies of the K loop
-  if (!late) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) issue_w(0, 1, q);
+  for (int q = 0; q < 4; ++q) issue_w(0, 1, q);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) issue_a(1, i);
-  }
+  for (int i = 0; i < 5; ++i) issue_a(1, i);
   rdA(0, 0, 0, 0);
   rdB(0, 0, 0, 0, 0);
 
 #ifdef HALO16_STAMP
   const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (!late) {
-    for (int c = 0; c < nv - 2; ++c) {
-      step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, Ff{}, c);          // waits W(c,1); A(c+1) may stay in flight
-      step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, Ff{}, c);
-      step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, Ff{}, c);          // stages W(c+1,1) then A(c+2)
-    }
+  for (int c = 0; c < nv - 2; ++c) {
+    step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, c);          // waits W(c,1); A(c+1) may stay in flight
+    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, c);
+    step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, c);          // stages W(c+1,1) then A(c+2)
+  }
 #ifdef HALO16_STAMP
-    if (blockIdx.x == 100 && tid == 0 && nv >= 32) {
-      g_halo_stamp[0] = __builtin_amdgcn_s_memtime() - st0;
-      g_halo_stamp[1] = __builtin_amdgcn_s_memrealtime() - rt0;
-      g_halo_stamp[2] = (unsigned long long)(nv - 2) * 3;
-    }
+  if (blockIdx.x == 100 && tid == 0 && nv >= 32) {
+    g_halo_stamp[0] = __builtin_amdgcn_s_memtime() - st0;
+    g_halo_stamp[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    g_halo_stamp[2] = (unsigned long long)(nv - 2) * 3;
+  }
 #endif
-    // The counted wait (vmcnt(5)) is only used inside the loop above, whose body holds no other vector-memory
-    // operation.  The two tail chunks wait for everything: register spills the compiler may place here (scratch
-    // accesses count in vmcnt) must not take part in a counted wait.
-    {
-      const int c = nv - 2;
-      step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, Ff{}, c);
-      step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, Ff{}, c);
-      step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, Ff{}, c);
-    }
-    {
-      const int c = nv - 1;
-      step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, Ff{}, c);
-      step(I1{}, Tt{}, Ff{}, Ff{}, I0{}, Ff{}, c);
-      step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, Ff{}, c);
-    }
-  } else if constexpr (STAGGER) {
-    // late waves: in step (c, T) they stage W of the NEXT step, in (c, 1) also A(c + 1) behind it (counted wait: the five
-    // A pieces may stay in flight across that step's barrier, they are needed one step later)
-    for (int c = 0; c < nv - 2; ++c) {
-      step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, Tt{}, c);
-      step(I1{}, Tt{}, Tt{}, Tt{}, I5{}, Tt{}, c);
-      step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, Tt{}, c);
-    }
-    {
-      const int c = nv - 2;                         // A(nv - 1) is the last block: waited in full (no counted wait in the tail)
-      step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, Tt{}, c);
-      step(I1{}, Tt{}, Tt{}, Tt{}, I0{}, Tt{}, c);
-      step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, Tt{}, c);
-    }
-    {
-      const int c = nv - 1;
-      step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, Tt{}, c);
-      step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, Tt{}, c);
-      step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, Tt{}, c);
-    }
+  // The counted wait (vmcnt(5)) is only used inside the loop above, whose body holds no other vector-memory
+  // operation.  The two tail chunks wait for everything: register spills the compiler may place here (scratch
+  // accesses count in vmcnt) must not take part in a counted wait.
+  {
+    const int c = nv - 2;
+    step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, c);
+    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, c);
+    step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, c);
+  }
+  {
+    const int c = nv - 1;
+    step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, c);
+    step(I1{}, Tt{}, Ff{}, Ff{}, I0{}, c);
+    step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, c);
   }
   __syncthreads();
   gemm_epilogue16<ET, SPLIT>(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
+}
+
+// =================================================================================================
+// conv3_halo16x3_kernel: the halo kernel for the split (hi + lo) formats.
+//
+// Same tile, wave geometry, LDS image sizes, double buffers, barrier protocol and epilogue as conv3_halo16_kernel.  What
+// differs is what a 128-byte LDS row holds and how many MFMAs a K-step runs on it: a row is [32 channels of the hi plane |
+// the same 32 channels of the lo plane] (the 16-byte staging slots 0..3 come from the hi plane, 4..7 from the lo plane --
+// only the per-lane source offset knows), so fragment read "ks = 0" is the hi and "ks = 1" the lo fragment of the SAME 32
+// channels, for activations and weights alike.  One K-step (32 channels of one tap) then forms all three products
+//      A_hi x W_lo,  A_hi x W_hi,  A_lo x W_hi            (A_lo x W_lo, 2^-22 of the result, is dropped)
+// = 96 MFMAs per wave on the bytes a plain K-step stages for 64: against walking the planes as three separate passes
+// (what the first version did: 14.7 k candidates/s) a third fewer barriers and LDS-DMA issues per MFMA.
+//   Phases (16 MFMAs each; af[0] = A_hi, af[1] = A_lo; bq[] double-buffers the four weight fragment groups):
+//     P1 A_hi x W_lo(half 0)   P2 A_hi x W_lo(half 1)   P3 A_hi x W_hi(0)   P4 A_lo x W_hi(0)   P5 A_hi x W_hi(1)
+//     -- wait, barrier, read-ahead of the next step's A_hi / W_lo(0) --   P6 A_lo x W_hi(1) + the LDS-DMA issue.
+//   The small cross terms are accumulated first.
+// =================================================================================================
+template <int ET>
+__global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int A_BUF = 40960, W_BUF = 32768, W_BASE = 2 * A_BUF;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r4 = lane & 15, h4 = lane >> 4;
+  const int wm = w >> 1, wn = w & 1;
+  const int ntn = (p.N + 255) >> 8;
+  const int ntm = (p.M + 255) >> 8;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int tm = tile / ntn, tn = tile - tm * ntn;
+  const int L = p.L, Lp = p.in_Lp, S = 256 / L;
+  const int a_rows = S * Lp;
+  const int nv = p.Cin >> 5;                                         // 32-channel chunks
+  const long long K = 3LL * p.Cin;
+  const unsigned a_plane = (unsigned)p.a_plane, w_plane = (unsigned)p.w_plane;
+
+  unsigned pa0, pa4, pbe, pbo;
+  const char* const a_base = (const char*)p.A + ((long long)tm * S * Lp + p.in_off) * p.lda * 2;
+  const char* const w_base = (const char*)p.W + ((long long)tn * 256) * K * 2;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
+  {
+    const int r = w * 8 + (lane >> 3);
+    const int slot = (lane & 7) ^ ((r >> 1) & 7);                    // LDS slot this lane fills; slots 4..7 = lo plane
+    const unsigned po = (slot & 4) ? a_plane : 0u;
+    pa0 = (unsigned)((r * p.lda + (slot & 3) * 8) * 2) + po;
+    const int r4r = r + 256;
+    const int rs = r4r < a_rows ? r4r : a_rows - 1;
+    pa4 = (unsigned)((rs * p.lda + (slot & 3) * 8) * 2) + po;
+  }
+  const int a_piece = 64 * p.lda * 2;
+  long long wq[4];
+  {
+    const int lr = lane >> 3;
+    const int slot0 = (lane & 7) ^ (lr >> 1);
+    const int slot1 = slot0 ^ 4;
+    pbe = (unsigned)(((long long)(8 * lr) * K + (slot0 & 3) * 8) * 2) + ((slot0 & 4) ? w_plane : 0u);
+    pbo = (unsigned)(((long long)(8 * lr) * K + (slot1 & 3) * 8) * 2) + ((slot1 & 4) ? w_plane : 0u);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r0 = (w * 4 + q) * 8;
+      const int cu = (r0 & 128) + 8 * (r0 & 8) + ((r0 >> 4) & 7);
+      wq[q] = (long long)cu * K * 2;
+    }
+  }
+  const int w_tap = p.Cin * 2;
+  auto issue_a = [&](int v, int i) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (LDS_AS void*)(smem + (v & 1) * A_BUF + (w + 8 * i) * 1024), 16,
+                                             i < 4 ? pa0 : pa4, v * 64 + (i < 4 ? i * a_piece : 0), 0, 0);
+  };
+  auto issue_w = [&](int v, int t, int q) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (LDS_AS void*)(smem + W_BASE + ((v + t) & 1) * W_BUF + (w * 4 + q) * 1024),
+                                             16, (q & 1) ? pbo : pbe, (int)wq[q] + v * 64 + t * w_tap, 0, 0);
+  };
+
+  int lrow0;
+  {
+    const int ml = wm * 64 + r4;
+    const int sb = ml / L;
+    lrow0 = sb * Lp + (ml - sb * L);
+  }
+  int lstep[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) lstep[mb] = 16 * mb + 2 * (((wm * 64 + 16 * mb) / L) - ((wm * 64) / L));
+  const int swl = (r4 >> 1) & 7;
+  const int b_row_off = (wn * 128 + r4) * 128;
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[mb][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  short8_t af[2][4], bq[2][4];
+  // pl: 0 = hi plane, 1 = lo plane (slots 0..3 / 4..7 of the row)
+  auto rdA = [&](int set, int v, int t, int pl) {
+    const char* ab = smem + (v & 1) * A_BUF;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int row = lrow0 + lstep[mb] + t;
+      const int ps = (((pl << 2) | h4) ^ ((row >> 1) & 7)) << 4;
+      af[set][mb] = *(const short8_t*)(ab + row * 128 + ps);
+    }
+  };
+  auto rdB = [&](int set, int v, int t, int pl, int half) {
+    const char* wb = smem + W_BASE + ((v + t) & 1) * W_BUF + b_row_off + half * 8192;
+    const int psb = (((pl << 2) | h4) ^ swl) << 4;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) bq[set][jj] = *(const short8_t*)(wb + jj * 2048 + psb);
+  };
+  auto mm = [&](int aset, int bset, int half, int mb, int jj) {
+    acc[mb][half * 4 + jj] = mfma16<ET>(af[aset][mb], bq[bset][jj], acc[mb][half * 4 + jj]);
+  };
+  auto mm16 = [&](int aset, int bset, int half) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) mm(aset, bset, half, mb, (mb & 1) ? 3 - jj : jj);
+  };
+
+  // One K-step (chunk v, tap T).  On entry af[0] = A_hi, bq[0] = W_lo(half 0) of this step.
+  auto step = [&](auto tT, auto tNext, auto tIW, auto tIA, auto tVM, int v) {
+    constexpr int T = decltype(tT)::value;
+    constexpr bool HAS_NEXT = decltype(tNext)::value, ISSUE_W = decltype(tIW)::value, ISSUE_A = decltype(tIA)::value;
+    constexpr int VM = decltype(tVM)::value;
+    asm volatile("" : "+v"(lrow0));
+    rdB(1, v, T, 1, 1);                 // P1: A_hi x W_lo(0); fetch W_lo(1)
+    mm16(0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    rdB(0, v, T, 0, 0);                 // P2: A_hi x W_lo(1); fetch W_hi(0) and A_lo
+    rdA(1, v, T, 1);
+    mm16(0, 1, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    rdB(1, v, T, 0, 1);                 // P3: A_hi x W_hi(0); fetch W_hi(1)
+    mm16(0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mm16(1, 0, 0);                      // P4: A_lo x W_hi(0)
+    __builtin_amdgcn_sched_barrier(0);
+    mm16(0, 1, 1);                      // P5: A_hi x W_hi(1)
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (HAS_NEXT) {
+      if constexpr (VM == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      constexpr int T1 = (T + 1) % 3;
+      rdA(0, v + (T + 1) / 3, T1, 0);               // next step's A_hi and W_lo(0)
+      rdB(0, v + (T + 1) / 3, T1, 1, 0);
+    }
+    constexpr int T2 = (T + 2) % 3;
+    const int v2 = v + (T + 2) / 3;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)      // P6: A_lo x W_hi(1) + the LDS-DMA issue of step s+2 / chunk v+2
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        mm(1, 1, 1, mb, (mb & 1) ? 3 - jj : jj);
+        const int i = mb * 4 + jj;
+        const int d = (i & 1) ? -1 : (i >> 1);
+        if constexpr (ISSUE_W) { if (d >= 0 && d < 4) issue_w(v2, T2, d); }
+        if constexpr (ISSUE_A) { if (d >= 4 && d < 8) issue_a(v + 2, d - 4); if (i == 15) issue_a(v + 2, 4); }
+      }
+    if constexpr (HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);
+    constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? 5 : 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+      if (!(i & 1) && (i >> 1) < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+      if (i == 15 && NV == 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I5 = std::integral_constant<int, 5>;
+  using Tt = std::true_type;
+  using Ff = std::false_type;
+
+#pragma unroll
+  for (int i = 0; i < 5; ++i) issue_a(0, i);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue_w(0, 0, q);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue_w(0, 1, q);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) issue_a(1, i);
+  rdA(0, 0, 0, 0);
+  rdB(0, 0, 0, 1, 0);
+
+  for (int v = 0; v < nv - 2; ++v) {
+    step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, v);
+    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, v);
+    step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, v);
+  }
+  {
+    const int v = nv - 2;               // tails wait for everything (no counted wait next to possible spill traffic)
+    step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, v);
+    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, v);
+    step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, v);
+  }
+  {
+    const int v = nv - 1;
+    step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, v);
+    step(I1{}, Tt{}, Ff{}, Ff{}, I0{}, v);
+    step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, v);
+  }
+  __syncthreads();
+  gemm_epilogue16<ET, true>(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
 }
 
 // =================================================================================================
@@ -1183,10 +1343,12 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
   const int ntn = p.N >> 8, ntm = p.M >> 8;
   const int tile = xcd_remap(blockIdx.x, ntm * ntn);
   const int tm = tile / ntn, tn = tile - tm * ntn;
-  const int nc = p.Cin >> 6, nk0 = p.taps * nc;
-  // SPLIT: K-step kv = 3 k + pass; pass 0: A hi x W hi, 1: A hi x W lo, 2: A lo x W hi
-  const int nk = SPLIT ? 3 * nk0 : nk0;
-  const int a_plane = (int)p.a_plane, w_plane = (int)p.w_plane;
+  // SPLIT (hi + lo planes): a K-step is 32 channels of one tap, an LDS row holds [32 ch hi | the same 32 ch lo] (slots
+  // 0..3 / 4..7, chosen by the per-lane source offset) and the step runs the three products A_hi W_lo, A_hi W_hi, A_lo W_hi
+  // = 96 MFMAs on it (conv3_halo16x3_kernel explains the scheme)
+  constexpr int KB = SPLIT ? 64 : 128;                               // bytes of K per plane and K-step
+  const int nc = SPLIT ? (p.Cin >> 5) : (p.Cin >> 6), nk = p.taps * nc;
+  const unsigned a_plane = (unsigned)p.a_plane, w_plane = (unsigned)p.w_plane;
   const long long K = (long long)p.taps * p.Cin;
 
   // buffer descriptors based at the TILE's first activation row / weight row: the 32-bit offsets below then only span the
@@ -1206,10 +1368,17 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
   {
     const int lr = lane >> 3;
     const int slot0 = (lane & 7) ^ (lr >> 1), slot1 = slot0 ^ 4;     // piece parity 0 / 1: (r >> 1) & 7 = (lr >> 1) (+ 4)
-    pae = (unsigned)((lr * p.in_stride * p.lda + slot0 * 8) * 2);
-    pao = (unsigned)((lr * p.in_stride * p.lda + slot1 * 8) * 2);
-    pbe = (unsigned)(((long long)(8 * lr) * K + slot0 * 8) * 2);
-    pbo = (unsigned)(((long long)(8 * lr) * K + slot1 * 8) * 2);
+    if constexpr (SPLIT) {
+      pae = (unsigned)((lr * p.in_stride * p.lda + (slot0 & 3) * 8) * 2) + ((slot0 & 4) ? a_plane : 0u);
+      pao = (unsigned)((lr * p.in_stride * p.lda + (slot1 & 3) * 8) * 2) + ((slot1 & 4) ? a_plane : 0u);
+      pbe = (unsigned)(((long long)(8 * lr) * K + (slot0 & 3) * 8) * 2) + ((slot0 & 4) ? w_plane : 0u);
+      pbo = (unsigned)(((long long)(8 * lr) * K + (slot1 & 3) * 8) * 2) + ((slot1 & 4) ? w_plane : 0u);
+    } else {
+      pae = (unsigned)((lr * p.in_stride * p.lda + slot0 * 8) * 2);
+      pao = (unsigned)((lr * p.in_stride * p.lda + slot1 * 8) * 2);
+      pbe = (unsigned)(((long long)(8 * lr) * K + slot0 * 8) * 2);
+      pbo = (unsigned)(((long long)(8 * lr) * K + slot1 * 8) * 2);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r0 = (w * 4 + q) * 8;                                // tile row of the piece's first lane row
@@ -1222,17 +1391,10 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
   }
   const int tap_bytes = p.lda * 2;                                   // one activation row further per tap
   // scalar source offsets of (virtual) K-step kv: activations / weights
-  auto src_off = [&](int kv, int& ao, int& wo) {
-    int k = kv, pa_ = 0, pw_ = 0;
-    if constexpr (SPLIT) {
-      k = kv / 3;
-      const int pass = kv - 3 * k;
-      pa_ = pass == 2 ? a_plane : 0;
-      pw_ = pass == 1 ? w_plane : 0;
-    }
+  auto src_off = [&](int k, int& ao, int& wo) {
     const int t = k / nc, c = k - t * nc;
-    ao = t * tap_bytes + c * 128 + pa_;
-    wo = k * 128 + pw_;
+    ao = t * tap_bytes + c * KB;
+    wo = k * KB;
   };
   auto issue = [&](int kv) {                                         // K-step kv -> buffers kv & 1
     int ao, wo;
@@ -1279,25 +1441,48 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) mm(aset, bset, half, mb, (mb & 1) ? 3 - jj : jj);
   };
-  // One K-step.  On entry af[0] = A(ks 0), bq[0] = B(ks 0, half 0) of step k.
+  // One K-step.  On entry af[0] = A(ks 0), bq[0] = B(ks 0, half 0) of step k  (SPLIT: af[0] = A_hi, bq[0] = W_lo(half 0)).
   auto step = [&](auto tNext, auto tIssue, int k) {
     constexpr bool HAS_NEXT = decltype(tNext)::value, ISSUE = decltype(tIssue)::value;
-    rdB(1, k, 0, 1);                    // phase (0,0)
-    mm16(0, 0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    rdA(1, k, 1);                       // phase (0,1)
-    rdB(0, k, 1, 0);
-    mm16(0, 1, 1);
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    rdB(1, k, 1, 1);                    // phase (1,0)
-    mm16(1, 0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SPLIT) {
+      rdB(1, k, 1, 1);                  // P1: A_hi x W_lo(0); fetch W_lo(1)
+      mm16(0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      rdB(0, k, 0, 0);                  // P2: A_hi x W_lo(1); fetch W_hi(0) and A_lo
+      rdA(1, k, 1);
+      mm16(0, 1, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      rdB(1, k, 0, 1);                  // P3: A_hi x W_hi(0); fetch W_hi(1)
+      mm16(0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm16(1, 0, 0);                    // P4: A_lo x W_hi(0)
+      __builtin_amdgcn_sched_barrier(0);
+      mm16(0, 1, 1);                    // P5: A_hi x W_hi(1)
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      rdB(1, k, 0, 1);                  // phase (0,0)
+      mm16(0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      rdA(1, k, 1);                     // phase (0,1)
+      rdB(0, k, 1, 0);
+      mm16(0, 1, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      rdB(1, k, 1, 1);                  // phase (1,0)
+      mm16(1, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     int ao2 = 0, wo2 = 0;
     if constexpr (ISSUE) src_off(k + 2, ao2, wo2);
     if constexpr (HAS_NEXT) {
@@ -1305,7 +1490,7 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       rdA(0, k + 1, 0);
-      rdB(0, k + 1, 0, 0);
+      rdB(0, k + 1, SPLIT ? 1 : 0, 0);
     }
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)      // phase (1,1) + the 8 LDS-DMA pieces of step k+2 into the buffers just released
@@ -1339,7 +1524,7 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
   __builtin_amdgcn_s_barrier();
   if (nk > 1) issue(1);
   rdA(0, 0, 0);
-  rdB(0, 0, 0, 0);
+  rdB(0, 0, SPLIT ? 1 : 0, 0);
   for (int k = 0; k < nk - 2; ++k) step(Tt{}, Tt{}, k);
   if (nk >= 2) step(Tt{}, Ff{}, nk - 2);
   step(Ff{}, Ff{}, nk - 1);
@@ -1376,14 +1561,10 @@ static void ensure_lds_attrs() {
   hipFuncSetAttribute((const void*)conv_gemm_kernel<0, true>, at, 131072);
   hipFuncSetAttribute((const void*)conv_gemm_kernel<1, true>, at, 131072);
   hipFuncSetAttribute((const void*)conv_gemm_kernel<2, true>, at, 131072);
-  hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, false, false>, at, 147456);
-  hipFuncSetAttribute((const void*)conv3_halo16_kernel<1, false, false>, at, 147456);
-  hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, true, false>, at, 147456);
-  hipFuncSetAttribute((const void*)conv3_halo16_kernel<1, true, false>, at, 147456);
-  hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, false, true>, at, 147456);
-  hipFuncSetAttribute((const void*)conv3_halo16_kernel<1, false, true>, at, 147456);
-  hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, true, true>, at, 147456);
-  hipFuncSetAttribute((const void*)conv3_halo16_kernel<1, true, true>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, false>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16_kernel<1, false>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<0>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<1>, at, 147456);
   hipFuncSetAttribute((const void*)gemm16_kernel<0, false>, at, 131072);
   hipFuncSetAttribute((const void*)gemm16_kernel<1, false>, at, 131072);
   hipFuncSetAttribute((const void*)gemm16_kernel<0, true>, at, 131072);
@@ -1397,25 +1578,12 @@ void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
   const int ntn = (p.N + 255) >> 8, ntm = (p.M + 255) >> 8;
   const dim3 grid(ntm * ntn), block(512);
   if (halo_eligible(p, fmt)) {
-    // DITREE_HALO_STAGGER=0/1: A/B switch of the late-wave DMA issue (both variants compute the same values)
-    static int stagger = -1;
-    if (stagger < 0) { const char* e = getenv("DITREE_HALO_STAGGER"); stagger = (e && atoi(e)) ? 1 : 0; }
-    if (stagger) {
-      if (split) {
-        if (f16) hipLaunchKernelGGL((conv3_halo16_kernel<1, true, true>), grid, block, 147456, s, p);
-        else hipLaunchKernelGGL((conv3_halo16_kernel<0, true, true>), grid, block, 147456, s, p);
-      } else {
-        if (f16) hipLaunchKernelGGL((conv3_halo16_kernel<1, false, true>), grid, block, 147456, s, p);
-        else hipLaunchKernelGGL((conv3_halo16_kernel<0, false, true>), grid, block, 147456, s, p);
-      }
-      return;
-    }
     if (split) {
-      if (f16) hipLaunchKernelGGL((conv3_halo16_kernel<1, true, false>), grid, block, 147456, s, p);
-      else hipLaunchKernelGGL((conv3_halo16_kernel<0, true, false>), grid, block, 147456, s, p);
+      if (f16) hipLaunchKernelGGL(conv3_halo16x3_kernel<1>, grid, block, 147456, s, p);
+      else hipLaunchKernelGGL(conv3_halo16x3_kernel<0>, grid, block, 147456, s, p);
     } else {
-      if (f16) hipLaunchKernelGGL((conv3_halo16_kernel<1, false, false>), grid, block, 147456, s, p);
-      else hipLaunchKernelGGL((conv3_halo16_kernel<0, false, false>), grid, block, 147456, s, p);
+      if (f16) hipLaunchKernelGGL((conv3_halo16_kernel<1, false>), grid, block, 147456, s, p);
+      else hipLaunchKernelGGL((conv3_halo16_kernel<0, false>), grid, block, 147456, s, p);
     }
     return;
   }

@@ -297,18 +297,19 @@ __device__ __forceinline__ void car_euler_step(double* s, double a0r, double a1r
 
 // ------------------------------------------------------------------------- rollout
 // planners/base_planner.py:257-320 + car_env.py:240-282,341-396 + common/map_utils.py:103-115 for a batch of candidates.
-// One lane per candidate (the A Euler steps with their goal + two-ball collision tests are a sequential FP64 chain of
-// ~1 200 instructions per step: 3 sin/cos pairs, tanh, 9 sqrt / hypot), 64-thread work-groups so that 1 024 candidates
-// already occupy 16 CUs and 65 536 all of them.  The actions of the next RO_S steps are requested (16-B loads into
-// registers) before the current RO_S steps are integrated, so the chain never waits for a load; states are stored per
-// lane as they are produced (stores do not stall the chain).
-//   Measured alternatives (MI355X, 65 536 x 16, profiles/r02_rollout_*): 256-thread groups without prefetch 68 us (38 % of
-//   the wave time in s_waitcnt); wave-cooperative LDS-staged loads and (A + 1, 6)-row stores (every candidate's rows
-//   leave as one contiguous run) 100 us -- with one wave per SIMD each of its 12 barriers exposes a full memory latency and
-//   the index arithmetic of the wave-wide copies adds a third to the instruction count.  The kernel is bound by the FP64
-//   chain, not by HBM (1.0 TB/s of algorithmic bytes = 13 % of peak): see DESIGN.md.
-#define RO_S 4
-__global__ void __launch_bounds__(64)
+// One lane per candidate: the A Euler steps with their goal + two-ball collision tests are a sequential FP64 chain of
+// ~1 200 instructions per step (3 sin / cos pairs, tanh, 9 sqrt / hypot).  Work-group size by batch (launcher): one wave
+// per group spreads a small batch over many CUs (the round's 1 024 candidates: 16 CUs instead of 4), 256 threads once every
+// SIMD has a wave anyway.
+//   The kernel is bound by that FP64 chain with one wave per SIMD, not by HBM: 65 536 x 16 steps take 68 us = 1.0 TB/s of
+//   algorithmic bytes (13 % of peak); rocprofv3 counters (profiles/r02_rollout_*): 57 % of the wave cycles issue
+//   instructions, 38 % wait on memory, 227 MB cross the fabric for 71 MB of algorithmic bytes (the per-lane 16..48-byte
+//   fragments at strides of hundreds of bytes touch a line each).  Two rewrites aimed at that traffic were measured and
+//   dropped: wave-cooperative LDS-staged action loads + (A + 1, 6)-row stores (every candidate's rows leave as one
+//   contiguous run; 100 us: each of its 12 barriers exposes a full memory latency to the only wave of the SIMD and the
+//   index arithmetic of the wave-wide copies adds a third to the instruction count) and register prefetch of the next four
+//   steps' actions (74 us).  What would help is a second wave per SIMD (two lanes per candidate, one ball each) -- DESIGN.md.
+__global__ void __launch_bounds__(256)
 car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, double* __restrict__ state_io,
                    const double* __restrict__ actions, int64_t act_stride, int32_t* __restrict__ status_io, int B,
                    int A, double gx, double gy, double* __restrict__ states_out, int64_t states_stride,
@@ -337,53 +338,32 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
   int steps = 0;
   double la0 = 0.0, la1 = 0.0;
   int i = 0;
-  const bool al16 = ((((uintptr_t)act) & 15) == 0);
-  double2 cur[RO_S], nxt[RO_S];
-  auto fetch = [&](double2 (&dst)[RO_S], int s0) {
+  for (; i < A; ++i) {
+    const double a0r = act[2 * i], a1r = act[2 * i + 1];
+    car_euler_step(s, a0r, a1r);
+    steps = i + 1;
+    if (so) {
 #pragma unroll
-    for (int j = 0; j < RO_S; ++j) {
-      const int t = s0 + j;
-      if (t < A) {
-        if (al16) dst[j] = *(const double2*)(act + 2 * t);
-        else dst[j] = double2{act[2 * t], act[2 * t + 1]};
-      } else {
-        dst[j] = double2{0.0, 0.0};
-      }
+      for (int k = 0; k < 6; ++k) so[(size_t)(i + 1) * 6 + k] = s[k];
     }
-  };
-  fetch(cur, 0);
-  bool ended = false;
-  for (int s0 = 0; s0 < A && !ended; s0 += RO_S) {
-    fetch(nxt, s0 + RO_S);                           // in flight while this chunk integrates
-#pragma unroll
-    for (int j = 0; j < RO_S; ++j) {
-      if (ended || s0 + j >= A) break;
-      i = s0 + j;
-      const double a0r = cur[j].x, a1r = cur[j].y;
-      car_euler_step(s, a0r, a1r);
-      steps = i + 1;
-      if (so) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) so[(size_t)(i + 1) * 6 + k] = s[k];
-      }
-      if (ao) { ao[2 * i] = a0r; ao[2 * i + 1] = a1r; }
-      la0 = a0r; la1 = a1r;
-      double ex = s[0] - gx, ey = s[1] - gy;
-      bool done = sqrt(fma(ey, ey, ex * ex)) < 0.5;   // np.linalg.norm (ddot rounds as one fma), car_env.py:346-351
-      bool coll = car_collides(s[0], s[1], s[2], lds, rows, cols);                 // base_planner.py:306
-      if (coll) {
-        status = DITREE_ST_COLLIDED | (done ? DITREE_ST_FLAG_GOAL_AT_COLLISION : 0);
-        ended = true;
-      } else if (done) {                                                          // :314-317
-        status = DITREE_ST_GOAL;
-        ended = true;
-      }
+    if (ao) { ao[2 * i] = a0r; ao[2 * i + 1] = a1r; }
+    la0 = a0r; la1 = a1r;
+    double ex = s[0] - gx, ey = s[1] - gy;
+    bool done = sqrt(fma(ey, ey, ex * ex)) < 0.5;   // np.linalg.norm (ddot rounds as one fma), car_env.py:346-351
+    bool coll = car_collides(s[0], s[1], s[2], lds, rows, cols);                 // base_planner.py:306
+    if (coll) {
+      status = DITREE_ST_COLLIDED | (done ? DITREE_ST_FLAG_GOAL_AT_COLLISION : 0);
+      ++i;
+      break;
     }
-#pragma unroll
-    for (int j = 0; j < RO_S; ++j) cur[j] = nxt[j];
+    if (done) {                                                                   // :314-317
+      status = DITREE_ST_GOAL;
+      ++i;
+      break;
+    }
   }
   // rows after the last executed step stay zero (states :282; actions zeroed :315)
-  for (int r = steps; r < A; ++r) {
+  for (int r = i; r < A; ++r) {
     if (so) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) so[(size_t)(r + 1) * 6 + k] = 0.0;
@@ -414,7 +394,10 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
                            uint8_t* has_prev_io, const int32_t* idx, int act_dense, hipStream_t s, const int32_t* budget,
                            int chunk_j) {
   size_t lds = ((size_t)rows * cols + 15) & ~(size_t)15;
-  hipLaunchKernelGGL(car_rollout_kernel, dim3((B + 63) / 64), dim3(64), lds, s, maze, rows, cols, state_io,
+  // work-group size: one wave per group spreads a small batch over many CUs (1 024 candidates: 16 CUs instead of 4); once
+  // every SIMD has a wave anyway, four waves per group share one staged maze
+  const int blk = B >= 16384 ? 256 : 64;
+  hipLaunchKernelGGL(car_rollout_kernel, dim3((B + blk - 1) / blk), dim3(blk), lds, s, maze, rows, cols, state_io,
                      actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out,
                      actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense,
                      budget, chunk_j);

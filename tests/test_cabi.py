@@ -52,7 +52,8 @@ def test_halo_kernel_loop_has_no_scratch_traffic(tmp_path):
     # every instantiation: <element type 0 bf16 / 1 f16, split 0 / 1>; the split ones spill in their (exact-Mish) epilogue,
     # which is fine -- but never inside the counted-wait loop
     for et, split, mfma in ((0, 0, "bf16"), (1, 0, "f16"), (0, 1, "bf16"), (1, 1, "f16")):
-        start = text.index(f"_Z19conv3_halo16_kernelILi{et}ELb{split}ELb0EEv14ConvGemmParams:")
+        name = f"_Z21conv3_halo16x3_kernelILi{et}EEv14ConvGemmParams:" if split else f"_Z19conv3_halo16_kernelILi{et}ELb0EEv14ConvGemmParams:"
+        start = text.index(name)
         body = text[start:text.index(".Lfunc_end", start)].splitlines()
         headers = [n for n, l in enumerate(body) if "Loop Header" in l]
         assert len(headers) == 1, "expected exactly one loop (the chunk loop) in the halo kernel"
@@ -60,7 +61,7 @@ def test_halo_kernel_loop_has_no_scratch_traffic(tmp_path):
         back = [n for n, l in enumerate(body) if re.search(r"s_cbranch\w+\s+" + re.escape(label) + r"\b", l)]
         assert back, "no backward branch to the chunk loop"
         loop = body[headers[0]:back[-1] + 1]
-        assert sum(f"v_mfma_f32_16x16x32_{mfma}" in l for l in loop) == 192          # 3 K-steps x 64 MFMAs
+        assert sum(f"v_mfma_f32_16x16x32_{mfma}" in l for l in loop) == (288 if split else 192)   # 3 K-steps x 64 (96: hi/lo) MFMAs
         assert any("vmcnt(5)" in l for l in loop)
         offenders = [l.strip() for l in loop if "scratch_" in l or re.search(r"\b(global|flat)_(load|store)", l)]
         assert not offenders, (et, split, offenders)

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import geometry as G
+from oracle import rrt as ORRT
 from oracle.tapes import ActionTape
 from tests.util import load_maze
 
