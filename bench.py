@@ -16,6 +16,7 @@ Other workloads of BASELINE.json's config list (each prints its own one-line JSO
     --workload rollout       config 5: 65 536 car rollouts x T = 16 steps, the rollout kernel alone (no denoiser)
     --workload lidar-round   config 4: a round of 8 192 candidates + one 181-ray lidar scan per candidate end pose
     --workload ant-denoise   config 3: the ant-sized denoiser + glue, 4 096 candidates x 24 calls (dynamics blocked on an oracle)
+    --workload geometry      the geometry kernels alone (NN, local map, cond vector, rollout chunk, lidar) with GB/s each
 """
 import argparse
 import json
@@ -230,6 +231,89 @@ def run_rollout(args):
         dist.destroy_process_group()
 
 
+def run_geometry(args):
+    """The geometry kernels of the path measured alone (HBM-bound nominally): nearest node, local map,
+    conditioning vector, lidar scan, rollout chunk (A = 8), accept -- at the config-4 round size (8192 candidates, 65 536-node
+    tree for the NN scan).  One JSON line; `roofline` is the rollout chunk's (the largest of them inside a round),
+    `kernels` lists every kernel's algorithmic bytes, time and GB/s."""
+    rank, world, local, dist, rehearse = _dist_setup(args)
+    from ditreeonlineplanner_amd.ops import Context
+    B = args.batch if args.batch_set else 8192
+    N = 65536
+    maze = load_maze("boxes")
+    ctx = Context(local)
+    dev = ctx.device
+    ctx.upload_maze(maze)
+    rng = np.random.default_rng(20260104 + rank)
+    Hh, W = maze.shape
+    free = np.argwhere(maze[1:-1, 1:-1] == 0) + 1
+
+    def poses(n):
+        cell = free[rng.integers(0, len(free), n)]
+        x = (cell[:, 1] + 0.5) - W / 2 + rng.uniform(-0.25, 0.25, n)
+        y = Hh / 2 - (cell[:, 0] + 0.5) + rng.uniform(-0.25, 0.25, n)
+        return np.stack([x, y, rng.uniform(-np.pi, np.pi, n), rng.uniform(0, 4, n), rng.uniform(0, 1, n),
+                         rng.uniform(-0.4, 0.4, n)], axis=1)
+    nodes = torch.as_tensor(poses(N), device=dev)
+    node_xy = nodes[:, :2].contiguous()
+    node_la = torch.zeros(N, 2, dtype=torch.float64, device=dev)
+    node_hp = torch.ones(N, dtype=torch.uint8, device=dev)
+    st = torch.as_tensor(poses(B), device=dev)
+    q = torch.as_tensor(np.stack([rng.uniform(-W / 2, W / 2, B), rng.uniform(-Hh / 2, Hh / 2, B)], axis=1), device=dev)
+    prev = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+    hasp = torch.ones(B, dtype=torch.uint8, device=dev)
+    goal = torch.as_tensor(np.tile(np.array([7.5, 7.5]), (B, 1)), device=dev)
+    acts = torch.as_tensor(np.stack([rng.normal(0.45, 1.0, (B, 8)), rng.normal(0.0, 0.92, (B, 8))], axis=2).copy(), device=dev)
+    cell_pose = torch.stack([st[:, 0] + W / 2, Hh / 2 - st[:, 1], st[:, 2]], dim=1).contiguous()
+    true_maze = torch.as_tensor(maze.astype(np.float32), device=dev)
+    lm = torch.empty(B, 20, 20, dtype=torch.float32, device=dev)
+    state = st.clone()
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    keep = {}
+
+    def k_rollout():
+        state.copy_(st)
+        status.zero_()
+        keep["r"] = ctx.car_rollout(state, acts, np.array([7.5, 7.5]), A=8, status=status, out=keep.get("r"))
+    kernels = {
+        "nn_argmin_kernel": (lambda: ctx.nn_argmin(q, node_xy, gather=(nodes, node_la, node_hp)), N * 16 + B * (16 + 4 + 72)),
+        "local_map_kernel": (lambda: ctx.local_map(st, n=20, scale=0.2, s_global=1.0, scaled=True, out=lm), B * (24 + 400 * 4)),
+        "cond_vector_kernel": (lambda: ctx.cond_vector(st, prev, hasp, goal), B * 109),
+        "car_rollout_kernel (A = 8)": (k_rollout, B * (56 + 64 * 8)),
+        "lidar_scan_kernel": (lambda: ctx.lidar_scan(cell_pose, true_maze, want_visited=True), B * (24 + 181 * 25 + maze.size) + maze.size * 4),
+    }
+    res_k = {}
+    for name, (fn, alg) in kernels.items():
+        for _ in range(args.warmup):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.steps
+        res_k[name] = {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg, "achieved_GBps": alg / (ms * 1e-3) / 1e9,
+                       "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    if rank == 0:
+        total_ms = sum(v["avg_launch_ms"] for v in res_k.values())
+        ro = res_k["car_rollout_kernel (A = 8)"]
+        res = {"metric": "geometry kernels of one chunk at the config-4 round size (NN + local map + cond + 8-step rollout + lidar)",
+               "value": B / (total_ms * 1e-3), "unit": "candidates/s through the geometry kernels alone", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": total_ms, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"geometry kernels alone: {B} candidates, {N}-node tree, boxes.csv; includes per-call tensor "
+                                      "allocation of the Python front end (event-timed around the front-end call)"},
+               "roofline": {"bound": "hbm", "achieved": ro["achieved_GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": ro["frac_of_hbm_peak"], "traffic": None, "kernel": "car_rollout_kernel (A = 8)",
+                            "avg_launch_ms": ro["avg_launch_ms"], "algorithmic_bytes_per_launch": ro["algorithmic_bytes_per_launch"]},
+               "kernels": res_k}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def run_lidar_round(args):
     """BASELINE config 4: the car round with the lidar in the loop -- a round of B candidates (B = 8192 global; NN ->
     4 x [map, cond, denoiser, 8 steps] -> accept) followed by one 181-ray `Lidar2DSim.scan` per candidate end pose on
@@ -399,7 +483,7 @@ def dataclass_replace(args, **kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="expand", choices=["expand", "rollout", "lidar-round", "ant-denoise"])
+    ap.add_argument("--workload", default="expand", choices=["expand", "rollout", "lidar-round", "ant-denoise", "geometry"])
     ap.add_argument("--global-batch", type=int, default=0,
                     help="fixed GLOBAL round size split over the GPUs (strong scaling); default: --batch per GPU (weak)")
     ap.add_argument("--horizon", type=int, default=0, help="rollout workload: steps per rollout (default 16)")
@@ -425,6 +509,8 @@ def main():
         return run_lidar_round(args)
     if args.workload == "ant-denoise":
         return run_ant_denoise(args)
+    if args.workload == "geometry":
+        return run_geometry(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

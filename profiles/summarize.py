@@ -70,15 +70,16 @@ def main(root, tag):
     for n in list(out["kernels"])[:6]:
         print(n, {k: round(v / 1e6, 2) if "bytes" in k else v for k, v in out["kernels"][n].items()})
     # SQ pass: per kernel and launch, every counter the pass collected
-    sqdir = os.path.join(root, "pmc_sq")
-    if os.path.isdir(sqdir) and (glob.glob(os.path.join(sqdir, "*.db")) or glob.glob(os.path.join(sqdir, "*counter_collection.csv"))):
+    rows = []
+    for sub in ("pmc_sq", "pmc_sq2"):
+        sqdir = os.path.join(root, sub)
         f = glob.glob(os.path.join(sqdir, "*counter_collection.csv"))
-        rows = []
         if f:
-            rows = [(r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])) for r in csv.DictReader(open(f[0]))]
-        else:
+            rows += [(r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])) for r in csv.DictReader(open(f[0]))]
+        elif glob.glob(os.path.join(sqdir, "*.db")):
             c = sqlite3.connect(glob.glob(os.path.join(sqdir, "*.db"))[0])
-            rows = list(c.execute("select kernel_name, counter_name, value from counters_collection"))
+            rows += list(c.execute("select kernel_name, counter_name, value from counters_collection"))
+    if rows:
         per = collections.defaultdict(lambda: collections.defaultdict(list))
         for n, cn, v in rows:
             per[short(n)][cn].append(v)
