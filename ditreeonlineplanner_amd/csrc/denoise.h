@@ -65,7 +65,7 @@ bool conv_gemm_supported(const ConvGemmParams& p, int fmt);   // split formats: 
 void launch_prep_sample(const float* x, void* A0, int B, int P, int D, int fmt, long long plane, hipStream_t s);
 void launch_time_embed(float t, const float* W1, const float* b1, const float* W2, const float* b2, float* out,
                        hipStream_t s);
-void launch_prep_cond(const float* temb, const float* map_emb, int E, const float* cond, int G, void* out, int B,
+void launch_prep_cond(const float* temb, const float* map_emb, int E, int E_ld, const float* cond, int G, void* out, int B,
                       int Kpad, int fmt, long long plane, hipStream_t s);
 void launch_final_proj_flow(const void* Y, int C, int Lp, long long plane, const float* W, const float* bias, int D, float* x,
                             float dt, const double* act_norm /*[mu[D], sigma[D]]*/, double* actions, int B, int P, int fmt,
@@ -78,12 +78,14 @@ void launch_gn1d(void* x, int ld, int Lp, int row_off, int coff, int L, int C, c
                  int mode, const float* film, int film_ld, int film_off, const void* res, int ldres, int res_Lp, int res_off,
                  int B, int fmt, long long x_plane, long long res_plane, hipStream_t s);
 void launch_encoder_stem(const float* lm, const float* W /*[49][64] f32 (tap-major), input channels folded*/, const float* gamma,
-                         const float* beta, void* out /*[B][25][64]*/, int B, float eps, int fmt, hipStream_t s);
+                         const float* beta, void* out /*[B][25][64]*/, int B, float eps, int fmt, long long plane, hipStream_t s);
 void launch_im2col2d(const void* in, bool src_f32, void* out, int B, int H, int W, int C, const TapList& taps, int stride,
                      int pad, int OH, int OW, int Kpad, int fmt, hipStream_t s);
 void launch_gn2d(const float* in, int nslab, long long slab_stride, const float* gamma, const float* beta, const void* res,
-                 int relu, void* out, int B, int HW, int C, float eps, int fmt, hipStream_t s);
+                 int relu, void* out, int B, int HW, int C, float eps, int fmt, long long res_plane, long long out_plane,
+                 hipStream_t s);
 void launch_maxpool2d(const void* in, void* out, int B, int H, int W, int C, int OH, int OW, int fmt, hipStream_t s);
-void launch_avgpool2d(const void* in, void* out, int B, int HW, int C, int fmt, hipStream_t s);
+void launch_avgpool2d(const void* in, void* out, int B, int HW, int C, int fmt, long long in_plane, long long out_plane,
+                      hipStream_t s);
 void launch_unpack_act(const void* in, int ld, int coff, int Lp, int roff, float* out, int B, int L, int C, int fmt,
                        long long plane, hipStream_t s);

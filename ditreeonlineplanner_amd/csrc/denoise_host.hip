@@ -84,7 +84,8 @@ struct DenoiserState {
   float* x_cur = nullptr;        // (Bmax, P, D) f32
   float* temb = nullptr;         // (256,) f32
   float temb_t = -1.0f;          // timestep the cached embedding was computed for (< 0: none)
-  float* map_emb = nullptr;      // (Bmax, E) f32
+  float* map_emb = nullptr;      // (Bmax, E_ld) f32
+  int E_ld = 400;                // row stride of map_emb (E, or E padded to 256 for the split encoder's fc tiles)
   float* film = nullptr;         // (Bp, film_cols) f32
   void* condA = nullptr;         // (Brows, condK) [x planes]
   long long cond_plane = 0;
@@ -441,12 +442,13 @@ struct DenoiserState {
 void DenoiserState::build(int prec_, int Bmax_) {
   free_workspace();
   prec = prec_;
-  // DITREE_PREC_*  ->  formats.  The split (f32-class) instantiations keep the small encoder (1 % of the FLOPs) in f32.
+  // DITREE_PREC_*  ->  formats of the U-Net and of the encoder.  The split instantiations run the encoder split as well
+  // when its stem is the fused 20 x 20 kernel (car); the layered stem (other map sizes) has no hi / lo form: f32 there.
   switch (prec) {
     case DITREE_PREC_BF16: ufmt = fmt_make(ST_BF16, false); efmt = ST_BF16; break;
     case DITREE_PREC_F32: ufmt = fmt_make(ST_F32, false); efmt = ST_F32; break;
-    case DITREE_PREC_F16X3: ufmt = fmt_make(ST_F16, true); efmt = ST_F32; break;
-    case DITREE_PREC_BF16X3: ufmt = fmt_make(ST_BF16, true); efmt = ST_F32; break;
+    case DITREE_PREC_F16X3: ufmt = fmt_make(ST_F16, true); efmt = lm == 20 ? ufmt : (int)ST_F32; break;
+    case DITREE_PREC_BF16X3: ufmt = fmt_make(ST_BF16, true); efmt = lm == 20 ? ufmt : (int)ST_F32; break;
     case DITREE_PREC_F16: ufmt = fmt_make(ST_F16, false); efmt = ST_F16; break;
     default: throw std::runtime_error("unknown precision");
   }
@@ -459,10 +461,12 @@ void DenoiserState::build(int prec_, int Bmax_) {
     throw std::runtime_error("the split precisions need down_dims that are multiples of 256 (halo / gemm16 tiles)");
   x_cur = (float*)dalloc((size_t)Bmax * P * D * 4);
   temb = (float*)dalloc(256 * 4);
-  map_emb = (float*)dalloc((size_t)Bmax * E * 4);
   condK = (cond_dim + 63) / 64 * 64;
   // the FiLM GEMM runs on whole 256-row tiles: rows padded (zero rows in, ignored rows out)
   const int Brows = (Bmax + 255) / 256 * 256;
+  // split encoder: its fc layer runs on the gemm16 tiles too (rows and columns padded to 256)
+  E_ld = fmt_split(efmt) ? (E + 255) / 256 * 256 : E;
+  map_emb = (float*)dalloc((size_t)Brows * E_ld * 4);
   cond_plane = planes() == 2 ? (long long)Brows * condK * es() : 0;
   condA = dalloc((size_t)Brows * condK * es() * planes());
 
@@ -623,7 +627,10 @@ void DenoiserState::build(int prec_, int Bmax_) {
     auto ebuf = [&](const std::string& name, int HW, int C) {
       Act a;
       a.L = HW; a.C = C; a.ld = C; a.coff = 0; a.padded = false; a.fmt = efmt;
-      a.p = dalloc((size_t)Bmax * HW * C * ees());
+      const size_t rows = HW == 1 ? (size_t)Brows : (size_t)Bmax;   // the pooled vector feeds a GEMM on whole 256-row tiles
+      const size_t bytes = rows * HW * C * ees();
+      a.plane = fmt_split(efmt) ? (long long)bytes : 0;
+      a.p = dalloc(bytes * (fmt_split(efmt) ? 2 : 1));
       named[name] = a;
       return a;
     };
@@ -643,8 +650,8 @@ void DenoiserState::build(int prec_, int Bmax_) {
     };
     // conv (+ optional folding of the 3 identical input channels) -> f32 GEMM output in the region's `gout`.
     // in == nullptr: the source is the caller's f32 local map (lm_ptr), C = 1.
-    auto conv2d = [&](const std::string& wname, const void* in, int H, int Cin, int Cout, int k, int stride, int pad,
-                      int OH, bool fold_in) {
+    auto conv2d = [&](const std::string& wname, const void* in, long long in_plane, int H, int Cin, int Cout, int k, int stride,
+                      int pad, int OH, bool fold_in) {
       const HostParam& w = P_(wname + ".weight");
       const float* wd = w.data;
       const int Cw = (int)w.dims[1];
@@ -662,6 +669,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
       });
       const float** lm_slot = &lm_ptr;
       const bool implicit = (in != nullptr) && (Cin % 64 == 0) && tl.n <= 12;
+      if (!implicit && fmt_split(efmt)) throw std::runtime_error("split encoder: " + wname + " needs the im2col path");
       const void* zr = zero_row;
       enc_ops.push_back([=, this](int b0, int Bn, int reg, hipStream_t s) {
         char* colr = col + (size_t)reg * colreg * E_;
@@ -670,7 +678,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
         const int M = Bn * OH * OH;
         if (implicit) {
           // implicit GEMM: the kernel gathers the (tap, channel-chunk) rows itself, no im2col pass
-          p.A = (const char*)in + (size_t)b0 * H * H * Cin * E_; p.lda = Cin; p.taps = tl.n; p.Cin = Cin;
+          p.A = (const char*)in + (size_t)b0 * H * H * Cin * E_; p.lda = Cin; p.taps = tl.n; p.Cin = Cin; p.a_plane = in_plane;
           p.c2d = 1; p.c2_H = H; p.c2_W = H; p.c2_OW = OH; p.c2_OHW = OH * OH; p.c2_stride = stride; p.c2_pad = pad;
           for (int t = 0; t < tl.n; ++t) { p.c2_kh[t] = tl.kh[t]; p.c2_kw[t] = tl.kw[t]; }
           p.zero = zr;
@@ -738,6 +746,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
       const char* rp = res ? (const char*)res->p : nullptr;
       char* op = (char*)out.p;
       const int HW = out.L, C = out.C;
+      const long long rpl = res ? res->plane : 0, opl = out.plane;
       {                                                  // shape contract of gn2d_kernel, checked when the plan is built
         const int pp = (C >= 64 && C <= 1024 && (C & (C - 1)) == 0) ? 256 / (C >> 2) : 0;
         if (pp == 0 || (HW + pp - 1) / pp > 7)
@@ -747,7 +756,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
         note_other();
         const size_t off = (size_t)b0 * HW * C * E_;
         launch_gn2d(gout + (size_t)reg * goutreg, last_splitk[reg], last_slab[reg], ga, be, rp ? rp + off : nullptr,
-                    relu ? 1 : 0, op + off, Bn, HW, C, 1e-5f, pr, s);
+                    relu ? 1 : 0, op + off, Bn, HW, C, 1e-5f, pr, rpl, opl, s);
       });
     };
     const int H0 = lm;
@@ -756,9 +765,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
     const int H2 = osz(H1, 3, 2, 1);                  // 5
     Act c1 = ebuf("enc.c1", H1 * H1, 64);
     Act pool = ebuf("enc.pool", H2 * H2, 64);
-    static int fused_stem = -1;                     // DITREE_FUSED_STEM=0: the layered im2col / GEMM / GroupNorm / pool path
-    if (fused_stem < 0) { const char* e = getenv("DITREE_FUSED_STEM"); fused_stem = (e && !atoi(e)) ? 0 : 1; }
-    if (fused_stem && H0 == 20) {
+    if (H0 == 20) {
       // one launch: conv 7x7/2 (input channels folded) + GroupNorm + ReLU + max-pool
       const HostParam& w = P_(R + "conv1.weight");
       const int Cw = (int)w.dims[1];
@@ -774,12 +781,13 @@ void DenoiserState::build(int prec_, int Bmax_) {
       float* be = vec(R + "bn1.bias");
       char* op = (char*)pool.p;
       const float** lm_slot = &lm_ptr;
+      const long long ppl = pool.plane;
       enc_ops.push_back([=, this](int b0, int Bn, int, hipStream_t s) {
         note_other();
-        launch_encoder_stem(*lm_slot + (size_t)b0 * 400, wdev, ga, be, op + (size_t)b0 * 25 * 64 * E_, Bn, 1e-5f, pr, s);
+        launch_encoder_stem(*lm_slot + (size_t)b0 * 400, wdev, ga, be, op + (size_t)b0 * 25 * 64 * E_, Bn, 1e-5f, pr, ppl, s);
       });
     } else {
-    conv2d(R + "conv1", nullptr, H0, 1, 64, 7, 2, 3, H1, true);
+    conv2d(R + "conv1", nullptr, 0, H0, 1, 64, 7, 2, 3, H1, true);
     gn(R + "bn1", c1, nullptr, true);
     {
       const char* ip = (const char*)c1.p; char* op = (char*)pool.p;
@@ -801,17 +809,17 @@ void DenoiserState::build(int prec_, int Bmax_) {
         const int Ho = osz(Hc, 3, stride, 1);
         const std::string tag = "enc.l" + std::to_string(li + 1) + "." + std::to_string(bi);
         Act t1 = ebuf(tag + ".t", Ho * Ho, Cout);
-        conv2d(pre + ".conv1", cur.p, Hc, Cc, Cout, 3, stride, 1, Ho, false);
+        conv2d(pre + ".conv1", cur.p, cur.plane, Hc, Cc, Cout, 3, stride, 1, Ho, false);
         gn(pre + ".bn1", t1, nullptr, true);
         Act idt = cur;
         if (has(pre + ".downsample.0.weight")) {
           Act ds = ebuf(tag + ".ds", Ho * Ho, Cout);
-          conv2d(pre + ".downsample.0", cur.p, Hc, Cc, Cout, 1, stride, 0, Ho, false);
+          conv2d(pre + ".downsample.0", cur.p, cur.plane, Hc, Cc, Cout, 1, stride, 0, Ho, false);
           gn(pre + ".downsample.1", ds, nullptr, false);
           idt = ds;
         }
         Act o = ebuf(tag + ".out", Ho * Ho, Cout);
-        conv2d(pre + ".conv2", t1.p, Ho, Cout, Cout, 3, 1, 1, Ho, false);
+        conv2d(pre + ".conv2", t1.p, t1.plane, Ho, Cout, Cout, 3, 1, 1, Ho, false);
         gn(pre + ".bn2", o, &idt, true);
         cur = o;
         Hc = Ho;
@@ -822,9 +830,10 @@ void DenoiserState::build(int prec_, int Bmax_) {
     {
       const char* ip = (const char*)cur.p; char* op = (char*)pooled.p;
       const int HW = Hc * Hc, C = Cc;
+      const long long ipl = cur.plane, opl = pooled.plane;
       enc_ops.push_back([=, this](int b0, int Bn, int, hipStream_t s) {
         note_other();
-        launch_avgpool2d(ip + (size_t)b0 * HW * C * E_, op + (size_t)b0 * C * E_, Bn, HW, C, pr, s);
+        launch_avgpool2d(ip + (size_t)b0 * HW * C * E_, op + (size_t)b0 * C * E_, Bn, HW, C, pr, ipl, opl, s);
       });
     }
     {
@@ -832,15 +841,26 @@ void DenoiserState::build(int prec_, int Bmax_) {
       const float* wd = w.data;
       const int Kf = (int)w.dims[1], Nf = (int)w.dims[0];
       const Packed wp = pack(R + "fc", efmt, Nf, 1, Kf, [=](int n, int, int ci) { return wd[(size_t)n * Kf + ci]; });
-      float* bd = vec(R + "fc.bias");
+      const bool esplit = fmt_split(efmt);
+      const int eld = E_ld;
+      float* bd;
+      if (esplit) {                                        // gemm16 tiles: columns padded to E_ld (zero weights, zero bias)
+        std::vector<float> bpad(eld, 0.0f);
+        std::memcpy(bpad.data(), P_(R + "fc.bias").data, (size_t)Nf * 4);
+        bd = upload_f32(R + "fc.bias#padded", bpad.data(), eld);
+      } else {
+        bd = vec(R + "fc.bias");
+      }
       const char* ip = (const char*)pooled.p;
       float* op = map_emb;
+      const long long ppl = pooled.plane;
       enc_ops.push_back([=, this](int b0, int Bn, int, hipStream_t s) {
         ConvGemmParams p{};
-        p.A = ip + (size_t)b0 * Kf * E_; p.lda = Kf; p.in_Lp = Bn; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = Kf;
-        set_w(p, wp);
-        p.Out = op + (size_t)b0 * Nf; p.ldc = Nf; p.out_Lp = Bn; p.out_stride = 1; p.out_off = 0;
-        p.L = Bn; p.M = Bn; p.N = Nf; p.bias = bd; p.mode = MODE_BIAS; p.out_f32 = 1;
+        const int Mr = esplit ? (Bn + 255) / 256 * 256 : Bn;      // split: whole tiles (rows beyond Bn are scratch rows)
+        p.A = ip + (size_t)b0 * Kf * E_; p.lda = Kf; p.in_Lp = Mr; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = Kf;
+        set_w(p, wp); p.a_plane = ppl;
+        p.Out = op + (size_t)b0 * eld; p.ldc = eld; p.out_Lp = Mr; p.out_stride = 1; p.out_off = 0;
+        p.L = Mr; p.M = Mr; p.N = esplit ? eld : Nf; p.bias = bd; p.mode = MODE_BIAS; p.out_f32 = 1;
         run_gemm(p, pr, s);
       });
     }
@@ -939,7 +959,7 @@ static int denoise_core(ditree_ctx* ctx, const float* noise, int64_t noise_strid
     // concurrency returns (34.9 vs 31.6 ms per round); default is one sub-batch, DITREE_ENC_SUBS overrides
     static int subs_env = -1;
     if (subs_env < 0) { const char* e = getenv("DITREE_ENC_SUBS"); subs_env = e ? std::max(1, std::min(atoi(e), (int)DenoiserState::ENC_SUBS)) : 1; }
-    const int nsub = (B >= 64) ? subs_env : 1;
+    const int nsub = (B >= 64 && !fmt_split(st->efmt)) ? subs_env : 1;      // the split encoder's fc writes whole 256-row tiles
     const int per = nsub == 1 ? B : std::min(st->sub_cap, (((B + nsub - 1) / nsub) + 15) / 16 * 16);
     if (nsub > 1 && !st->aux[1]) {
       for (int i = 1; i < DenoiserState::ENC_SUBS; ++i) {
@@ -970,7 +990,7 @@ static int denoise_core(ditree_ctx* ctx, const float* noise, int64_t noise_strid
       st->temb_t = K == 1 ? t : -1.0f;                                  // several steps share one buffer: recompute
     }
     st->note_other();
-    launch_prep_cond(st->temb, st->map_emb, st->E, cond, st->G, st->condA, B, st->condK, uf, st->cond_plane, s);
+    launch_prep_cond(st->temb, st->map_emb, st->E, st->E_ld, cond, st->G, st->condA, B, st->condK, uf, st->cond_plane, s);
     st->film_op(B, Bp, s);
     st->note_other();
     launch_prep_sample(st->x_cur, st->named["a0"].p, Bp, st->P, st->D, uf, st->named["a0"].plane, s);
@@ -1120,9 +1140,10 @@ int32_t ditree_denoise_debug_read(ditree_ctx* ctx, const char* name, int32_t B, 
   std::string nm(name);
   if (nm == "film" || nm == "map_emb") {
     const int cols = nm == "film" ? st->film_cols : st->E;
+    const int ld = nm == "film" ? st->film_cols : st->E_ld;
     const float* src = nm == "film" ? st->film : st->map_emb;
     if ((int64_t)B * cols > capacity) return set_err(ctx, DITREE_E_ARG, "debug_read: capacity");
-    HIP_TRY(ctx, hipMemcpyAsync(out, src, (size_t)B * cols * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(ctx, hipMemcpy2DAsync(out, (size_t)cols * 4, src, (size_t)ld * 4, (size_t)cols * 4, (size_t)B, hipMemcpyDeviceToDevice, s));
     dims3[0] = B; dims3[1] = 1; dims3[2] = cols;
     return DITREE_OK;
   }

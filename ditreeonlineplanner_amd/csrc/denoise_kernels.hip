@@ -1227,17 +1227,20 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
 //   (slot ^ (row >> 1) & 7), staged by LDS-DMA: 16 one-KiB pieces per stage, 4 per wave.
 //   Output f32 [M][N] (the GroupNorm kernel follows), rows >= M masked.
 // =================================================================================================
-template <int ET>
+//   SPLIT (hi + lo planes, the encoder of the f32-class instantiations): a K-step is 32 channels of a tap, an LDS row is
+//   [32 ch hi | the same 32 ch lo] and the step runs A_hi W_lo, A_hi W_hi, A_lo W_hi = 6 MFMAs instead of 4.
+template <int ET, bool SPLIT>
 __global__ void __launch_bounds__(256) conv2d_small_kernel(ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 16384;
+  constexpr int CK = SPLIT ? 32 : 64;                                // channels per K-step
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r5 = lane & 31, h = lane >> 5;
   const int wm = w >> 1, wn = w & 1;
   const int ntn = p.N >> 6;
   const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;      // N-tiles of one M-block are neighbours (A reuse in L2)
-  const int kpt = p.Cin >> 6;                                       // K-steps per tap
+  const int kpt = p.Cin / CK;                                       // K-steps per tap
   const long long K = (long long)p.taps * p.Cin;
   // split-K over blockIdx.y (layers with few tiles and long K): a contiguous range of K-steps per block, partial
   // tiles go to Out + y * slab_stride and are summed, in slab order, by the GroupNorm kernel
@@ -1255,10 +1258,14 @@ __global__ void __launch_bounds__(256) conv2d_small_kernel(ConvGemmParams p) {
   int ih0[2], iw0[2];
   const char* w_src[2];
   int slot_b[2];
+  long long plane_a[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int r = (2 * w + q) * 8 + (lane >> 3);                     // tile row 0..63
-    slot_b[q] = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+    const int slot = (lane & 7) ^ ((r >> 1) & 7);
+    slot_b[q] = SPLIT ? (slot & 3) * 16 : slot * 16;                 // byte offset inside the K-step's channel run
+    plane_a[q] = (SPLIT && (slot & 4)) ? p.a_plane : 0;
+    const long long plane_w = (SPLIT && (slot & 4)) ? p.w_plane : 0;
     int m = tm * 64 + r;
     m = m < p.M ? m : p.M - 1;
     const int b = m / p.c2_OHW, rem = m - b * p.c2_OHW;
@@ -1266,7 +1273,7 @@ __global__ void __launch_bounds__(256) conv2d_small_kernel(ConvGemmParams p) {
     a_base[q] = (const char*)p.A + (long long)b * p.c2_H * p.c2_W * p.Cin * 2;
     ih0[q] = oh * p.c2_stride - p.c2_pad;
     iw0[q] = ow * p.c2_stride - p.c2_pad;
-    w_src[q] = (const char*)p.W + ((long long)(tn * 64 + r) * K) * 2 + slot_b[q];
+    w_src[q] = (const char*)p.W + ((long long)(tn * 64 + r) * K) * 2 + slot_b[q] + plane_w;
   }
   auto issue = [&](int kl) {                                         // local K-step kl -> ring slot kl % 3
     const int k = k0 + kl;
@@ -1277,12 +1284,12 @@ __global__ void __launch_bounds__(256) conv2d_small_kernel(ConvGemmParams p) {
     for (int q = 0; q < 2; ++q) {
       const int ih = ih0[q] + kh, iw = iw0[q] + kw;
       const bool ok = ih >= 0 && ih < p.c2_H && iw >= 0 && iw < p.c2_W;
-      const char* src = ok ? a_base[q] + ((long long)(ih * p.c2_W + iw) * p.Cin + kin * 64) * 2 : (const char*)p.zero;
+      const char* src = ok ? a_base[q] + ((long long)(ih * p.c2_W + iw) * p.Cin + kin * CK) * 2 + plane_a[q] : (const char*)p.zero;
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + slot_b[q]), (LDS_AS void*)(st + (2 * w + q) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q)
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(w_src[q] + (long long)k * 128),
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(w_src[q] + (long long)k * (CK * 2)),
                                        (LDS_AS void*)(st + 8192 + (2 * w + q) * 1024), 16, 0, 0);
   };
 
@@ -1302,11 +1309,27 @@ __global__ void __launch_bounds__(256) conv2d_small_kernel(ConvGemmParams p) {
     __builtin_amdgcn_s_barrier();
     if (k + 2 < nk) issue(k + 2);                                    // into the slot read at step k-1
     const char* st = smem + (k % 3) * STAGE;
+    if constexpr (SPLIT) {
+      // 16-channel sub-steps 0, 1 = hi plane, 2, 3 = lo plane of the same 32 channels
+      short8_t af[4], bf[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const short8_t af = *(const short8_t*)(st + a_off + ((((ks << 1) | h) ^ sa) << 4));
-      const short8_t bf = *(const short8_t*)(st + b_off + ((((ks << 1) | h) ^ sb) << 4));
-      acc = mfma32<ET>(af, bf, acc);
+      for (int ks = 0; ks < 4; ++ks) {
+        af[ks] = *(const short8_t*)(st + a_off + ((((ks << 1) | h) ^ sa) << 4));
+        bf[ks] = *(const short8_t*)(st + b_off + ((((ks << 1) | h) ^ sb) << 4));
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) acc = mfma32<ET>(af[kk], bf[kk + 2], acc);       // A_hi x W_lo
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) acc = mfma32<ET>(af[kk], bf[kk], acc);           // A_hi x W_hi
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) acc = mfma32<ET>(af[kk + 2], bf[kk], acc);       // A_lo x W_hi
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const short8_t af = *(const short8_t*)(st + a_off + ((((ks << 1) | h) ^ sa) << 4));
+        const short8_t bf = *(const short8_t*)(st + b_off + ((((ks << 1) | h) ^ sb) << 4));
+        acc = mfma32<ET>(af, bf, acc);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's reads of stage k are complete
   }
@@ -1541,10 +1564,11 @@ static bool halo_eligible(const ConvGemmParams& p, int fmt) {
   return fmt_st(fmt) != ST_F32 && !p.c2d && p.taps == 3 && p.in_stride == 1 && p.in_Lp == p.L + 2 && (256 % p.L) == 0 &&
          p.L >= 16 && (p.M & 255) == 0 && (p.N & 255) == 0 && (p.Cin & 63) == 0 && p.Cin >= 192;
 }
-bool conv2d_small_eligible(int fmt) { return fmt_st(fmt) != ST_F32 && !fmt_split(fmt); }
+bool conv2d_small_eligible(int fmt) { return fmt_st(fmt) != ST_F32; }
 int conv_gemm_kind(const ConvGemmParams& p, int fmt) { return halo_eligible(p, fmt) ? 0 : (p.c2d ? 2 : 1); }
 bool conv_gemm_supported(const ConvGemmParams& p, int fmt) {
-  return !fmt_split(fmt) || halo_eligible(p, fmt) || gemm16_eligible(p, fmt);
+  return !fmt_split(fmt) || halo_eligible(p, fmt) || gemm16_eligible(p, fmt) ||
+         (p.c2d && (p.N & 63) == 0 && (p.Cin & 63) == 0 && p.out_f32 && p.mode == MODE_BIAS);
 }
 
 // > 64 KB of dynamic LDS needs the attribute once per kernel AND per device
@@ -1597,13 +1621,18 @@ void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
     }
     return;
   }
-  if (split) abort();      // host contract (conv_gemm_supported): a split GEMM always fits the halo / gemm16 tiles
   if (p.c2d && conv2d_small_eligible(fmt) && (p.N & 63) == 0 && (p.Cin & 63) == 0 && p.out_f32 && p.mode == MODE_BIAS) {
     const dim3 g2(((p.M + 63) >> 6) * (p.N >> 6), p.splitk > 1 ? p.splitk : 1);
-    if (f16) hipLaunchKernelGGL(conv2d_small_kernel<1>, g2, dim3(256), 3 * 16384, s, p);
-    else hipLaunchKernelGGL(conv2d_small_kernel<0>, g2, dim3(256), 3 * 16384, s, p);
+    if (split) {
+      if (f16) hipLaunchKernelGGL((conv2d_small_kernel<1, true>), g2, dim3(256), 3 * 16384, s, p);
+      else hipLaunchKernelGGL((conv2d_small_kernel<0, true>), g2, dim3(256), 3 * 16384, s, p);
+    } else {
+      if (f16) hipLaunchKernelGGL((conv2d_small_kernel<1, false>), g2, dim3(256), 3 * 16384, s, p);
+      else hipLaunchKernelGGL((conv2d_small_kernel<0, false>), g2, dim3(256), 3 * 16384, s, p);
+    }
     return;
   }
+  if (split) abort();      // host contract (conv_gemm_supported): a split GEMM always fits the halo / gemm16 / small-Conv2d tiles
   if (p.c2d) {
     const dim3 grid2(ntm * ntn, p.splitk > 1 ? p.splitk : 1);
     if (st == ST_F32) hipLaunchKernelGGL((conv_gemm_kernel<1, true>), grid2, block, 131072, s, p);
@@ -1747,7 +1776,7 @@ template <int PREC>
 __global__ void __launch_bounds__(256) encoder_stem_kernel(const float* __restrict__ lm /*[B][20][20]*/,
                                                            const float* __restrict__ W /*[49][64]: tap-major, coalesced per lane*/,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           void* __restrict__ out /*[B][25][64]*/, float eps) {
+                                                           void* __restrict__ out /*[B][25][64]*/, float eps, long long plane) {
   __shared__ float s_map[26 * 26];
   __shared__ float s_act[100 * 64];
   __shared__ float s_red[2][4][4];                    // [pass][position quarter][group]
@@ -1794,7 +1823,7 @@ __global__ void __launch_bounds__(256) encoder_stem_kernel(const float* __restri
     float y = fmaf(v[j], ga, be);
     y = y > 0.f ? y : 0.f;
     if constexpr (PREC == ST_BF16) y = bf2f(f2bf(y));      // the activation is stored as bf16 before the pool in the layered path
-    if constexpr (PREC == ST_F16) y = h2f(f2h(y));
+    if constexpr (PREC == ST_F16) y = h2f(f2h(y));         // (the split formats keep the f32 value: hi + lo carries it)
     s_act[(q + 4 * j) * 64 + c] = y;
   }
   __syncthreads();
@@ -1808,13 +1837,13 @@ __global__ void __launch_bounds__(256) encoder_stem_kernel(const float* __restri
         const int ih = oh * 2 + kh - 1, iw = ow * 2 + kw - 1;
         if (ih >= 0 && ih < 10 && iw >= 0 && iw < 10) best = fmaxf(best, s_act[(ih * 10 + iw) * 64 + oc]);
       }
-    store_elem<PREC>(out, (long long)b * 1600 + o, best);
+    store_elem<PREC>(out, (long long)b * 1600 + o, best, plane);
   }
 }
 void launch_encoder_stem(const float* lm, const float* W, const float* gamma, const float* beta, void* out, int B, float eps,
-                         int fmt, hipStream_t s) {
-#define CALL(F) hipLaunchKernelGGL(encoder_stem_kernel<F>, dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps)
-  DISPATCH_ST(fmt, CALL)
+                         int fmt, long long plane, hipStream_t s) {
+#define CALL(F) hipLaunchKernelGGL(encoder_stem_kernel<F>, dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps, plane)
+  DISPATCH_FMT(fmt, CALL)
 #undef CALL
 }
 
@@ -1879,22 +1908,22 @@ void launch_time_embed(float t, const float* W1, const float* b1, const float* W
 // FiLM input: Mish(cat(time_emb 256, map_emb E, obs_cond G)) zero-padded to Kpad columns
 // (conditional_unet1d.py:59-64 cond_encoder = Mish -> Linear, :293 global_feature).
 template <int PREC>
-__global__ void prep_cond_kernel(const float* __restrict__ temb, const float* __restrict__ map_emb, int E,
+__global__ void prep_cond_kernel(const float* __restrict__ temb, const float* __restrict__ map_emb, int E, int E_ld,
                                  const float* __restrict__ cond, int G, void* __restrict__ out, int B, int Kpad, long long plane) {
   const int b = blockIdx.x;
   for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
     float v = 0.f;
     bool live = true;
     if (k < 256) v = temb[k];
-    else if (k < 256 + E) v = map_emb[(long long)b * E + (k - 256)];
+    else if (k < 256 + E) v = map_emb[(long long)b * E_ld + (k - 256)];
     else if (k < 256 + E + G) v = cond[(long long)b * G + (k - 256 - E)];
     else live = false;
     store_elem<PREC>(out, (long long)b * Kpad + k, live ? MISH_OF(PREC)(v) : 0.f, plane);
   }
 }
-void launch_prep_cond(const float* temb, const float* map_emb, int E, const float* cond, int G, void* out, int B,
+void launch_prep_cond(const float* temb, const float* map_emb, int E, int E_ld, const float* cond, int G, void* out, int B,
                       int Kpad, int fmt, long long plane, hipStream_t s) {
-#define CALL(F) hipLaunchKernelGGL(prep_cond_kernel<F>, dim3(B), dim3(256), 0, s, temb, map_emb, E, cond, G, out, B, Kpad, plane)
+#define CALL(F) hipLaunchKernelGGL(prep_cond_kernel<F>, dim3(B), dim3(256), 0, s, temb, map_emb, E, E_ld, cond, G, out, B, Kpad, plane)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
 }
@@ -2020,7 +2049,7 @@ template <int PREC>
 __global__ void __launch_bounds__(256) gn2d_kernel(const float* __restrict__ in, int nslab, long long slab_stride,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const void* __restrict__ res, int relu, void* __restrict__ out, int HW,
-                                                   int C, float eps) {
+                                                   int C, float eps, long long res_plane, long long out_plane) {
   __shared__ float red[2][64];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int T = C >> 2, PP = 256 / T, G = C >> 4;
@@ -2074,39 +2103,54 @@ __global__ void __launch_bounds__(256) gn2d_kernel(const float* __restrict__ in,
     float y[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) y[j] = (v[k][j] - mean) * rstd * ga[j] + be[j];
+    constexpr int ET = (PREC & 3) == ST_F16 ? 1 : 0;
     if (res != nullptr) {
-      if constexpr (PREC == 1) {
+      if constexpr ((PREC & 3) == ST_F32) {
         const f32x4_t r = *(const f32x4_t*)((const float*)res + idx);
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] += r[j];
       } else {
         const short4_t r = *(const short4_t*)((const unsigned short*)res + idx);
+        if constexpr ((PREC & 4) != 0) {
+          const short4_t rl = *(const short4_t*)((const unsigned short*)((const char*)res + res_plane) + idx);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] += e2f<(PREC == ST_F16 ? 1 : 0)>((unsigned short)r[j]);
+          for (int j = 0; j < 4; ++j) y[j] += e2f<ET>((unsigned short)r[j]) + e2f<ET>((unsigned short)rl[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[j] += e2f<ET>((unsigned short)r[j]);
+        }
       }
     }
     if (relu) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) y[j] = y[j] > 0.f ? y[j] : 0.f;
     }
-    if constexpr (PREC == 1) {
+    if constexpr ((PREC & 3) == ST_F32) {
       const f32x4_t o = {y[0], y[1], y[2], y[3]};
       *(f32x4_t*)((float*)out + idx) = o;
     } else {
       short4_t o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (short)f2e<(PREC == ST_F16 ? 1 : 0)>(y[j]);
+      for (int j = 0; j < 4; ++j) o[j] = (short)f2e<ET>(y[j]);
       *(short4_t*)((unsigned short*)out + idx) = o;
+      if constexpr ((PREC & 4) != 0) {
+        short4_t o2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o2[j] = (short)f2e<ET>(y[j] - e2f<ET>((unsigned short)o[j]));
+        *(short4_t*)((unsigned short*)((char*)out + out_plane) + idx) = o2;
+      }
     }
   }
 }
 void launch_gn2d(const float* in, int nslab, long long slab_stride, const float* gamma, const float* beta, const void* res,
-                 int relu, void* out, int B, int HW, int C, float eps, int fmt, hipStream_t s) {
+                 int relu, void* out, int B, int HW, int C, float eps, int fmt, long long res_plane, long long out_plane,
+                 hipStream_t s) {
   // host-side shape contract of the kernel (ResNet-18 stages on maps up to 10 x 10)
   if (C < 64 || C > 1024 || (C & (C - 1)) != 0 || (HW + 256 / (C >> 2) - 1) / (256 / (C >> 2)) > GN2D_MAXP) abort();
   dim3 grid((unsigned)B), block(256);
-#define CALL(F) hipLaunchKernelGGL(gn2d_kernel<F>, grid, block, 0, s, in, nslab, slab_stride, gamma, beta, res, relu, out, HW, C, eps)
-  DISPATCH_ST(fmt, CALL)
+#define CALL(F) hipLaunchKernelGGL(gn2d_kernel<F>, grid, block, 0, s, in, nslab, slab_stride, gamma, beta, res, relu, out, HW, C, eps, \
+                                   res_plane, out_plane)
+  DISPATCH_FMT(fmt, CALL)
 #undef CALL
 }
 
@@ -2140,19 +2184,21 @@ void launch_maxpool2d(const void* in, void* out, int B, int H, int W, int C, int
 
 // AdaptiveAvgPool2d(1) on NHWC -> [B][C].
 template <int PREC>
-__global__ void avgpool2d_kernel(const void* __restrict__ in, void* __restrict__ out, int B, int HW, int C) {
+__global__ void avgpool2d_kernel(const void* __restrict__ in, void* __restrict__ out, int B, int HW, int C, long long in_plane,
+                                 long long out_plane) {
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (idx >= (long long)B * C) return;
   const int c = (int)(idx % C), b = (int)(idx / C);
   float s = 0.f;
-  for (int q = 0; q < HW; ++q) s += load_elem<PREC>(in, ((long long)b * HW + q) * C + c);
-  store_elem<PREC>(out, idx, s / (float)HW);
+  for (int q = 0; q < HW; ++q) s += load_elem<PREC>(in, ((long long)b * HW + q) * C + c, in_plane);
+  store_elem<PREC>(out, idx, s / (float)HW, out_plane);
 }
-void launch_avgpool2d(const void* in, void* out, int B, int HW, int C, int fmt, hipStream_t s) {
+void launch_avgpool2d(const void* in, void* out, int B, int HW, int C, int fmt, long long in_plane, long long out_plane,
+                      hipStream_t s) {
   long long total = (long long)B * C;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
-#define CALL(F) hipLaunchKernelGGL(avgpool2d_kernel<F>, grid, block, 0, s, in, out, B, HW, C)
-  DISPATCH_ST(fmt, CALL)
+#define CALL(F) hipLaunchKernelGGL(avgpool2d_kernel<F>, grid, block, 0, s, in, out, B, HW, C, in_plane, out_plane)
+  DISPATCH_FMT(fmt, CALL)
 #undef CALL
 }
 
