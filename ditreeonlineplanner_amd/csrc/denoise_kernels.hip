@@ -11,8 +11,12 @@
 //  * GEMM orientation: M = positions (B*L), N = output channels, K = taps*C_in;
 //    256 x 256 x (128 bytes of K) tiles, 8 waves as 4(M) x 2(N), each wave 64 x 128 with
 //    v_mfma_f32_32x32x16_bf16 / _f16 (PREC 0 / 2) or v_mfma_f32_32x32x2_f32 (PREC 1, parity path);
-//  * LDS rows are 128 B; the 16-B slot index is XOR-swizzled with (row>>1)&7 on the
-//    *source* address and on the ds_read_b128 address (conflict-free fragment reads);
+//  * LDS rows are 128 B; the 16-B slot index is XOR-swizzled on the *source* address and on the ds_read_b128 address:
+//    with (row >> 1) & 7 in the kernels whose fragment rows start at multiples of 16 (conflict-free there), with row & 7 in
+//    the halo kernels, whose fragment rows are shifted by the tap and by the halo rows of the samples in front (the
+//    (row >> 1) swizzle cost them 17.6 % of their LDS cycles in bank conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE,
+//    profiles/r02_bf16_pmc_sq.json; row & 7 is conflict-free for ANY row offset: a ds_read_b128 lane group then holds
+//    16 distinct (row parity, slot) pairs);
 //  * the weight rows of a tile are permuted in LDS so that lane r of a wave owns output
 //    channels 4r..4r+3: the epilogue then stores 8 B (bf16) / 16 B (f32) per lane,
 //    256 / 512 contiguous bytes per output row;
@@ -800,7 +804,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
   {
     const int r = w * 8 + (lane >> 3);                               // LDS row of the A block, piece 0
-    const int slot = (lane & 7) ^ ((r >> 1) & 7);                    // (r + 64 i) >> 1 & 7 is the same for every piece
+    const int slot = (lane & 7) ^ (r & 7);                           // (r + 64 i) & 7 is the same for every piece
     pa0 = (unsigned)((r * p.lda + slot * 8) * 2);
     const int r4r = r + 256;
     const int rs = r4r < a_rows ? r4r : a_rows - 1;
@@ -813,8 +817,8 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
   long long wq[4];
   {
     const int lr = lane >> 3;
-    const int slot0 = (lane & 7) ^ (lr >> 1);                        // q even: (r >> 1) & 7 = lr >> 1
-    const int slot1 = slot0 ^ 4;                                     // q odd:  (r >> 1) & 7 = 4 + (lr >> 1)
+    const int slot0 = (lane & 7) ^ lr;                               // r & 7 = lr for every piece q
+    const int slot1 = slot0;
     pbe = (unsigned)(((long long)(8 * lr) * K + slot0 * 8) * 2);
     pbo = (unsigned)(((long long)(8 * lr) * K + slot1 * 8) * 2);
 #pragma unroll
@@ -850,7 +854,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
   int lstep[4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) lstep[mb] = 16 * mb + 2 * (((wm * 64 + 16 * mb) / L) - ((wm * 64) / L));
-  const int swl = (r4 >> 1) & 7;
+  const int swl = r4 & 7;
   const int b_row_off = (wn * 128 + r4) * 128;
 
   f32x4_t acc[4][8];
@@ -865,7 +869,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       const int row = lrow0 + lstep[mb] + t;
-      const int ps = (((ks << 2) | h4) ^ ((row >> 1) & 7)) << 4;
+      const int ps = (((ks << 2) | h4) ^ (row & 7)) << 4;
       af[set][mb] = *(const short8_t*)(ab + row * 128 + ps);
     }
   };
@@ -1040,7 +1044,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
   {
     const int r = w * 8 + (lane >> 3);
-    const int slot = (lane & 7) ^ ((r >> 1) & 7);                    // LDS slot this lane fills; slots 4..7 = lo plane
+    const int slot = (lane & 7) ^ (r & 7);                           // logical slot this lane fetches; 4..7 = lo plane
     const unsigned po = (slot & 4) ? a_plane : 0u;
     pa0 = (unsigned)((r * p.lda + (slot & 3) * 8) * 2) + po;
     const int r4r = r + 256;
@@ -1051,8 +1055,8 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   long long wq[4];
   {
     const int lr = lane >> 3;
-    const int slot0 = (lane & 7) ^ (lr >> 1);
-    const int slot1 = slot0 ^ 4;
+    const int slot0 = (lane & 7) ^ lr;                               // r & 7 = lr for every piece q
+    const int slot1 = slot0;
     pbe = (unsigned)(((long long)(8 * lr) * K + (slot0 & 3) * 8) * 2) + ((slot0 & 4) ? w_plane : 0u);
     pbo = (unsigned)(((long long)(8 * lr) * K + (slot1 & 3) * 8) * 2) + ((slot1 & 4) ? w_plane : 0u);
 #pragma unroll
@@ -1081,7 +1085,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   int lstep[4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) lstep[mb] = 16 * mb + 2 * (((wm * 64 + 16 * mb) / L) - ((wm * 64) / L));
-  const int swl = (r4 >> 1) & 7;
+  const int swl = r4 & 7;
   const int b_row_off = (wn * 128 + r4) * 128;
 
   f32x4_t acc[4][8];
@@ -1097,7 +1101,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       const int row = lrow0 + lstep[mb] + t;
-      const int ps = (((pl << 2) | h4) ^ ((row >> 1) & 7)) << 4;
+      const int ps = (((pl << 2) | h4) ^ (row & 7)) << 4;
       af[set][mb] = *(const short8_t*)(ab + row * 128 + ps);
     }
   };

@@ -32,7 +32,7 @@ def rel(a, b):
 TOL = {   # measured (worst tapped layer): see profiles/r02_denoiser_precision_report.json
     1: dict(l2=4e-6, maxn=5e-5, atol=2.5e-5, rtol=2.5e-5),    # f32 MFMA: 1.7e-6 / 2.3e-5 / 1.1e-5 (summation order only)
     2: dict(l2=3e-6, maxn=3e-5, atol=2e-5, rtol=2e-5),        # f16 x3: 1.2e-6 / 1.3e-5 / 7.5e-6 (f32-class)
-    3: dict(l2=1.6e-5, maxn=1.2e-4, atol=8e-5, rtol=8e-5),    # bf16 x3: 7.6e-6 / 6.0e-5 / 3.9e-5 (16 significand bits)
+    3: dict(l2=3e-5, maxn=2e-4, atol=1.8e-4, rtol=1.8e-4),    # bf16 x3: 1.4e-5 / 9.7e-5 / 9.2e-5 (16 significand bits, encoder split too)
     4: dict(l2=2e-3, maxn=1.4e-2, atol=1e-2, rtol=1e-2),      # plain f16: 9.4e-4 / 6.9e-3 / 5.0e-3 (11 bits)
     0: dict(l2=1.6e-2, maxn=1.1e-1, atol=8.5e-2, rtol=8.5e-2),  # plain bf16: 7.8e-3 / 5.3e-2 / 4.1e-2 (8 bits)
 }
