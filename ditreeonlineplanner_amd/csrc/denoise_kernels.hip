@@ -772,7 +772,7 @@ extern "C" int ditree_debug_halo_stamp(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_stamp), sizeof(g_halo_stamp));
 }
 #endif
-template <int ET, bool SPLIT, int SCHED = 0>
+template <int ET, bool SPLIT>
 __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int A_BUF = 40960, W_BUF = 32768, W_BASE = 2 * A_BUF;
@@ -900,45 +900,22 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
     // Each phase is its own scheduling region (sched_barrier), inside it the fragment reads for the NEXT phase
     // are issued first, then the 16 MFMAs: hipcc otherwise sinks the reads to the end of the phase and the next
     // phase waits for LDS in front of every MFMA.
-    if constexpr (SCHED == 0) {
-      rdB(1, c, T, 0, 1);                 // phase (0,0)
-      mm16(0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      rdA(1, c, T, 1);                    // phase (0,1)
-      rdB(0, c, T, 1, 0);
-      mm16(0, 1, 1);
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      rdB(1, c, T, 1, 1);                 // phase (1,0)
-      mm16(1, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      // experiment: the three phases as ONE scheduling region; the fragment-address VALU of the following phases may
-      // move up between the MFMAs of the current one (two VALU slots behind every MFMA) instead of running as a block of
-      // ~25 instructions in front of each group of reads, during which neither wave of the SIMD feeds the matrix pipe
-      rdB(1, c, T, 0, 1);
-      mm16(0, 0, 0);
-      rdA(1, c, T, 1);
-      rdB(0, c, T, 1, 0);
-      mm16(0, 1, 1);
-      rdB(1, c, T, 1, 1);
-      mm16(1, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
-      if constexpr (SCHED == 1) __builtin_amdgcn_sched_barrier(0);          // SCHED 2: the read-ahead addresses may move above the barrier
-    }
+    rdB(1, c, T, 0, 1);                 // phase (0,0)
+    mm16(0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    rdA(1, c, T, 1);                    // phase (0,1)
+    rdB(0, c, T, 1, 0);
+    mm16(0, 1, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    rdB(1, c, T, 1, 1);                 // phase (1,0)
+    mm16(1, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (HAS_NEXT) {
       if constexpr (VM == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
@@ -1613,8 +1590,6 @@ static void ensure_lds_attrs() {
   hipFuncSetAttribute((const void*)conv_gemm_kernel<1, true>, at, 131072);
   hipFuncSetAttribute((const void*)conv_gemm_kernel<2, true>, at, 131072);
   hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, false>, at, 147456);
-  hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, false, 1>, at, 147456);
-  hipFuncSetAttribute((const void*)conv3_halo16_kernel<0, false, 2>, at, 147456);
   hipFuncSetAttribute((const void*)conv3_halo16_kernel<1, false>, at, 147456);
   hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<0>, at, 147456);
   hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<1>, at, 147456);
@@ -1635,11 +1610,7 @@ void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
       if (f16) hipLaunchKernelGGL(conv3_halo16x3_kernel<1>, grid, block, 147456, s, p);
       else hipLaunchKernelGGL(conv3_halo16x3_kernel<0>, grid, block, 147456, s, p);
     } else {
-      static int sched = -1;      // DITREE_HALO_SCHED=1: A/B of the one-region schedule (same results either way)
-      if (sched < 0) { const char* e = getenv("DITREE_HALO_SCHED"); sched = e ? atoi(e) : 0; }
       if (f16) hipLaunchKernelGGL((conv3_halo16_kernel<1, false>), grid, block, 147456, s, p);
-      else if (sched == 1) hipLaunchKernelGGL((conv3_halo16_kernel<0, false, 1>), grid, block, 147456, s, p);
-      else if (sched == 2) hipLaunchKernelGGL((conv3_halo16_kernel<0, false, 2>), grid, block, 147456, s, p);
       else hipLaunchKernelGGL((conv3_halo16_kernel<0, false>), grid, block, 147456, s, p);
     }
     return;
