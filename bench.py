@@ -110,7 +110,9 @@ def pmc_traffic(kernel, precision="bf16"):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02_{precision}_pmc_traffic.json")
     try:
         with open(path) as f:
-            k = json.load(f)["kernels"][kernel]
+            ks = json.load(f)["kernels"]
+        k = ks.get(kernel.replace("halo16_", "halo16x3_")) if precision in ("f16x3", "bf16x3") else None
+        k = k or ks[kernel]
         return {"traffic": k["hbm_bytes_per_launch"], "traffic_unit": "bytes per launch (L2-miss side: FETCH_SIZE*2 + WRITE_SIZE)",
                 "traffic_source": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))}
     except (OSError, KeyError, ValueError):

@@ -83,6 +83,21 @@ __device__ __forceinline__ float mish_f(float x) {
     const float n = __expf(x);
     const float d = fmaf(n, n + 2.0f, 2.0f);
     return fmaf(-2.0f * x, __builtin_amdgcn_rcpf(d), x);
+  } else if constexpr (PREC == 2) {
+    // f32-class at a third of the instructions of expf + IEEE division (the epilogue of the split kernels is VALU-bound):
+    // e^x = 2^t * (1 + r ln 2) with t = rnd(x log2 e) and r its exact residual (fma) plus the low part of the constant,
+    // 2^t by v_exp_f32 (1 ulp); 1 / (w + 2) by v_rcp_f32 and one Newton step.  Relative error ~1e-7, no branch.
+    const float L2E = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-08f, LN2 = 0.693147182464599609375f;
+    const float t = x * L2E;
+    const float r = fmaf(x, L2E_LO, fmaf(x, L2E, -t));
+    const float e = __builtin_amdgcn_exp2f(t);
+    const float n = fmaf(e, r * LN2, e);
+    const float w = n * (n + 2.0f);
+    const float d = w + 2.0f;
+    float q = __builtin_amdgcn_rcpf(d);
+    q = fmaf(fmaf(-d, q, 1.0f), q, q);
+    const float y = x * (w * q);
+    return x > 20.0f ? x : y;                      // softplus threshold as torch (also keeps w finite)
   } else {
     if (x > 20.0f) return x;                       // softplus threshold as torch
     const float n = expf(x);
@@ -747,7 +762,7 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if constexpr (SPLIT) v[j] = mish_f<1>((acc[mb][j][i] - mean) * ga[j] + (j < 4 ? bet0[j & 3] : bet1[j & 3])) * fs[j] + fb[j];
+        if constexpr (SPLIT) v[j] = mish_f<2>((acc[mb][j][i] - mean) * ga[j] + (j < 4 ? bet0[j & 3] : bet1[j & 3])) * fs[j] + fb[j];
         else v[j] = mish_f<0>(acc[mb][j][i] * ga[j] + be[j]) * fs[j] + fb[j];
       }
       if (has_res) {

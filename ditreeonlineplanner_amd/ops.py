@@ -336,7 +336,7 @@ def _ctx_profile(self, enable=True):
     check(self._h, lib().ditree_profile(self._h, int(enable)), "profile")
 
 
-PROFILE_KINDS = ("conv3_halo16_kernel", "gemm16_kernel + conv_gemm_kernel", "conv2d_small_kernel")
+PROFILE_KINDS = ("conv3_halo16_kernel", "gemm16_kernel + conv_gemm_kernel", "conv2d_small_kernel")      # split: conv3_halo16x3_kernel
 
 
 def _ctx_profile_read(self):

@@ -33,7 +33,7 @@ def counter_rows(path, counter):
 
 
 def short(name):
-    for k in ("conv3_halo16_kernel", "gemm16_kernel", "conv2d_small_kernel", "conv_gemm_kernel", "gn2d_kernel", "gn1d_kernel",
+    for k in ("conv3_halo16x3_kernel", "conv3_halo16_kernel", "gemm16_kernel", "conv2d_small_kernel", "conv_gemm_kernel", "gn2d_kernel", "gn1d_kernel",
               "final_proj_flow_kernel", "car_rollout_kernel", "lidar_scan_kernel", "nn_argmin_kernel", "local_map_kernel",
               "im2col2d_kernel", "maxpool2d_kernel", "encoder_stem_kernel"):
         if k in name:
