@@ -34,6 +34,9 @@ typedef __attribute__((ext_vector_type(8))) short short8_t;
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 half2_t;
+typedef __attribute__((ext_vector_type(2))) short short2_t;
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
@@ -104,6 +107,39 @@ __device__ __forceinline__ float mish_f(float x) {
     const float w = n * (n + 2.0f);
     return x * (w / (w + 2.0f));
   }
+}
+
+// the same on a pair of values (two tile rows of one channel: adjacent accumulator registers, so the packed f32
+// instructions v_pk_fma / v_pk_mul / v_pk_add take them without register shuffles).  PREC 0: throughput, 2: f32-class.
+template <int PREC>
+__device__ __forceinline__ f32x2_t mish2(f32x2_t x) {
+  if constexpr (PREC == 0) {
+    const f32x2_t n = {__expf(x[0]), __expf(x[1])};
+    const f32x2_t d = __builtin_elementwise_fma(n, n + 2.0f, f32x2_t{2.0f, 2.0f});
+    const f32x2_t q = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return __builtin_elementwise_fma(-2.0f * x, q, x);
+  } else {
+    const float L2E = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-08f, LN2 = 0.693147182464599609375f;
+    // exponent of min(x, 20): above torch's softplus threshold w / (w + 2) rounds to 1 and x comes back (no select)
+    const f32x2_t xm = {__builtin_fminf(x[0], 20.0f), __builtin_fminf(x[1], 20.0f)};
+    const f32x2_t l2e = {L2E, L2E};
+    const f32x2_t t = xm * l2e;
+    f32x2_t r = __builtin_elementwise_fma(xm, l2e, -t);
+    r = __builtin_elementwise_fma(xm, f32x2_t{L2E_LO, L2E_LO}, r);
+    const f32x2_t e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    const f32x2_t n = __builtin_elementwise_fma(e, r * LN2, e);
+    const f32x2_t w = n * (n + 2.0f);
+    const f32x2_t d = w + 2.0f;
+    f32x2_t q = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(-d, q, f32x2_t{1.0f, 1.0f}), q, q);
+    return x * (w * q);
+  }
+}
+
+// s + s of the lane that the row-local DPP control CTRL selects (a VALU add with a DPP operand: no LDS round trip)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float s) {
+  return s + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), CTRL, 0xf, 0xf, true));
 }
 
 // bijective XCD-aware tile remap (blocks b and b+8 share an XCD): each XCD gets a
@@ -594,189 +630,247 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
     blk_b[mb] = b;
     blk_l[mb] = m0 - b * p.L;
   }
-  // SPLIT: the row goes out as two planes, hi = rnd16(v) and lo = rnd16(v - hi)
-  auto store_row = [&](int mb, int i, const float (&v)[8]) {
-    const int b = blk_b[mb], l = blk_l[mb] + 4 * h4 + i;
-    const long long orow = (long long)b * p.out_Lp + (long long)l * p.out_stride + p.out_off;
-    const long long oidx = orow * p.ldc + p.out_coff + n0;
-    short8_t o;
+  // SPLIT: the row goes out as two planes, hi = rnd16(v) and lo = rnd16(v - hi).  f16 saturates at +-65504 (one
+  // v_med3 per element, before the split: |v - hi| is below half an ulp of hi and needs no clamp of its own).
+  auto store_row = [&](char* o, const float (&v)[8]) {
+    short8_t hi, lo;
+    if constexpr (ET == 1) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (short)f2e<ET>(v[j]);
-    *(short8_t*)((char*)p.Out + oidx * 2) = o;
-    if constexpr (SPLIT) {
-      short8_t o2;
+      for (int jj = 0; jj < 4; ++jj) {
+        const f32x2_t c = {__builtin_amdgcn_fmed3f(v[2 * jj], -65504.0f, 65504.0f),
+                           __builtin_amdgcn_fmed3f(v[2 * jj + 1], -65504.0f, 65504.0f)};
+        const half2_t h = __builtin_convertvector(c, half2_t);                  // v_cvt_pk_f16_f32 (RNE)
+        const short2_t hs = __builtin_bit_cast(short2_t, h);
+        hi[2 * jj] = hs[0]; hi[2 * jj + 1] = hs[1];
+        if constexpr (SPLIT) {
+          const half2_t l = __builtin_convertvector(c - __builtin_convertvector(h, f32x2_t), half2_t);
+          const short2_t ls = __builtin_bit_cast(short2_t, l);
+          lo[2 * jj] = ls[0]; lo[2 * jj + 1] = ls[1];
+        }
+      }
+    } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o2[j] = (short)f2e<ET>(v[j] - e2f<ET>((unsigned short)o[j]));
-      *(short8_t*)((char*)p.Out + p.out_plane + oidx * 2) = o2;
+      for (int j = 0; j < 8; ++j) {
+        hi[j] = (short)f2bf(v[j]);
+        if constexpr (SPLIT) lo[j] = (short)f2bf(v[j] - bf2f((unsigned short)hi[j]));
+      }
     }
+    *(short8_t*)o = hi;
+    if constexpr (SPLIT) *(short8_t*)(o + p.out_plane) = lo;
+  };
+  // first row of 16-row block mb of this lane (row 4*h4 of the block), and the byte step to the next row
+  auto out_ptr = [&](int mb, int esize) {
+    const long long orow = (long long)blk_b[mb] * p.out_Lp + (long long)(blk_l[mb] + 4 * h4) * p.out_stride + p.out_off;
+    return (char*)p.Out + (orow * p.ldc + p.out_coff + n0) * esize;
   };
   if (p.mode < MODE_GN_MISH) {                                // plain store: 16-bit activations, or f32 (the FiLM table)
+    const int esize = p.out_f32 ? 4 : 2;
+    const long long ostep = (long long)p.out_stride * p.ldc * esize;
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+    for (int mb = 0; mb < 4; ++mb) {
+      char* ob = out_ptr(mb, esize);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 4; ++i, ob += ostep) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = acc[mb][j][i];
         if (p.out_f32) {
-          const int b = blk_b[mb], l = blk_l[mb] + 4 * h4 + i;
-          const long long orow = (long long)b * p.out_Lp + (long long)l * p.out_stride + p.out_off;
-          float* o = (float*)p.Out + orow * p.ldc + p.out_coff + n0;
-          *(f32x4_t*)o = f32x4_t{v[0], v[1], v[2], v[3]};
-          *(f32x4_t*)(o + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+          *(f32x4_t*)ob = f32x4_t{v[0], v[1], v[2], v[3]};
+          *(f32x4_t*)(ob + 16) = f32x4_t{v[4], v[5], v[6], v[7]};
         } else {
-          store_row(mb, i, v);
+          store_row(ob, v);
         }
       }
+    }
     return;
   }
+  // LDS (free after the K loop): GroupNorm sums, then the tile's per-channel and per-sample operands.  They are read
+  // back block by block (16 transient registers instead of 48 resident ones: the accumulators fill the register file),
+  // and an LDS read does not queue behind the row stores the way a global load does (see below).
   float* s_sum = (float*)smem;                                // [16 slots][4 groups]
   float* s_sq = s_sum + 64;
-  if (tid < 128) s_sum[tid] = 0.0f;
-  const f32x4_t gam0 = *(const f32x4_t*)(p.gamma + n0), gam1 = *(const f32x4_t*)(p.gamma + n0 + 4);
-  const f32x4_t bet0 = *(const f32x4_t*)(p.beta + n0), bet1 = *(const f32x4_t*)(p.beta + n0 + 4);
-  // FiLM rows (per sample) and residual rows are fetched two / one 16-row block ahead.  The two modes exclude
-  // each other, so both use the same 2 x 4 x 16-B prefetch registers:
-  //   FiLM: pre[blk & 1] = {scale lo, scale hi, bias lo, bias hi} (f32);  residual: pre[blk & 1][i] = 8 elements of row i
-  //   (SPLIT: no look-ahead for the residual -- pre[0] = hi plane, pre[1] = lo plane of the CURRENT block; the epilogue is
-  //   a few % of a split kernel and a second pair of prefetch registers would spill)
-  f32x4_t pre[2][4];
-  auto fetch_film = [&](int blk) {
-    const float* fr = p.film + (long long)blk_b[blk] * p.film_ld + p.film_off + n0;
-    pre[blk & 1][0] = *(const f32x4_t*)fr;
-    pre[blk & 1][1] = *(const f32x4_t*)(fr + 4);
-    pre[blk & 1][2] = *(const f32x4_t*)(fr + p.N);
-    pre[blk & 1][3] = *(const f32x4_t*)(fr + p.N + 4);
-  };
-  auto fetch_res = [&](int blk) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long long rrow = (long long)blk_b[blk] * p.res_Lp + blk_l[blk] + 4 * h4 + i + p.res_off;
-      const char* rp = (const char*)p.Res + (rrow * p.ldres + n0) * 2;
-      if constexpr (SPLIT) {
-        pre[0][i] = *(const f32x4_t*)rp;
-        pre[1][i] = *(const f32x4_t*)(rp + p.res_plane);
-      } else {
-        pre[blk & 1][i] = *(const f32x4_t*)rp;
-      }
-    }
-  };
+  float* s_gb = s_sum + 128;                                  // gamma[256] | beta[256] of the tile's channels
+  float* s_film = s_gb + 512;                                 // FiLM rows of the tile's samples: [slot][scale 256 | bias 256]
   const bool has_film = p.mode == MODE_GN_MISH_FILM, has_res = p.mode == MODE_GN_MISH_RES;
-  if (has_film) { fetch_film(0); fetch_film(1); }
-  if (has_res && !SPLIT) fetch_res(0);
-  __syncthreads();
   const int spt = 256 / p.L;
+  if (tid < 128) s_sum[tid] = 0.0f;
+  s_gb[tid] = tid < 256 ? p.gamma[tn * 256 + tid] : p.beta[tn * 256 + tid - 256];
+  if (has_film) {
+    const int b_last = p.M / p.L - 1;
+    for (int idx = tid; idx < spt * 128; idx += 512) {
+      const int sm = idx >> 7, c4 = idx & 127;
+      const int b = min(tm * spt + sm, b_last);
+      const float* src = p.film + (long long)b * p.film_ld + p.film_off + tn * 256 + (c4 & 63) * 4 + (c4 >> 6) * p.N;
+      *(f32x4_t*)(s_film + sm * 512 + c4 * 4) = *(const f32x4_t*)src;
+    }
+  }
+  // The memory counter (vmcnt) retires in issue order and counts stores too: a load that is waited for behind a row's
+  // stores pays their round trip.  The residual rows therefore run in a ring of two tile rows (8 channels: hi [, lo]
+  // per row), refilled as soon as a pair has been read -- before the stores of that pair are issued.
+  f32x4_t rh[2], rl[2];
+  const long long rstep = (long long)p.ldres * 2;
+  auto fetch_res = [&](int r) {
+    const long long rrow = (long long)blk_b[r >> 2] * p.res_Lp + blk_l[r >> 2] + 4 * h4 + p.res_off;
+    const char* rp = (const char*)p.Res + (rrow * p.ldres + n0) * 2 + (r & 3) * rstep;
+    rh[r & 1] = *(const f32x4_t*)rp;
+    if constexpr (SPLIT) rl[r & 1] = *(const f32x4_t*)(rp + p.res_plane);
+  };
+  if (has_res) { fetch_res(0); fetch_res(1); }
+  __syncthreads();
   const int gi = c_l / p.group_ch;
   const bool wide = p.group_ch >= 128;
   const float inv_cnt = 1.0f / (float)(p.group_ch * p.L);
   int slot[4];
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) slot[mb] = blk_b[mb] - tm * spt;
-  // group reduction of a per-lane partial: the 16 lanes r4 of a row block hold 8 channels each -> xor 1, 2, 4 (64
-  // channels), 8 when the group is 128+ wide; h4 (xor 16, 32) walks the rows
-  auto wave_sum = [&](float s) {
-    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-    if (wide) s += __shfl_xor(s, 8);
-    return s;
+  for (int mb = 0; mb < 4; ++mb) slot[mb] = (blk_b[mb] - tm * spt) * 4 + gi;
+  // group reduction of the per-lane partials of the four row blocks: the 16 lanes r4 of a row hold 8 channels each ->
+  // DPP adds inside the row of 16 lanes (xor 1, 2, 4: 64 channels; the mirror of 16 when the group is 128+ wide), then the
+  // first lane of every row (h4 walks the tile rows) adds into the sample's LDS cell
+  const bool adder = r4 == 0 || (!wide && r4 == 8);
+  auto block_sums = [&](float (&s)[4], float* cell) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) s[mb] = dpp_add<0xB1>(s[mb]);           // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) s[mb] = dpp_add<0x4E>(s[mb]);           // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) s[mb] = dpp_add<0x141>(s[mb]);          // row_half_mirror
+    if (wide) {
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) s[mb] = dpp_add<0x140>(s[mb]);        // row_mirror
+    }
+    if (adder) {
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) atomicAdd(&cell[slot[mb]], s[mb]);
+    }
   };
   float mean_[4], rstd_[4];
+  auto pair = [&](int mb, int j, int ip) { return f32x2_t{acc[mb][j][2 * ip], acc[mb][j][2 * ip + 1]}; };
   if constexpr (!SPLIT) {
     // one pass: sum and sum of squares (f32), var = E[x^2] - mean^2
+    float s[4], q[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
-      float s = 0.f, q = 0.f;
+      f32x2_t s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float v = acc[mb][j][i];
-          s += v;
-          q = fmaf(v, v, q);
+        for (int ip = 0; ip < 2; ++ip) {
+          const f32x2_t v = pair(mb, j, ip);
+          s2 += v;
+          q2 = __builtin_elementwise_fma(v, v, q2);
         }
-      s = wave_sum(s);
-      q = wave_sum(q);
-      if (lane == 0 || (!wide && lane == 8)) {
-        atomicAdd(&s_sum[slot[mb] * 4 + gi], s);
-        atomicAdd(&s_sq[slot[mb] * 4 + gi], q);
-      }
+      s[mb] = s2[0] + s2[1];
+      q[mb] = q2[0] + q2[1];
     }
+    block_sums(s, s_sum);
+    block_sums(q, s_sq);
     __syncthreads();
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
-      mean_[mb] = s_sum[slot[mb] * 4 + gi] * inv_cnt;
-      const float var = fmaxf(s_sq[slot[mb] * 4 + gi] * inv_cnt - mean_[mb] * mean_[mb], 0.0f);
+      mean_[mb] = s_sum[slot[mb]] * inv_cnt;
+      const float var = fmaxf(s_sq[slot[mb]] * inv_cnt - mean_[mb] * mean_[mb], 0.0f);
       rstd_[mb] = rsqrtf(var + p.eps);
     }
   } else {
     // f32-class instantiations: mean first, then centred squares (as torch's GroupNorm)
+    float s[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
-      float s = 0.f;
+      f32x2_t s2 = {0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s += acc[mb][j][i];
-      s = wave_sum(s);
-      if (lane == 0 || (!wide && lane == 8)) atomicAdd(&s_sum[slot[mb] * 4 + gi], s);
+        for (int ip = 0; ip < 2; ++ip) s2 += pair(mb, j, ip);
+      s[mb] = s2[0] + s2[1];
     }
+    block_sums(s, s_sum);
     __syncthreads();
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
-      mean_[mb] = s_sum[slot[mb] * 4 + gi] * inv_cnt;
-      float q = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const float d = acc[mb][j][i] - mean_[mb]; q = fmaf(d, d, q); }
-      q = wave_sum(q);
-      if (lane == 0 || (!wide && lane == 8)) atomicAdd(&s_sq[slot[mb] * 4 + gi], q);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) rstd_[mb] = rsqrtf(s_sq[slot[mb] * 4 + gi] * inv_cnt + p.eps);
-  }
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
-    const float mean = mean_[mb], rstd = rstd_[mb];
-    if constexpr (SPLIT) { if (has_res) fetch_res(mb); }
-    else { if (has_res && mb < 3) fetch_res(mb + 1); }
-    float ga[8], be[8], fs[8], fb[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ga[j] = gam0[j] * rstd; ga[4 + j] = gam1[j] * rstd;
-      be[j] = bet0[j] - mean * ga[j]; be[4 + j] = bet1[j] - mean * ga[4 + j];
-      fs[j] = fs[4 + j] = 1.f;
-      fb[j] = fb[4 + j] = 0.f;
-    }
-    if (has_film) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        fs[j] = pre[mb & 1][0][j]; fs[4 + j] = pre[mb & 1][1][j];
-        fb[j] = pre[mb & 1][2][j]; fb[4 + j] = pre[mb & 1][3][j];
-      }
-      if (mb < 2) fetch_film(mb + 2);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float v[8];
+      mean_[mb] = s_sum[slot[mb]] * inv_cnt;
+      f32x2_t q2 = {0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if constexpr (SPLIT) v[j] = mish_f<2>((acc[mb][j][i] - mean) * ga[j] + (j < 4 ? bet0[j & 3] : bet1[j & 3])) * fs[j] + fb[j];
-        else v[j] = mish_f<0>(acc[mb][j][i] * ga[j] + be[j]) * fs[j] + fb[j];
-      }
-      if (has_res) {
-        const short8_t rv = __builtin_bit_cast(short8_t, pre[SPLIT ? 0 : (mb & 1)][i]);
-        if constexpr (SPLIT) {
-          const short8_t rl = __builtin_bit_cast(short8_t, pre[1][i]);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += e2f<ET>((unsigned short)rv[j]) + e2f<ET>((unsigned short)rl[j]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += e2f<ET>((unsigned short)rv[j]);
+        for (int ip = 0; ip < 2; ++ip) {
+          const f32x2_t d = pair(mb, j, ip) - mean_[mb];
+          q2 = __builtin_elementwise_fma(d, d, q2);
         }
+        if (j & 1) __builtin_amdgcn_sched_barrier(0);         // keeps the differences short-lived (they would spill)
       }
-      store_row(mb, i, v);
+      s[mb] = q2[0] + q2[1];
+    }
+    block_sums(s, s_sq);
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) rstd_[mb] = rsqrtf(s_sq[slot[mb]] * inv_cnt + p.eps);
+  }
+  // rows go through the arithmetic two at a time (rows 2ip, 2ip+1 of a block: the accumulator pairs above)
+  const long long ostep = (long long)p.out_stride * p.ldc * 2;
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    float mean = mean_[mb];
+    const float rstd = rstd_[mb];
+    // (SPLIT: x - mean is formed again here.  Made opaque so that the compiler does not keep the 128 centred values of
+    // the statistics pass alive next to the accumulators instead)
+    if constexpr (SPLIT) asm volatile("" : "+v"(mean));
+    float ga[8], be[8], fs[8], fb[8];
+    {
+      const f32x4_t gam0 = *(const f32x4_t*)(s_gb + c_l), gam1 = *(const f32x4_t*)(s_gb + c_l + 4);
+      const f32x4_t bet0 = *(const f32x4_t*)(s_gb + 256 + c_l), bet1 = *(const f32x4_t*)(s_gb + 256 + c_l + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ga[j] = gam0[j] * rstd; ga[4 + j] = gam1[j] * rstd;
+        if constexpr (SPLIT) { be[j] = bet0[j]; be[4 + j] = bet1[j]; }
+        else { be[j] = bet0[j] - mean * ga[j]; be[4 + j] = bet1[j] - mean * ga[4 + j]; }
+      }
+    }
+    if (has_film) {
+      const float* fr = s_film + (blk_b[mb] - tm * spt) * 512 + c_l;
+      const f32x4_t f0 = *(const f32x4_t*)fr, f1 = *(const f32x4_t*)(fr + 4);
+      const f32x4_t f2 = *(const f32x4_t*)(fr + 256), f3 = *(const f32x4_t*)(fr + 260);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { fs[j] = f0[j]; fs[4 + j] = f1[j]; fb[j] = f2[j]; fb[4 + j] = f3[j]; }
+    }
+    char* ob = out_ptr(mb, 2);
+#pragma unroll
+    for (int ip = 0; ip < 2; ++ip, ob += 2 * ostep) {
+      const int r = mb * 4 + 2 * ip;
+      f32x2_t v[8];
+      if (has_res) {
+        const short8_t h0 = __builtin_bit_cast(short8_t, rh[0]), h1 = __builtin_bit_cast(short8_t, rh[1]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f32x2_t{e2f<ET>((unsigned short)h0[j]), e2f<ET>((unsigned short)h1[j])};
+        if constexpr (SPLIT) {
+          const short8_t l0 = __builtin_bit_cast(short8_t, rl[0]), l1 = __builtin_bit_cast(short8_t, rl[1]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += f32x2_t{e2f<ET>((unsigned short)l0[j]), e2f<ET>((unsigned short)l1[j])};
+        }
+        if (r + 2 < 16) { fetch_res(r + 2); fetch_res(r + 3); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f32x2_t{0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f32x2_t x = pair(mb, j, ip);
+        if constexpr (SPLIT) x = (x - mean) * ga[j] + be[j];
+        else x = x * ga[j] + be[j];
+        x = mish2<SPLIT ? 2 : 0>(x);
+        v[j] += x;
+      }
+      if (has_film) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * fs[j] + fb[j];
+      }
+      float row[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) row[j] = v[j][0];
+      store_row(ob, row);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) row[j] = v[j][1];
+      store_row(ob + ostep, row);
+      __builtin_amdgcn_sched_barrier(0);                      // one row pair at a time: interleaved pairs spill
     }
   }
 }
@@ -785,6 +879,17 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
 __device__ unsigned long long g_halo_stamp[8];
 extern "C" int ditree_debug_halo_stamp(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_stamp), sizeof(g_halo_stamp));
+}
+// per-block timeline of the split halo kernel: {t_start, t_loop, t_epilogue, t_end} (100 MHz real-time clock),
+// {nv, block, HW_ID, XCC_ID}; one record per work-group, launch order
+#define X3_STAMP_MAX 65536
+__device__ unsigned long long g_x3_stamp[X3_STAMP_MAX][6];
+__device__ unsigned int g_x3_count;
+extern "C" int ditree_debug_x3_stamp(unsigned long long* out, unsigned int* count, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(count, HIP_SYMBOL(g_x3_count), 4);
+  if (rc == 0 && out != nullptr) rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x3_stamp), sizeof(unsigned long long) * 6 * X3_STAMP_MAX);
+  if (rc == 0 && reset) { unsigned int z = 0; rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_x3_count), &z, 4); }
+  return rc;
 }
 #endif
 template <int ET, bool SPLIT>
@@ -1199,6 +1304,9 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   using Tt = std::true_type;
   using Ff = std::false_type;
 
+#ifdef HALO16_STAMP
+  const unsigned long long xs0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
   for (int i = 0; i < 5; ++i) issue_a(0, i);
 #pragma unroll
@@ -1211,6 +1319,9 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   for (int i = 0; i < 5; ++i) issue_a(1, i);
   rdA(0, 0, 0, 0);
   rdB(0, 0, 0, 1, 0);
+#ifdef HALO16_STAMP
+  const unsigned long long xs1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   for (int v = 0; v < nv - 2; ++v) {
     step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, v);
@@ -1230,7 +1341,23 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
     step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, v);
   }
   __syncthreads();
+#ifdef HALO16_STAMP
+  const unsigned long long xs2 = __builtin_amdgcn_s_memrealtime();
+#endif
   gemm_epilogue16<ET, true>(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
+#ifdef HALO16_STAMP
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned long long xs3 = __builtin_amdgcn_s_memrealtime();
+    const unsigned int k = atomicAdd(&g_x3_count, 1u);
+    if (k < X3_STAMP_MAX) {
+      g_x3_stamp[k][0] = xs0; g_x3_stamp[k][1] = xs1; g_x3_stamp[k][2] = xs2; g_x3_stamp[k][3] = xs3;
+      g_x3_stamp[k][4] = ((unsigned long long)nv << 32) | blockIdx.x;
+      g_x3_stamp[k][5] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                         (unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+  }
+#endif
 }
 
 // =================================================================================================
