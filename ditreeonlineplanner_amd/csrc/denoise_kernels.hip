@@ -724,9 +724,11 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) slot[mb] = (blk_b[mb] - tm * spt) * 4 + gi;
   // group reduction of the per-lane partials of the four row blocks: the 16 lanes r4 of a row hold 8 channels each ->
-  // DPP adds inside the row of 16 lanes (xor 1, 2, 4: 64 channels; the mirror of 16 when the group is 128+ wide), then the
-  // first lane of every row (h4 walks the tile rows) adds into the sample's LDS cell
-  const bool adder = r4 == 0 || (!wide && r4 == 8);
+  // DPP adds inside the row of 16 lanes (xor 1, 2, 4: 64 channels; the mirror of 16 when the group is 128+ wide), the
+  // four rows h4 by two lane exchanges, and one lane per group adds into the sample's LDS cell.  For L <= 64 a cell is
+  // fed by one wave (in program order) or by the two wn waves of a 256-wide group with one add each, so the sum does not
+  // depend on the order the adds land in: results are reproducible bit for bit, whatever batch a sample is part of.
+  const bool adder = lane == 0 || (!wide && lane == 8);
   auto block_sums = [&](float (&s)[4], float* cell) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) s[mb] = dpp_add<0xB1>(s[mb]);           // quad_perm [1,0,3,2]
@@ -738,6 +740,10 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) s[mb] = dpp_add<0x140>(s[mb]);        // row_mirror
     }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) s[mb] += __shfl_xor(s[mb], 16);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) s[mb] += __shfl_xor(s[mb], 32);
     if (adder) {
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) atomicAdd(&cell[slot[mb]], s[mb]);

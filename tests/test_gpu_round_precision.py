@@ -22,13 +22,16 @@ from tests.util import REPO, load_maze
 
 pytestmark = pytest.mark.gpu
 B, H, A, P, N0 = 256, 32, 8, 64, 1024
-# precision -> (max |d state| allowed, status flips allowed among the 256 candidates)
 # precision -> (max |d state| allowed, status flips allowed among the 256 candidates, share of candidates that must stay
-# within 1e-5).  Measured (profiles/r02_round_precision.json): max 2.2e-6 / 2.6e-6 / 1.1e-3 / 3.2e-3 / 3.8e-2, no flips.  The
-# pipeline is discontinuous (a state difference of 1e-5 can move a pose across a cell boundary of the local map, the map
-# conditions the next chunk's denoiser call), so below f32-class accuracy the MAXIMUM over the candidates is set by a few
-# outliers: bf16x3 keeps 84 % of the candidates within 1e-5 (median 2.7e-6, 99th percentile 2.3e-5) but its worst one is off by 1e-3.
-BOUND = {1: (1e-5, 0, 1.0), 2: (1e-5, 0, 1.0), 3: (5e-3, 0, 0.7), 4: (1e-2, 2, 0.0), 0: (7.5e-2, 4, 0.0)}
+# within 1e-5, 99th percentile of |d state| allowed).  Measured (profiles/r02_round_precision.json): f32 2.2e-6, f16x3 2.6e-6
+# at the maximum, no flips.  The pipeline is discontinuous (a state difference of 1e-5 can move a pose across a cell boundary
+# of the local map, and the map conditions the next chunk's denoiser call), so below f32-class accuracy the MAXIMUM over the
+# candidates is set by one or two outliers and moves by an order of magnitude with any change of summation order (bf16x3:
+# 1.1e-3 on one build, 2.4e-5 on the next; f16: 3.2e-3, then 2.8e-2) while median and 99th percentile stay put (bf16x3
+# 2.7e-6 / 2.3e-5, f16 2.3e-4 / 3e-3, bf16 1.2e-3 / 2.4e-2).  The throughput modes are therefore held to three times their
+# 99th percentile, and their maximum only to a sanity bound.
+BOUND = {1: (1e-5, 0, 1.0, 1e-5), 2: (1e-5, 0, 1.0, 1e-5), 3: (5e-3, 0, 0.7, 1e-4), 4: (1e-1, 2, 0.0, 1e-2),
+         0: (2e-1, 4, 0.0, 7.5e-2)}
 NAMES = {0: "bf16", 1: "f32", 2: "f16x3", 3: "bf16x3", 4: "f16"}
 
 
@@ -138,10 +141,11 @@ def test_round_deviation(ctx, setup, prec):
     with open(out, "w") as f:
         json.dump(allr, f, indent=1)
     print(NAMES[prec], dev)
-    tol, flips, share = BOUND[prec]
+    tol, flips, share, p99 = BOUND[prec]
     assert dev["nn_parent_mismatches"] == 0                      # nearest node never depends on the denoiser
     assert dev["status_flips"] <= flips, dev
     assert max(dev["max_abs_end_state"], dev["max_abs_trajectory_state"]) < tol, dev
     assert dev["share_within_1e5"] >= share, dev
+    assert dev["p99_abs_trajectory_state"] < p99, dev
     if flips == 0:
         assert dev["tree_parent_mismatches"] == 0, dev
