@@ -68,6 +68,7 @@ struct DenoiserState {
   bool loaded = false;
   // workspace
   int prec = -1, Bmax = 0;     // prec: the DITREE_PREC_* the workspace was built for
+  int bgran = 16;              // batch rows are padded to a multiple of this
   int ufmt = 0, efmt = 0;      // formats (denoise.h) of the U-Net activations / GEMMs and of the encoder
   std::vector<void*> allocs;
   std::map<std::string, Act> named;
@@ -452,11 +453,13 @@ void DenoiserState::build(int prec_, int Bmax_) {
     case DITREE_PREC_F16: ufmt = fmt_make(ST_F16, false); efmt = ST_F16; break;
     default: throw std::runtime_error("unknown precision");
   }
-  Bmax = (Bmax_ + 15) / 16 * 16;
   const int C0 = dims[0], C1 = dims[1], C2 = dims[2];
   const int L0 = P, L1 = P / 2, L2 = P / 4;
   if (P % 16 != 0 || P < 16 || P > 256 || (256 % P) != 0) throw std::runtime_error("pred_horizon must be 16, 32, 64, 128 or 256");
-  if (fmt_split(ufmt) && P % 64 != 0) throw std::runtime_error("the split precisions need pred_horizon % 64 == 0 (halo / gemm16 tiles)");
+  // rows of a batch are padded to whole work units: 16 samples, or -- the split formats exist on the 256-row halo / gemm16
+  // tiles only -- as many as fill a tile at the shortest level (P / 4 rows per sample: 64 samples at P = 16)
+  bgran = fmt_split(ufmt) ? std::max(16, 1024 / P) : 16;
+  Bmax = (Bmax_ + bgran - 1) / bgran * bgran;
   if (fmt_split(ufmt) && ((C0 | C1 | C2) & 255) != 0)
     throw std::runtime_error("the split precisions need down_dims that are multiples of 256 (halo / gemm16 tiles)");
   x_cur = (float*)dalloc((size_t)Bmax * P * D * 4);
@@ -941,7 +944,7 @@ static int denoise_core(ditree_ctx* ctx, const float* noise, int64_t noise_strid
   if (B <= 0 || B > st->Bmax) return set_err(ctx, DITREE_E_ARG, "denoise: batch exceeds the reserved workspace");
   if (!noise || !local_map || !cond || !t0 || !dt || !act_norm || K <= 0 || (!actions && !x_out))
     return set_err(ctx, DITREE_E_ARG, "denoise: bad argument");
-  const int Bp = (B + 15) / 16 * 16;
+  const int Bp = (B + st->bgran - 1) / st->bgran * st->bgran;
   const int uf = st->ufmt;
   {
     const size_t row = (size_t)st->P * st->D * 4;         // one candidate's (P, D) f32 noise

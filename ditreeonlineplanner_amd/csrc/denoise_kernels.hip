@@ -666,11 +666,17 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
   if (p.mode < MODE_GN_MISH) {                                // plain store: 16-bit activations, or f32 (the FiLM table)
     const int esize = p.out_f32 ? 4 : 2;
     const long long ostep = (long long)p.out_stride * p.ldc * esize;
+    const bool short_l = (p.L & 15) != 0;                     // L = 8, 4: the rows of a 16-row block belong to several samples
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       char* ob = out_ptr(mb, esize);
 #pragma unroll
       for (int i = 0; i < 4; ++i, ob += ostep) {
+        if (short_l) {
+          const int m = tm * 256 + wm * 64 + mb * 16 + 4 * h4 + i;
+          const int b = m / p.L, l = m - b * p.L;
+          ob = (char*)p.Out + (((long long)b * p.out_Lp + (long long)l * p.out_stride + p.out_off) * p.ldc + p.out_coff + n0) * esize;
+        }
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = acc[mb][j][i];
@@ -1503,9 +1509,10 @@ __global__ void __launch_bounds__(256) conv2d_small_kernel(ConvGemmParams p) {
 // K-step with the next phase's ds_reads issued first, epilogue16; what differs is the K walk: K-step k = (tap k / nc,
 // 64-channel chunk k % nc) stages BOTH a 256-row activation tile and a 256-row weight tile (2 x 32 KB each,
 // double-buffered), two K-steps in flight, one barrier per K-step with a plain vmcnt(0).
-//   Activation row of tile row m = (b, l):  b*in_Lp + l*in_stride + in_off + tap.  An 8-row staging piece never leaves
-//   a sample (8 | L), so its source offset is wave-uniform + 8 lane-dependent rows: two lane offsets (the XOR swizzle
-//   depends on the piece parity) + scalar offsets, as for the weights.
+//   Activation row of tile row m = (b, l):  b*in_Lp + l*in_stride + in_off + tap.  An 8-row staging piece covers whole
+//   samples or lies inside one (L = 4, or 8 | L), so its source offset is wave-uniform + 8 lane-dependent rows: two lane
+//   offsets (the XOR swizzle depends on the piece parity) + scalar offsets, as for the weights.  L = 8 and 4 (the ant
+//   config's lower levels) are served for plain stores only (GroupNorm etc. then run in gn1d_kernel).
 // =================================================================================================
 template <int ET, bool SPLIT>
 __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
@@ -1543,14 +1550,17 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
   {
     const int lr = lane >> 3;
     const int slot0 = (lane & 7) ^ (lr >> 1), slot1 = slot0 ^ 4;     // piece parity 0 / 1: (r >> 1) & 7 = (lr >> 1) (+ 4)
+    // activation row of piece row lr, relative to the piece's first row: L >= 8 keeps the piece inside a sample, L = 4
+    // puts its second half into the next sample (in_Lp rows further)
+    const int lrb = lr / p.L, lro = lrb * p.in_Lp + (lr - lrb * p.L) * p.in_stride;
     if constexpr (SPLIT) {
-      pae = (unsigned)((lr * p.in_stride * p.lda + (slot0 & 3) * 8) * 2) + ((slot0 & 4) ? a_plane : 0u);
-      pao = (unsigned)((lr * p.in_stride * p.lda + (slot1 & 3) * 8) * 2) + ((slot1 & 4) ? a_plane : 0u);
+      pae = (unsigned)((lro * p.lda + (slot0 & 3) * 8) * 2) + ((slot0 & 4) ? a_plane : 0u);
+      pao = (unsigned)((lro * p.lda + (slot1 & 3) * 8) * 2) + ((slot1 & 4) ? a_plane : 0u);
       pbe = (unsigned)(((long long)(8 * lr) * K + (slot0 & 3) * 8) * 2) + ((slot0 & 4) ? w_plane : 0u);
       pbo = (unsigned)(((long long)(8 * lr) * K + (slot1 & 3) * 8) * 2) + ((slot1 & 4) ? w_plane : 0u);
     } else {
-      pae = (unsigned)((lr * p.in_stride * p.lda + slot0 * 8) * 2);
-      pao = (unsigned)((lr * p.in_stride * p.lda + slot1 * 8) * 2);
+      pae = (unsigned)((lro * p.lda + slot0 * 8) * 2);
+      pao = (unsigned)((lro * p.lda + slot1 * 8) * 2);
       pbe = (unsigned)(((long long)(8 * lr) * K + slot0 * 8) * 2);
       pbo = (unsigned)(((long long)(8 * lr) * K + slot1 * 8) * 2);
     }
@@ -1709,8 +1719,11 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
 // fmt = storage type | split << 2 (denoise.h).  The 16-bit tiles (halo, gemm16, small Conv2d) exist for bf16 and f16;
 // the hi/lo split forms only on the halo / gemm16 pipeline; f32 runs everything on conv_gemm_kernel<1>.
 static bool gemm16_eligible(const ConvGemmParams& p, int fmt) {
+  // L = 8 and 4 (the ant config's lower levels): plain stores only -- a 16-row block of the epilogue spans 2 or 4 samples
+  const bool short_ok = (p.L == 8 || p.L == 4) && p.mode == MODE_BIAS;
   return fmt_st(fmt) != ST_F32 && !p.c2d && (!p.out_f32 || p.mode == MODE_BIAS) && p.taps >= 1 && p.taps <= 3 && (p.M & 255) == 0 &&
-         (p.N & 255) == 0 && (p.Cin & 63) == 0 && (p.L & 15) == 0 && p.M > 0 && (p.mode == MODE_BIAS || (256 % p.L) == 0);
+         (p.N & 255) == 0 && (p.Cin & 63) == 0 && ((p.L & 15) == 0 || short_ok) && p.M > 0 &&
+         (p.mode == MODE_BIAS || (256 % p.L) == 0);
 }
 static bool halo_eligible(const ConvGemmParams& p, int fmt) {
   return fmt_st(fmt) != ST_F32 && !p.c2d && p.taps == 3 && p.in_stride == 1 && p.in_Lp == p.L + 2 && (256 % p.L) == 0 &&

@@ -72,7 +72,7 @@ class DiffusionSampler(nn.Module):
         # whose channels are not multiples of 256 have no split tiles: those default to the f32 MFMA instantiation.
         if precision is None:
             dims = getattr(noise_pred_net, "down_dims", ())
-            precision = _lib.PREC_F16X3 if dims and all(d % 256 == 0 for d in dims) and pred_horizon % 64 == 0 else _lib.PREC_F32
+            precision = _lib.PREC_F16X3 if dims and all(d % 256 == 0 for d in dims) and pred_horizon % 16 == 0 else _lib.PREC_F32
         self.precision = precision
         t0, dt = get_timesteps("exp", num_diffusion_iters, exp_scale=4.0)
         self.t0, self.dt = t0.numpy().copy(), dt.numpy().copy()

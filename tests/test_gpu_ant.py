@@ -67,11 +67,12 @@ def ant_net():
     return net
 
 
-# precision -> relative L2 bound on the flow-step output (the L = 8 and L = 4 levels run the unfused GEMM + GroupNorm kernels)
-ANT_TOL = {1: 1e-5, 4: 2e-3, 0: 1.6e-2}
+# precision -> relative L2 bound on the flow-step output (the L = 8 and L = 4 levels run the unfused GEMM + GroupNorm kernels;
+# the split instantiations run them on the gemm16 tiles with plain stores, the encoder of the 16 x 16 map in f32)
+ANT_TOL = {1: 1e-5, 2: 1e-5, 3: 1e-4, 4: 2e-3, 0: 1.6e-2}
 
 
-@pytest.mark.parametrize("prec", [1, 4, 0])
+@pytest.mark.parametrize("prec", [1, 2, 3, 4, 0])
 def test_ant_denoiser_against_oracle(ctx, ant_net, prec):
     from ditreeonlineplanner_amd.model import NoisePredNet
     g = torch.Generator().manual_seed(21)
@@ -92,14 +93,10 @@ def test_ant_denoiser_against_oracle(ctx, ant_net, prec):
     a = ctx.denoise(noise[:5].cuda().contiguous(), lm[:5].cuda().contiguous(), cond[:5].cuda().contiguous(),
                     act_norm=np.concatenate([OS.ANT_META["Actions_mean"], OS.ANT_META["Actions_std"]]), want_actions=True)
     assert a.dtype == torch.float64 and a.shape == (5, 16, 8)
-    assert np.abs(a.cpu().numpy() - x[:5].astype(np.float64)).max() < (1e-6 if prec == 1 else 1e-1)
+    assert np.abs(a.cpu().numpy() - x[:5].astype(np.float64)).max() < (1e-6 if prec in (1, 2) else 1e-1)
     # wrong shapes are refused, not mis-strided
     with pytest.raises(ValueError):
         ctx.denoise(torch.zeros(B, 64, 2, device="cuda"), lm.cuda(), cond.cuda(), want_actions=False)
-    # the split instantiations have no tiles for 16-step sequences: a clean error
-    from ditreeonlineplanner_amd._lib import DitreeError
-    with pytest.raises(DitreeError, match="pred_horizon"):
-        net.bind(ctx, precision=2, max_batch=B)
 
 
 def test_ant_sampler_facade(ctx, ant_net):
