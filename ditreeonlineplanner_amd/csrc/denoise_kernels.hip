@@ -892,6 +892,10 @@ __device__ unsigned long long g_halo_stamp[8];
 extern "C" int ditree_debug_halo_stamp(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_stamp), sizeof(g_halo_stamp));
 }
+__device__ unsigned int g_x3_phase[8][32];
+extern "C" int ditree_debug_x3_phase(unsigned int* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x3_phase), sizeof(g_x3_phase));
+}
 // per-block timeline of the split halo kernel: {t_start, t_loop, t_epilogue, t_end} (100 MHz real-time clock),
 // {nv, block, HW_ID, XCC_ID}; one record per work-group, launch order
 #define X3_STAMP_MAX 65536
@@ -1027,7 +1031,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
     constexpr int T = decltype(tT)::value;
     constexpr bool HAS_NEXT = decltype(tNext)::value, ISSUE_W = decltype(tIW)::value, ISSUE_A = decltype(tIA)::value;
     constexpr int VM = decltype(tVM)::value;
-    constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? 5 : 0);
+    constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? (T == 1 ? 1 : 2) : 0);
     asm volatile("" : "+v"(lrow0));    // keep the fragment-address arithmetic inside the step (hoisted it spills)
     // Each phase is its own scheduling region (sched_barrier), inside it the fragment reads for the NEXT phase
     // are issued first, then the 16 MFMAs: hipcc otherwise sinks the reads to the end of the phase and the next
@@ -1050,8 +1054,13 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (HAS_NEXT) {
       if constexpr (VM == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      // The two waves of a SIMD do not share the MFMA pipe evenly: the older one issues back to back and reaches the barrier
+      // early, the younger one crawls through this last phase (its MFMAs and, in program order behind them, its LDS-DMA
+      // issues) while the older one already runs the next step (in-kernel phase stamps, profiles/probes/x3_phases.py).
+      // Raised priority for the phase lets it finish first.
+      __builtin_amdgcn_s_setprio(2);
       constexpr int T1 = (T + 1) % 3;
       rdA(0, c + (T + 1) / 3, T1, 0);
       rdB(0, c + (T + 1) / 3, T1, 0, 0);
@@ -1065,29 +1074,36 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
         mm(1, 1, 1, mb, SNAKE ? ((mb & 1) ? 3 - jj : jj) : jj);
         const int i = mb * 4 + jj;
         // An LDS-DMA issue holds the wave's instruction stream for 60-180 cycles and both waves of a SIMD run this
-        // phase together: one issue behind every second MFMA (the ninth behind the last) instead of nine in a row
-        // leaves the partner wave MFMAs to issue in between (-1.7 % kernel time).
+        // phase together: one issue behind every second MFMA instead of all in a row leaves the partner wave MFMAs to
+        // issue in between (-1.7 % kernel time).  The five pieces of an activation stage go out over three steps
+        // (T = 2: pieces 0, 1 of chunk c+2; T = 0: pieces 2, 3 and T = 1: piece 4 of chunk c+1) instead of in one burst of
+        // nine issues per wave behind the T = 2 barrier: that burst (72 KB per CU at once) filled the address FIFO and held
+        // the younger wave of every SIMD for 3 000 cycles.
         const int d = (i & 1) ? -1 : (i >> 1);
         if constexpr (ISSUE_W) { if (d >= 0 && d < 4) issue_w(c2, T2, d); }
-        if constexpr (ISSUE_A) { if (d >= 4 && d < 8) issue_a(c + 2, d - 4); if (i == 15) issue_a(c + 2, 4); }
+        if constexpr (ISSUE_A) {
+          if constexpr (T == 2) { if (d == 4 || d == 5) issue_a(c + 2, d - 4); }
+          else if constexpr (T == 0) { if (d == 4 || d == 5) issue_a(c + 1, d - 2); }
+          else { if (d == 4) issue_a(c + 1, 4); }
+        }
       }
     if constexpr (HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
       if (!(i & 1) && (i >> 1) < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
-      if (i == 15 && NV == 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (HAS_NEXT) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
-  using I5 = std::integral_constant<int, 5>;
   using Tt = std::true_type;
   using Ff = std::false_type;
 
-  // ---- prologue: A(0), W(0,0) -> visible; then W(0,1) and A(1) in flight ----------------------------
+  // ---- prologue: A(0), W(0,0) -> visible; then W(0,1) and the first two pieces of A(1) in flight ------
 #pragma unroll
   for (int i = 0; i < 5; ++i) issue_a(0, i);
 #pragma unroll
@@ -1096,18 +1112,21 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int q = 0; q < 4; ++q) issue_w(0, 1, q);
-#pragma unroll
-  for (int i = 0; i < 5; ++i) issue_a(1, i);
+  issue_a(1, 0);
+  issue_a(1, 1);
   rdA(0, 0, 0, 0);
   rdB(0, 0, 0, 0, 0);
 
 #ifdef HALO16_STAMP
   const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
+  // Group issued in the last phase of a step: {W of the step after next x 4, then its A pieces}.  At the barrier of a step
+  // the previous step's W pieces must have landed -- the A pieces issued behind them may stay in flight: vmcnt(2) -- and at
+  // the barrier of T = 2 the whole next activation stage: vmcnt(0).
   for (int c = 0; c < nv - 2; ++c) {
-    step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, c);          // waits W(c,1); A(c+1) may stay in flight
-    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, c);
-    step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, c);          // stages W(c+1,1) then A(c+2)
+    step(I0{}, Tt{}, Tt{}, Tt{}, I2{}, c);          // waits W(c,1); A(c+1)[0,1] may stay in flight; stages W(c,2), A(c+1)[2,3]
+    step(I1{}, Tt{}, Tt{}, Tt{}, I2{}, c);          // stages W(c+1,0), A(c+1)[4]
+    step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, c);          // waits for all of A(c+1); stages W(c+1,1), A(c+2)[0,1]
   }
 #ifdef HALO16_STAMP
   if (blockIdx.x == 100 && tid == 0 && nv >= 32) {
@@ -1116,13 +1135,13 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
     g_halo_stamp[2] = (unsigned long long)(nv - 2) * 3;
   }
 #endif
-  // The counted wait (vmcnt(5)) is only used inside the loop above, whose body holds no other vector-memory
+  // The counted wait (vmcnt(2)) is only used inside the loop above, whose body holds no other vector-memory
   // operation.  The two tail chunks wait for everything: register spills the compiler may place here (scratch
   // accesses count in vmcnt) must not take part in a counted wait.
   {
     const int c = nv - 2;
-    step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, c);
-    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, c);
+    step(I0{}, Tt{}, Tt{}, Tt{}, I0{}, c);          // the rest of A(nv-1)
+    step(I1{}, Tt{}, Tt{}, Tt{}, I0{}, c);
     step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, c);
   }
   {
@@ -1253,36 +1272,50 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
       for (int jj = 0; jj < 4; ++jj) mm(aset, bset, half, mb, (mb & 1) ? 3 - jj : jj);
   };
 
+#ifdef X3_PHASE_STAMP     // diagnostic build: issue time (core clock) of every phase of the last full K-steps, per tap
+  unsigned pst[24];
+#define PSTAMP(k) do { pst[T * 8 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
   // One K-step (chunk v, tap T).  On entry af[0] = A_hi, bq[0] = W_lo(half 0) of this step.
   auto step = [&](auto tT, auto tNext, auto tIW, auto tIA, auto tVM, int v) {
     constexpr int T = decltype(tT)::value;
     constexpr bool HAS_NEXT = decltype(tNext)::value, ISSUE_W = decltype(tIW)::value, ISSUE_A = decltype(tIA)::value;
     constexpr int VM = decltype(tVM)::value;
     asm volatile("" : "+v"(lrow0));
+    PSTAMP(0);
     rdB(1, v, T, 1, 1);                 // P1: A_hi x W_lo(0); fetch W_lo(1)
     mm16(0, 0, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     __builtin_amdgcn_sched_barrier(0);
+    PSTAMP(1);
     rdB(0, v, T, 0, 0);                 // P2: A_hi x W_lo(1); fetch W_hi(0) and A_lo
     rdA(1, v, T, 1);
     mm16(0, 1, 1);
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     __builtin_amdgcn_sched_barrier(0);
+    PSTAMP(2);
     rdB(1, v, T, 0, 1);                 // P3: A_hi x W_hi(0); fetch W_hi(1)
     mm16(0, 0, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     __builtin_amdgcn_sched_barrier(0);
+    PSTAMP(3);
     mm16(1, 0, 0);                      // P4: A_lo x W_hi(0)
     __builtin_amdgcn_sched_barrier(0);
+    PSTAMP(4);
     mm16(0, 1, 1);                      // P5: A_hi x W_hi(1)
     __builtin_amdgcn_sched_barrier(0);
+    PSTAMP(5);
     if constexpr (HAS_NEXT) {
       if constexpr (VM == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(2);    // the last phase (LDS-DMA issue) ahead of the partner wave's next step (conv3_halo16_kernel)
+      PSTAMP(6);
       constexpr int T1 = (T + 1) % 3;
       rdA(0, v + (T + 1) / 3, T1, 0);               // next step's A_hi and W_lo(0)
       rdB(0, v + (T + 1) / 3, T1, 1, 0);
@@ -1297,22 +1330,29 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
         const int i = mb * 4 + jj;
         const int d = (i & 1) ? -1 : (i >> 1);
         if constexpr (ISSUE_W) { if (d >= 0 && d < 4) issue_w(v2, T2, d); }
-        if constexpr (ISSUE_A) { if (d >= 4 && d < 8) issue_a(v + 2, d - 4); if (i == 15) issue_a(v + 2, 4); }
+        // the five pieces of an activation stage go out over three steps (2 + 2 + 1) instead of in one burst
+        if constexpr (ISSUE_A) {
+          if constexpr (T == 2) { if (d == 4 || d == 5) issue_a(v + 2, d - 4); }
+          else if constexpr (T == 0) { if (d == 4 || d == 5) issue_a(v + 1, d - 2); }
+          else { if (d == 4) issue_a(v + 1, 4); }
+        }
       }
     if constexpr (HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);
-    constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? 5 : 0);
+    constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? (T == 1 ? 1 : 2) : 0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
       if (!(i & 1) && (i >> 1) < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
-      if (i == 15 && NV == 9) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (HAS_NEXT) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    PSTAMP(7);
   };
+#undef PSTAMP
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
-  using I5 = std::integral_constant<int, 5>;
   using Tt = std::true_type;
   using Ff = std::false_type;
 
@@ -1327,23 +1367,33 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int q = 0; q < 4; ++q) issue_w(0, 1, q);
-#pragma unroll
-  for (int i = 0; i < 5; ++i) issue_a(1, i);
+  issue_a(1, 0);
+  issue_a(1, 1);
   rdA(0, 0, 0, 0);
   rdB(0, 0, 0, 1, 0);
 #ifdef HALO16_STAMP
   const unsigned long long xs1 = __builtin_amdgcn_s_memrealtime();
 #endif
 
+  // group issued in the last phase of a step: {W of the step after next x 4, then A pieces}: T = 2 -> A(v+2)[0,1],
+  // T = 0 -> A(v+1)[2,3], T = 1 -> A(v+1)[4].  At the barrier of a step the previous step's W pieces must have landed (its
+  // A pieces, issued behind them, may stay in flight: vmcnt(2)), at the barrier of T = 2 the whole next A stage: vmcnt(0).
   for (int v = 0; v < nv - 2; ++v) {
-    step(I0{}, Tt{}, Tt{}, Ff{}, I5{}, v);
-    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, v);
+    step(I0{}, Tt{}, Tt{}, Tt{}, I2{}, v);
+    step(I1{}, Tt{}, Tt{}, Tt{}, I2{}, v);
     step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, v);
   }
+#ifdef X3_PHASE_STAMP
+  if (blockIdx.x == 100 && lane == 0 && nv == 64) {
+#pragma unroll
+    for (int k = 0; k < 24; ++k) g_x3_phase[w][k] = pst[k];
+    g_x3_phase[w][24] = (unsigned)nv;
+  }
+#endif
   {
     const int v = nv - 2;               // tails wait for everything (no counted wait next to possible spill traffic)
-    step(I0{}, Tt{}, Tt{}, Ff{}, I0{}, v);
-    step(I1{}, Tt{}, Tt{}, Ff{}, I0{}, v);
+    step(I0{}, Tt{}, Tt{}, Tt{}, I0{}, v);
+    step(I1{}, Tt{}, Tt{}, Tt{}, I0{}, v);
     step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, v);
   }
   {
