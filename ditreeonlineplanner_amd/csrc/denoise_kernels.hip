@@ -1027,40 +1027,54 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
   };
 
   // One K-step (chunk c, tap T); flags as in conv3_halo_kernel.  On entry af[0] = A(ks 0), bq[0] = B(ks 0, half 0).
+  // Wave priorities and the placement of the LDS-DMA requests: see conv3_halo16x3_kernel (same scheme, four phases).
   auto step = [&](auto tT, auto tNext, auto tIW, auto tIA, auto tVM, int c) {
     constexpr int T = decltype(tT)::value;
     constexpr bool HAS_NEXT = decltype(tNext)::value, ISSUE_W = decltype(tIW)::value, ISSUE_A = decltype(tIA)::value;
     constexpr int VM = decltype(tVM)::value;
-    constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? (T == 1 ? 1 : 2) : 0);
+    constexpr int NV = ISSUE_W ? 4 : 0;
     asm volatile("" : "+v"(lrow0));    // keep the fragment-address arithmetic inside the step (hoisted it spills)
     // Each phase is its own scheduling region (sched_barrier), inside it the fragment reads for the NEXT phase
     // are issued first, then the 16 MFMAs: hipcc otherwise sinks the reads to the end of the phase and the next
     // phase waits for LDS in front of every MFMA.
+    __builtin_amdgcn_s_setprio(2);
     rdB(1, c, T, 0, 1);                 // phase (0,0)
     mm16(0, 0, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
     rdA(1, c, T, 1);                    // phase (0,1)
     rdB(0, c, T, 1, 0);
     mm16(0, 1, 1);
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     __builtin_amdgcn_sched_barrier(0);
-    rdB(1, c, T, 1, 1);                 // phase (1,0)
+    __builtin_amdgcn_s_setprio(0);
+    rdB(1, c, T, 1, 1);                 // phase (1,0) + the activation pieces of chunk c+1 (T = 0: 0..2, T = 1: 3, 4)
     mm16(1, 0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    if constexpr (ISSUE_A && T != 2) {
+      if constexpr (T == 0) { issue_a(c + 1, 0); issue_a(c + 1, 1); issue_a(c + 1, 2); }
+      else { issue_a(c + 1, 3); issue_a(c + 1, 4); }
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      if constexpr (T == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (HAS_NEXT) {
       if constexpr (VM == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else if constexpr (VM == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      // The two waves of a SIMD do not share the MFMA pipe evenly: the older one issues back to back and reaches the barrier
-      // early, the younger one crawls through this last phase (its MFMAs and, in program order behind them, its LDS-DMA
-      // issues) while the older one already runs the next step (in-kernel phase stamps, profiles/probes/x3_phases.py).
-      // Raised priority for the phase lets it finish first.
-      __builtin_amdgcn_s_setprio(2);
+      __builtin_amdgcn_s_setprio(3);
       constexpr int T1 = (T + 1) % 3;
       rdA(0, c + (T + 1) / 3, T1, 0);
       rdB(0, c + (T + 1) / 3, T1, 0, 0);
@@ -1068,24 +1082,16 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
     constexpr int T2 = (T + 2) % 3;
     const int c2 = c + (T + 2) / 3;
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)      // phase (1,1) + the LDS-DMA issue of step s+2 / chunk c+2
+    for (int mb = 0; mb < 4; ++mb)      // phase (1,1) + the weight pieces of step s+2
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         mm(1, 1, 1, mb, SNAKE ? ((mb & 1) ? 3 - jj : jj) : jj);
         const int i = mb * 4 + jj;
         // An LDS-DMA issue holds the wave's instruction stream for 60-180 cycles and both waves of a SIMD run this
         // phase together: one issue behind every second MFMA instead of all in a row leaves the partner wave MFMAs to
-        // issue in between (-1.7 % kernel time).  The five pieces of an activation stage go out over three steps
-        // (T = 2: pieces 0, 1 of chunk c+2; T = 0: pieces 2, 3 and T = 1: piece 4 of chunk c+1) instead of in one burst of
-        // nine issues per wave behind the T = 2 barrier: that burst (72 KB per CU at once) filled the address FIFO and held
-        // the younger wave of every SIMD for 3 000 cycles.
+        // issue in between (-1.7 % kernel time).
         const int d = (i & 1) ? -1 : (i >> 1);
         if constexpr (ISSUE_W) { if (d >= 0 && d < 4) issue_w(c2, T2, d); }
-        if constexpr (ISSUE_A) {
-          if constexpr (T == 2) { if (d == 4 || d == 5) issue_a(c + 2, d - 4); }
-          else if constexpr (T == 0) { if (d == 4 || d == 5) issue_a(c + 1, d - 2); }
-          else { if (d == 4) issue_a(c + 1, 4); }
-        }
       }
     if constexpr (HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);
 #pragma unroll
@@ -1094,16 +1100,15 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
       if (!(i & 1) && (i >> 1) < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (HAS_NEXT) __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
   using Tt = std::true_type;
   using Ff = std::false_type;
 
-  // ---- prologue: A(0), W(0,0) -> visible; then W(0,1) and the first two pieces of A(1) in flight ------
+  // ---- prologue: A(0), W(0,0) -> visible; then W(0,1) in flight ----------------------------------------
 #pragma unroll
   for (int i = 0; i < 5; ++i) issue_a(0, i);
 #pragma unroll
@@ -1112,21 +1117,18 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int q = 0; q < 4; ++q) issue_w(0, 1, q);
-  issue_a(1, 0);
-  issue_a(1, 1);
   rdA(0, 0, 0, 0);
   rdB(0, 0, 0, 0, 0);
 
 #ifdef HALO16_STAMP
   const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  // Group issued in the last phase of a step: {W of the step after next x 4, then its A pieces}.  At the barrier of a step
-  // the previous step's W pieces must have landed -- the A pieces issued behind them may stay in flight: vmcnt(2) -- and at
-  // the barrier of T = 2 the whole next activation stage: vmcnt(0).
+  // Issue order and counted waits as in conv3_halo16x3_kernel: vmcnt(3) at the barrier of T = 0 (the three activation
+  // pieces requested in this step may stay in flight), vmcnt(2) at T = 1, vmcnt(0) at T = 2 (whole next activation stage).
   for (int c = 0; c < nv - 2; ++c) {
-    step(I0{}, Tt{}, Tt{}, Tt{}, I2{}, c);          // waits W(c,1); A(c+1)[0,1] may stay in flight; stages W(c,2), A(c+1)[2,3]
-    step(I1{}, Tt{}, Tt{}, Tt{}, I2{}, c);          // stages W(c+1,0), A(c+1)[4]
-    step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, c);          // waits for all of A(c+1); stages W(c+1,1), A(c+2)[0,1]
+    step(I0{}, Tt{}, Tt{}, Tt{}, I3{}, c);
+    step(I1{}, Tt{}, Tt{}, Tt{}, I2{}, c);
+    step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, c);
   }
 #ifdef HALO16_STAMP
   if (blockIdx.x == 100 && tid == 0 && nv >= 32) {
@@ -1135,12 +1137,12 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
     g_halo_stamp[2] = (unsigned long long)(nv - 2) * 3;
   }
 #endif
-  // The counted wait (vmcnt(2)) is only used inside the loop above, whose body holds no other vector-memory
-  // operation.  The two tail chunks wait for everything: register spills the compiler may place here (scratch
-  // accesses count in vmcnt) must not take part in a counted wait.
+  // The counted waits are only used inside the loop above, whose body holds no other vector-memory operation.  The two
+  // tail chunks wait for everything: register spills the compiler may place here (scratch accesses count in vmcnt) must
+  // not take part in a counted wait.
   {
     const int c = nv - 2;
-    step(I0{}, Tt{}, Tt{}, Tt{}, I0{}, c);          // the rest of A(nv-1)
+    step(I0{}, Tt{}, Tt{}, Tt{}, I0{}, c);          // the activation stage of the last chunk
     step(I1{}, Tt{}, Tt{}, Tt{}, I0{}, c);
     step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, c);
   }
@@ -1150,6 +1152,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
     step(I1{}, Tt{}, Ff{}, Ff{}, I0{}, c);
     step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, c);
   }
+  __builtin_amdgcn_s_setprio(0);
   __syncthreads();
   gemm_epilogue16<ET, SPLIT>(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
 }
@@ -1279,12 +1282,25 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
 #define PSTAMP(k) do { } while (0)
 #endif
   // One K-step (chunk v, tap T).  On entry af[0] = A_hi, bq[0] = W_lo(half 0) of this step.
+  //
+  // Wave priorities.  The in-kernel phase stamps (profiles/probes/x3_phases.py) showed that the two waves of a SIMD do not
+  // share the MFMA pipe: the older one issues back to back (16 MFMAs in 256 cycles), reaches the barrier 1 500 - 2 600
+  // cycles early and idles there, the younger one only gets the slots the older one leaves and then runs alone with nobody
+  // to cover its LDS waits.  Graded priorities (early phases high, late phases low, the phase behind the barrier highest)
+  // let the wave that is behind win the arbitration: the two stay within a phase of each other and arrive together.
+  //
+  // LDS-DMA issue.  All of a step's requests used to go out behind its barrier (4 weight pieces per wave, and the 5
+  // activation pieces of the chunk after next behind the T = 2 barrier): 72 KB per CU in one burst, on every CU at the same
+  // moment.  The address FIFO filled, and the younger waves sat 1 500 - 3 000 cycles in ONE buffer_load (MFMAs queued behind
+  // it in program order).  The activation pieces now go out in the middle of the following steps (3 in P4 of T = 0, 2 in
+  // P4 of T = 1), 16 - 24 KB per CU at a time.
   auto step = [&](auto tT, auto tNext, auto tIW, auto tIA, auto tVM, int v) {
     constexpr int T = decltype(tT)::value;
     constexpr bool HAS_NEXT = decltype(tNext)::value, ISSUE_W = decltype(tIW)::value, ISSUE_A = decltype(tIA)::value;
     constexpr int VM = decltype(tVM)::value;
     asm volatile("" : "+v"(lrow0));
     PSTAMP(0);
+    __builtin_amdgcn_s_setprio(2);
     rdB(1, v, T, 1, 1);                 // P1: A_hi x W_lo(0); fetch W_lo(1)
     mm16(0, 0, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
@@ -1298,23 +1314,37 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     __builtin_amdgcn_sched_barrier(0);
     PSTAMP(2);
+    __builtin_amdgcn_s_setprio(1);
     rdB(1, v, T, 0, 1);                 // P3: A_hi x W_hi(0); fetch W_hi(1)
     mm16(0, 0, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     __builtin_amdgcn_sched_barrier(0);
     PSTAMP(3);
-    mm16(1, 0, 0);                      // P4: A_lo x W_hi(0)
+    mm16(1, 0, 0);                      // P4: A_lo x W_hi(0) + the activation pieces of chunk v+1 (T = 0: 0..2, T = 1: 3, 4)
+    if constexpr (ISSUE_A && T != 2) {
+      if constexpr (T == 0) { issue_a(v + 1, 0); issue_a(v + 1, 1); issue_a(v + 1, 2); }
+      else { issue_a(v + 1, 3); issue_a(v + 1, 4); }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 2);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 2);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 2);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 2);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 2);
+      if constexpr (T == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 2);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 2);
+    }
     __builtin_amdgcn_sched_barrier(0);
     PSTAMP(4);
+    __builtin_amdgcn_s_setprio(0);
     mm16(0, 1, 1);                      // P5: A_hi x W_hi(1)
     __builtin_amdgcn_sched_barrier(0);
     PSTAMP(5);
     if constexpr (HAS_NEXT) {
       if constexpr (VM == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else if constexpr (VM == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_setprio(2);    // the last phase (LDS-DMA issue) ahead of the partner wave's next step (conv3_halo16_kernel)
+      __builtin_amdgcn_s_setprio(3);
       PSTAMP(6);
       constexpr int T1 = (T + 1) % 3;
       rdA(0, v + (T + 1) / 3, T1, 0);               // next step's A_hi and W_lo(0)
@@ -1323,29 +1353,21 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
     constexpr int T2 = (T + 2) % 3;
     const int v2 = v + (T + 2) / 3;
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)      // P6: A_lo x W_hi(1) + the LDS-DMA issue of step s+2 / chunk v+2
+    for (int mb = 0; mb < 4; ++mb)      // P6: A_lo x W_hi(1) + the weight pieces of step s+2, one behind every second MFMA
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         mm(1, 1, 1, mb, (mb & 1) ? 3 - jj : jj);
         const int i = mb * 4 + jj;
         const int d = (i & 1) ? -1 : (i >> 1);
         if constexpr (ISSUE_W) { if (d >= 0 && d < 4) issue_w(v2, T2, d); }
-        // the five pieces of an activation stage go out over three steps (2 + 2 + 1) instead of in one burst
-        if constexpr (ISSUE_A) {
-          if constexpr (T == 2) { if (d == 4 || d == 5) issue_a(v + 2, d - 4); }
-          else if constexpr (T == 0) { if (d == 4 || d == 5) issue_a(v + 1, d - 2); }
-          else { if (d == 4) issue_a(v + 1, 4); }
-        }
       }
     if constexpr (HAS_NEXT) __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);
-    constexpr int NV = (ISSUE_W ? 4 : 0) + (ISSUE_A ? (T == 1 ? 1 : 2) : 0);
+    constexpr int NV = ISSUE_W ? 4 : 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
       if (!(i & 1) && (i >> 1) < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (HAS_NEXT) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     PSTAMP(7);
   };
@@ -1353,6 +1375,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
   using Tt = std::true_type;
   using Ff = std::false_type;
 
@@ -1367,19 +1390,18 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int q = 0; q < 4; ++q) issue_w(0, 1, q);
-  issue_a(1, 0);
-  issue_a(1, 1);
   rdA(0, 0, 0, 0);
   rdB(0, 0, 0, 1, 0);
 #ifdef HALO16_STAMP
   const unsigned long long xs1 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-  // group issued in the last phase of a step: {W of the step after next x 4, then A pieces}: T = 2 -> A(v+2)[0,1],
-  // T = 0 -> A(v+1)[2,3], T = 1 -> A(v+1)[4].  At the barrier of a step the previous step's W pieces must have landed (its
-  // A pieces, issued behind them, may stay in flight: vmcnt(2)), at the barrier of T = 2 the whole next A stage: vmcnt(0).
+  // Issue order: [behind the barrier of (v-1,2): W(v,1) x 4] [P4 of (v,0): A(v+1)[0..2]] [behind the barrier of (v,0): W(v,2)
+  // x 4] [P4 of (v,1): A(v+1)[3,4]] [(v,1): W(v+1,0) x 4] [(v,2): W(v+1,1) x 4] ...  The barrier of a step needs the W
+  // pieces requested behind the previous barrier -- what was requested after them may stay in flight: vmcnt(3) at T = 0,
+  // vmcnt(2) at T = 1 -- and the barrier of T = 2 the whole activation stage of the next chunk: vmcnt(0).
   for (int v = 0; v < nv - 2; ++v) {
-    step(I0{}, Tt{}, Tt{}, Tt{}, I2{}, v);
+    step(I0{}, Tt{}, Tt{}, Tt{}, I3{}, v);
     step(I1{}, Tt{}, Tt{}, Tt{}, I2{}, v);
     step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, v);
   }
@@ -1392,7 +1414,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
 #endif
   {
     const int v = nv - 2;               // tails wait for everything (no counted wait next to possible spill traffic)
-    step(I0{}, Tt{}, Tt{}, Tt{}, I0{}, v);
+    step(I0{}, Tt{}, Tt{}, Tt{}, I0{}, v);          // the activation stage of the last chunk
     step(I1{}, Tt{}, Tt{}, Tt{}, I0{}, v);
     step(I2{}, Tt{}, Tt{}, Ff{}, I0{}, v);
   }
@@ -1402,6 +1424,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
     step(I1{}, Tt{}, Ff{}, Ff{}, I0{}, v);
     step(I2{}, Ff{}, Ff{}, Ff{}, I0{}, v);
   }
+  __builtin_amdgcn_s_setprio(0);
   __syncthreads();
 #ifdef HALO16_STAMP
   const unsigned long long xs2 = __builtin_amdgcn_s_memrealtime();
