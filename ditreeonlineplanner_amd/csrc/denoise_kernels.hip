@@ -1994,9 +1994,118 @@ __global__ void __launch_bounds__(256) gn1d_kernel(void* __restrict__ x, int ld,
     }
   }
 }
+// The same for short sequences in the 16-bit formats (the ant config's L = 8 and 4 levels: a (sample, group) is 128
+// 8-channel vectors): one WAVE per (sample, group), its vectors (up to four per lane) stay in registers -- one 16-byte load
+// per vector and plane, statistics by wave reductions, one 16-byte store per vector and plane; four (sample, group)s per
+// work-group.  Same arithmetic as gn1d_kernel (mean, then centred squares), so results are identical.
+template <int FMT>
+__global__ void __launch_bounds__(256) gn1d_short_kernel(void* __restrict__ x, int ld, int Lp, int row_off, int coff, int L, int C,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, int mode, const float* __restrict__ film, int film_ld,
+                                                         int film_off, const void* __restrict__ res, int ldres, int res_Lp,
+                                                         int res_off, long long x_plane, long long res_plane, int n_sg) {
+  constexpr int ET = (FMT & 3) == ST_F16 ? 1 : 0;
+  constexpr bool SPL = (FMT & 4) != 0;
+  const int lane = threadIdx.x & 63;
+  const int sg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (sg >= n_sg) return;
+  const int b = sg >> 3, g = sg & 7;
+  const int gc = C >> 3, vpr = gc >> 3, nvec = L * vpr;
+  float v[4][8];
+  long long idx[4];
+  int cc[4], ll[4];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int vi = lane + 64 * k;
+    if (vi < nvec) {
+      const int l = vi / vpr, c = g * gc + (vi - l * vpr) * 8;
+      ll[k] = l; cc[k] = c;
+      idx[k] = ((long long)b * Lp + l + row_off) * ld + coff + c;
+      const short8_t h = *(const short8_t*)((const char*)x + idx[k] * 2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[k][j] = e2f<ET>((unsigned short)h[j]);
+      if constexpr (SPL) {
+        const short8_t lo = *(const short8_t*)((const char*)x + x_plane + idx[k] * 2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[k][j] += e2f<ET>((unsigned short)lo[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[k][j];
+    }
+  }
+  auto wave_sum = [&](float t) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m);
+    return t;
+  };
+  const float inv_n = 1.0f / (float)(L * gc);
+  const float mean = wave_sum(s) * inv_n;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (lane + 64 * k < nvec) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mean; q = fmaf(d, d, q); }
+    }
+  const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (lane + 64 * k < nvec) {
+      const int c = cc[k];
+      const f32x4_t g0 = *(const f32x4_t*)(gamma + c), g1 = *(const f32x4_t*)(gamma + c + 4);
+      const f32x4_t b0 = *(const f32x4_t*)(beta + c), b1 = *(const f32x4_t*)(beta + c + 4);
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        y[j] = MISH_OF(FMT)((v[k][j] - mean) * rstd * (j < 4 ? g0[j & 3] : g1[j & 3]) + (j < 4 ? b0[j & 3] : b1[j & 3]));
+      if (mode == MODE_GN_MISH_FILM) {
+        const float* fr = film + (long long)b * film_ld + film_off + c;
+        const f32x4_t s0 = *(const f32x4_t*)fr, s1 = *(const f32x4_t*)(fr + 4);
+        const f32x4_t t0 = *(const f32x4_t*)(fr + C), t1 = *(const f32x4_t*)(fr + C + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = y[j] * (j < 4 ? s0[j & 3] : s1[j & 3]) + (j < 4 ? t0[j & 3] : t1[j & 3]);
+      } else if (mode == MODE_GN_MISH_RES) {
+        const long long ri = ((long long)b * res_Lp + ll[k] + res_off) * ldres + c;
+        const short8_t rh = *(const short8_t*)((const char*)res + ri * 2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] += e2f<ET>((unsigned short)rh[j]);
+        if constexpr (SPL) {
+          const short8_t rl = *(const short8_t*)((const char*)res + res_plane + ri * 2);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) y[j] += e2f<ET>((unsigned short)rl[j]);
+        }
+      }
+      short8_t oh, ol;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned short hh = f2e<ET>(y[j]);
+        oh[j] = (short)hh;
+        if constexpr (SPL) ol[j] = (short)f2e<ET>(y[j] - e2f<ET>(hh));
+      }
+      *(short8_t*)((char*)x + idx[k] * 2) = oh;
+      if constexpr (SPL) *(short8_t*)((char*)x + x_plane + idx[k] * 2) = ol;
+    }
+}
 void launch_gn1d(void* x, int ld, int Lp, int row_off, int coff, int L, int C, const float* gamma, const float* beta, float eps,
                  int mode, const float* film, int film_ld, int film_off, const void* res, int ldres, int res_Lp, int res_off,
                  int B, int fmt, long long x_plane, long long res_plane, hipStream_t s) {
+  // short (sample, group)s in a 16-bit format, 16-byte aligned vectors: the one-wave form
+  if (fmt_st(fmt) != ST_F32 && L * (C >> 6) <= 256 && (C & 63) == 0 && (ld & 7) == 0 && (coff & 7) == 0 &&
+      (mode != MODE_GN_MISH_RES || (ldres & 7) == 0) && (mode != MODE_GN_MISH_FILM || ((film_ld | film_off) & 3) == 0)) {
+    const int n_sg = B * 8;
+#define CALLS(F) hipLaunchKernelGGL(gn1d_short_kernel<F>, dim3((n_sg + 3) / 4), dim3(256), 0, s, x, ld, Lp, row_off, coff, L, C, gamma, \
+                                    beta, eps, mode, film, film_ld, film_off, res, ldres, res_Lp, res_off, x_plane, res_plane, n_sg)
+    switch (fmt) {
+      case 0: CALLS(0); break;
+      case 2: CALLS(2); break;
+      case 4: CALLS(4); break;
+      case 6: CALLS(6); break;
+      default: abort();
+    }
+#undef CALLS
+    return;
+  }
 #define CALL(F) hipLaunchKernelGGL(gn1d_kernel<F>, dim3(B * 8), dim3(256), 0, s, x, ld, Lp, row_off, coff, L, C, gamma, beta, eps, \
                                    mode, film, film_ld, film_off, res, ldres, res_Lp, res_off, x_plane, res_plane)
   DISPATCH_FMT(fmt, CALL)
