@@ -464,7 +464,7 @@ def run_ant_denoise(args):
                                       "[local map 16x16@0.8 s_global 4, ant cond vector (rot6d), encoder + U-Net P=16 D=8 cond 497, flow step]; "
                                       "NO dynamics (MuJoCo: no oracle)", "batch_per_gpu": B, "calls_per_candidate": n_calls},
                "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                            "kernel": "all MFMA kernels of the denoiser (L = 8 / 4 levels: plain GEMM + gn1d_kernel, unfused; split formats: 3 MFMAs per product, encoder of the 16 x 16 map in f32)",
+                            "kernel": "all MFMA kernels of the denoiser (L = 8 / 4 levels: plain GEMM + gn1d_short_kernel, unfused; split formats: 3 MFMAs per product)",
                             "per_kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
                             "algorithmic_gflop_per_candidate": 2.0 * mac * n_calls / 1e9,
                             "note": "events around every MFMA launch inside the timed region (costs a few %)"}}

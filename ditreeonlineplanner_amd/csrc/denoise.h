@@ -77,8 +77,8 @@ struct TapList {          // live (kh, kw) taps of a Conv2d on a small map
 void launch_gn1d(void* x, int ld, int Lp, int row_off, int coff, int L, int C, const float* gamma, const float* beta, float eps,
                  int mode, const float* film, int film_ld, int film_off, const void* res, int ldres, int res_Lp, int res_off,
                  int B, int fmt, long long x_plane, long long res_plane, hipStream_t s);
-void launch_encoder_stem(const float* lm, const float* W /*[49][64] f32 (tap-major), input channels folded*/, const float* gamma,
-                         const float* beta, void* out /*[B][25][64]*/, int B, float eps, int fmt, long long plane, hipStream_t s);
+void launch_encoder_stem(const float* lm, int n, const float* W, const float* gamma, const float* beta, void* out, int B, float eps,
+                         int fmt, long long plane, hipStream_t s);
 void launch_im2col2d(const void* in, bool src_f32, void* out, int B, int H, int W, int C, const TapList& taps, int stride,
                      int pad, int OH, int OW, int Kpad, int fmt, hipStream_t s);
 void launch_gn2d(const float* in, int nslab, long long slab_stride, const float* gamma, const float* beta, const void* res,

@@ -443,13 +443,13 @@ struct DenoiserState {
 void DenoiserState::build(int prec_, int Bmax_) {
   free_workspace();
   prec = prec_;
-  // DITREE_PREC_*  ->  formats of the U-Net and of the encoder.  The split instantiations run the encoder split as well
-  // when its stem is the fused 20 x 20 kernel (car); the layered stem (other map sizes) has no hi / lo form: f32 there.
+  // DITREE_PREC_*  ->  formats of the U-Net and of the encoder (the split instantiations run the encoder split as well: its
+  // stem is the fused kernel for both map sizes, 20 x 20 and 16 x 16).
   switch (prec) {
     case DITREE_PREC_BF16: ufmt = fmt_make(ST_BF16, false); efmt = ST_BF16; break;
     case DITREE_PREC_F32: ufmt = fmt_make(ST_F32, false); efmt = ST_F32; break;
-    case DITREE_PREC_F16X3: ufmt = fmt_make(ST_F16, true); efmt = lm == 20 ? ufmt : (int)ST_F32; break;
-    case DITREE_PREC_BF16X3: ufmt = fmt_make(ST_BF16, true); efmt = lm == 20 ? ufmt : (int)ST_F32; break;
+    case DITREE_PREC_F16X3: ufmt = fmt_make(ST_F16, true); efmt = ufmt; break;
+    case DITREE_PREC_BF16X3: ufmt = fmt_make(ST_BF16, true); efmt = ufmt; break;
     case DITREE_PREC_F16: ufmt = fmt_make(ST_F16, false); efmt = ST_F16; break;
     default: throw std::runtime_error("unknown precision");
   }
@@ -768,7 +768,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
     const int H2 = osz(H1, 3, 2, 1);                  // 5
     Act c1 = ebuf("enc.c1", H1 * H1, 64);
     Act pool = ebuf("enc.pool", H2 * H2, 64);
-    if (H0 == 20) {
+    if (H0 == 20 || H0 == 16) {
       // one launch: conv 7x7/2 (input channels folded) + GroupNorm + ReLU + max-pool
       const HostParam& w = P_(R + "conv1.weight");
       const int Cw = (int)w.dims[1];
@@ -787,7 +787,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
       const long long ppl = pool.plane;
       enc_ops.push_back([=, this](int b0, int Bn, int, hipStream_t s) {
         note_other();
-        launch_encoder_stem(*lm_slot + (size_t)b0 * 400, wdev, ga, be, op + (size_t)b0 * 25 * 64 * E_, Bn, 1e-5f, pr, ppl, s);
+        launch_encoder_stem(*lm_slot + (size_t)b0 * H0 * H0, H0, wdev, ga, be, op + (size_t)b0 * H2 * H2 * 64 * E_, Bn, 1e-5f, pr, ppl, s);
       });
     } else {
     conv2d(R + "conv1", nullptr, 0, H0, 1, 64, 7, 2, 3, H1, true);

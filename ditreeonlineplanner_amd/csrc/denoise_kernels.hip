@@ -2119,35 +2119,37 @@ void launch_gn1d(void* x, int ld, int Lp, int row_off, int coff, int L, int C, c
 // computes channel c at positions q, q+4, ... (25 of the 100), f32 FMA in (kh, kw) order; group statistics in two
 // passes over registers; the normalised 10 x 10 x 64 map goes through LDS to the 5 x 5 max-pool.
 // Replaces im2col + GEMM + GroupNorm + max-pool launches (and their 26 MB of intermediates per 1024 samples).
-template <int PREC>
-__global__ void __launch_bounds__(256) encoder_stem_kernel(const float* __restrict__ lm /*[B][20][20]*/,
+template <int PREC, int N>
+__global__ void __launch_bounds__(256) encoder_stem_kernel(const float* __restrict__ lm /*[B][N][N]*/,
                                                            const float* __restrict__ W /*[49][64]: tap-major, coalesced per lane*/,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           void* __restrict__ out /*[B][25][64]*/, float eps, long long plane) {
-  __shared__ float s_map[26 * 26];
-  __shared__ float s_act[100 * 64];
+                                                           void* __restrict__ out /*[B][PH*PH][64]*/, float eps, long long plane) {
+  // N = 20 (car): 26 x 26 padded map, 10 x 10 conv outputs, 5 x 5 after the pool;  N = 16 (ant): 22, 8 x 8, 4 x 4
+  constexpr int PD = N + 6, OH = N / 2, NP = OH * OH, J = NP / 4, PH = (OH - 1) / 2 + 1;
+  __shared__ float s_map[PD * PD];
+  __shared__ float s_act[NP * 64];
   __shared__ float s_red[2][4][4];                    // [pass][position quarter][group]
   const int b = blockIdx.x, tid = threadIdx.x;
   const int c = tid & 63, q = tid >> 6, g = c >> 4;
-  for (int i = tid; i < 26 * 26; i += 256) {
-    const int r = i / 26 - 3, cc = i % 26 - 3;
-    s_map[i] = (r >= 0 && r < 20 && cc >= 0 && cc < 20) ? lm[(size_t)b * 400 + r * 20 + cc] : 0.0f;
+  for (int i = tid; i < PD * PD; i += 256) {
+    const int r = i / PD - 3, cc = i % PD - 3;
+    s_map[i] = (r >= 0 && r < N && cc >= 0 && cc < N) ? lm[(size_t)b * (N * N) + r * N + cc] : 0.0f;
   }
   float w[49];
 #pragma unroll
   for (int k = 0; k < 49; ++k) w[k] = W[k * 64 + c];
   __syncthreads();
-  float v[25];
+  float v[J];
   float sum = 0.f;
 #pragma unroll
-  for (int j = 0; j < 25; ++j) {
-    const int p = q + 4 * j, oh = p / 10, ow = p - oh * 10;
-    const float* m0 = s_map + (oh * 2) * 26 + ow * 2;
+  for (int j = 0; j < J; ++j) {
+    const int p = q + 4 * j, oh = p / OH, ow = p - oh * OH;
+    const float* m0 = s_map + (oh * 2) * PD + ow * 2;
     float a = 0.f;
 #pragma unroll
     for (int kh = 0; kh < 7; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 7; ++kw) a = fmaf(w[kh * 7 + kw], m0[kh * 26 + kw], a);
+      for (int kw = 0; kw < 7; ++kw) a = fmaf(w[kh * 7 + kw], m0[kh * PD + kw], a);
     v[j] = a;
     sum += a;
   }
@@ -2155,18 +2157,19 @@ __global__ void __launch_bounds__(256) encoder_stem_kernel(const float* __restri
   sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
   if ((c & 15) == 0) s_red[0][q][g] = sum;
   __syncthreads();
-  const float mean = ((s_red[0][0][g] + s_red[0][1][g]) + (s_red[0][2][g] + s_red[0][3][g])) * (1.0f / 1600.0f);
+  constexpr float inv_n = 1.0f / (float)(NP * 16);
+  const float mean = ((s_red[0][0][g] + s_red[0][1][g]) + (s_red[0][2][g] + s_red[0][3][g])) * inv_n;
   float sq = 0.f;
 #pragma unroll
-  for (int j = 0; j < 25; ++j) { const float d = v[j] - mean; sq = fmaf(d, d, sq); }
+  for (int j = 0; j < J; ++j) { const float d = v[j] - mean; sq = fmaf(d, d, sq); }
   sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4); sq += __shfl_xor(sq, 8);
   if ((c & 15) == 0) s_red[1][q][g] = sq;
   __syncthreads();
-  const float var = ((s_red[1][0][g] + s_red[1][1][g]) + (s_red[1][2][g] + s_red[1][3][g])) * (1.0f / 1600.0f);
+  const float var = ((s_red[1][0][g] + s_red[1][1][g]) + (s_red[1][2][g] + s_red[1][3][g])) * inv_n;
   const float rstd = rsqrtf(var + eps);
   const float ga = gamma[c] * rstd, be = beta[c] - mean * ga;
 #pragma unroll
-  for (int j = 0; j < 25; ++j) {
+  for (int j = 0; j < J; ++j) {
     float y = fmaf(v[j], ga, be);
     y = y > 0.f ? y : 0.f;
     if constexpr (PREC == ST_BF16) y = bf2f(f2bf(y));      // the activation is stored as bf16 before the pool in the layered path
@@ -2174,22 +2177,27 @@ __global__ void __launch_bounds__(256) encoder_stem_kernel(const float* __restri
     s_act[(q + 4 * j) * 64 + c] = y;
   }
   __syncthreads();
-  for (int o = tid; o < 25 * 64; o += 256) {
-    const int oc = o & 63, op = o >> 6, oh = op / 5, ow = op - oh * 5;
+  for (int o = tid; o < PH * PH * 64; o += 256) {
+    const int oc = o & 63, op = o >> 6, oh = op / PH, ow = op - oh * PH;
     float best = -__builtin_huge_valf();
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int ih = oh * 2 + kh - 1, iw = ow * 2 + kw - 1;
-        if (ih >= 0 && ih < 10 && iw >= 0 && iw < 10) best = fmaxf(best, s_act[(ih * 10 + iw) * 64 + oc]);
+        if (ih >= 0 && ih < OH && iw >= 0 && iw < OH) best = fmaxf(best, s_act[(ih * OH + iw) * 64 + oc]);
       }
-    store_elem<PREC>(out, (long long)b * 1600 + o, best, plane);
+    store_elem<PREC>(out, (long long)b * (PH * PH * 64) + o, best, plane);
   }
 }
-void launch_encoder_stem(const float* lm, const float* W, const float* gamma, const float* beta, void* out, int B, float eps,
+void launch_encoder_stem(const float* lm, int n, const float* W, const float* gamma, const float* beta, void* out, int B, float eps,
                          int fmt, long long plane, hipStream_t s) {
-#define CALL(F) hipLaunchKernelGGL(encoder_stem_kernel<F>, dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps, plane)
+  if (n != 20 && n != 16) abort();
+#define CALL(F)                                                                                                                    \
+  do {                                                                                                                             \
+    if (n == 20) hipLaunchKernelGGL((encoder_stem_kernel<F, 20>), dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps, plane);  \
+    else hipLaunchKernelGGL((encoder_stem_kernel<F, 16>), dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps, plane);          \
+  } while (0)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
 }

@@ -68,7 +68,7 @@ def ant_net():
 
 
 # precision -> relative L2 bound on the flow-step output (the L = 8 and L = 4 levels run the unfused GEMM + GroupNorm kernels;
-# the split instantiations run them on the gemm16 tiles with plain stores, the encoder of the 16 x 16 map in f32)
+# the split instantiations run them on the gemm16 tiles with plain stores, the encoder split as well)
 ANT_TOL = {1: 1e-5, 2: 1e-5, 3: 1e-4, 4: 2e-3, 0: 1.6e-2}
 
 
