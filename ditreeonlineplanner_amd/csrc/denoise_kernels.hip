@@ -1669,6 +1669,15 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
                                                wq[q] + wo, 0, 0);
   };
 
+  // split formats: the weight pieces of a step go out in the first two phases of the step BEFORE it (two each) instead of
+  // with the activation pieces behind the barrier: eight requests per wave in one burst fill the address FIFO (see
+  // conv3_halo16x3_kernel); -2 % on these launches
+  auto issue_wq = [&](int kv, int q) {                               // one weight piece of K-step kv
+    int ao, wo;
+    src_off(kv, ao, wo);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (LDS_AS void*)(smem + W_BASE + (kv & 1) * BUF + (w * 4 + q) * 1024), 16,
+                                             (q & 1) ? pbo : pbe, wq[q] + wo, 0, 0);
+  };
   const int a_row = wm * 64 + r4;                                    // + 16 mb
   const int swa = (a_row >> 1) & 7;                                  // (a_row + 16 mb) >> 1 & 7 is the same for every mb
   const int a_off = a_row * 128, b_off = (wn * 128 + r4) * 128;
@@ -1705,14 +1714,36 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
     if constexpr (SPLIT) {
       rdB(1, k, 1, 1);                  // P1: A_hi x W_lo(0); fetch W_lo(1)
       mm16(0, 0, 0);
+      if constexpr (HAS_NEXT) {
+        issue_wq(k + 1, 0); issue_wq(k + 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      } else
+      {
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       rdB(0, k, 0, 0);                  // P2: A_hi x W_lo(1); fetch W_hi(0) and A_lo
       rdA(1, k, 1);
       mm16(0, 1, 1);
+      if constexpr (HAS_NEXT) {
+        issue_wq(k + 1, 2); issue_wq(k + 1, 3);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      } else
+      {
       __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       rdB(1, k, 0, 1);                  // P3: A_hi x W_hi(0); fetch W_hi(1)
       mm16(0, 0, 0);
@@ -1751,7 +1782,7 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
       rdB(0, k + 1, SPLIT ? 1 : 0, 0);
     }
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)      // phase (1,1) + the 8 LDS-DMA pieces of step k+2 into the buffers just released
+    for (int mb = 0; mb < 4; ++mb)      // phase (1,1) + the LDS-DMA pieces of step k+2 into the buffers just released (split: activations only)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         mm(1, 1, 1, mb, (mb & 1) ? 3 - jj : jj);
@@ -1761,7 +1792,7 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
           if (i >= 0 && i < 4)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (LDS_AS void*)(smem + (k & 1) * BUF + (w * 4 + i) * 1024), 16,
                                                      (i & 1) ? pao : pae, aq[i] + ao2, 0, 0);
-          else if (i >= 4 && i < 8)
+          else if (!SPLIT && i >= 4 && i < 8)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (LDS_AS void*)(smem + W_BASE + (k & 1) * BUF + (w * 4 + i - 4) * 1024),
                                                      16, ((i - 4) & 1) ? pbo : pbe, wq[i - 4] + wo2, 0, 0);
         }
@@ -1770,7 +1801,7 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-      if (ISSUE && !(i & 1)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+      if (ISSUE && !(i & 1) && (!SPLIT || i < 8)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -1780,7 +1811,18 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
   issue(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if (nk > 1) issue(1);
+  if (nk > 1) {
+    if constexpr (SPLIT) {             // A(1) only: W(1) goes out in the first phases of step 0
+      int ao, wo;
+      src_off(1, ao, wo);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (LDS_AS void*)(smem + BUF + (w * 4 + q) * 1024), 16, (q & 1) ? pao : pae,
+                                                 aq[q] + ao, 0, 0);
+    } else {
+      issue(1);
+    }
+  }
   rdA(0, 0, 0);
   rdB(0, 0, SPLIT ? 1 : 0, 0);
   for (int k = 0; k < nk - 2; ++k) step(Tt{}, Tt{}, k);
