@@ -119,28 +119,131 @@ def pmc_traffic(kernel, precision="bf16"):
         return {"traffic": None}
 
 
+def launch_ranks(argv, n):
+    """`python bench.py --gpus N` without a torchrun environment: this process -- which never initialises the GPU --
+    starts N fresh rank processes of this same script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one GPU each),
+    forwards rank 0's stdout (the one JSON line), and returns non-zero as soon as any rank does.  Nothing is re-exec'ed
+    and no process that has touched the GPU starts another program."""
+    import socket
+    import subprocess
+    rehearse = os.environ.get("DITREE_REHEARSE_ONE_GPU", "0") == "1"
+    dry = os.environ.get("DITREE_BENCH_DRYRUN", "0") == "1"
+    if not (rehearse or dry):
+        have = torch.cuda.device_count()               # counts devices without creating a HIP context on this image
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DITREE_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        import threading
+
+        def pump():
+            for line in procs[0].stdout:            # the JSON line goes to stdout, library chatter (gloo's banner) to stderr
+                text = line.decode(errors="replace")
+                dst = sys.stdout if text.lstrip().startswith("{") else sys.stderr
+                dst.write(text)
+                dst.flush()
+        th = threading.Thread(target=pump, daemon=True)
+        th.start()
+        alive = set(range(n))
+        while alive and rc == 0:
+            for r in list(alive):
+                code = procs[r].poll()
+                if code is not None:
+                    alive.discard(r)
+                    if code != 0:
+                        rc = code if code > 0 else 1
+                        print(f"bench.py: rank {r} exited with {code}", file=sys.stderr)
+            time.sleep(0.05)
+        th.join(timeout=5.0)
+    finally:
+        for p in procs:                                 # exactly the processes started above
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
+
+
 def _dist_setup(args):
-    """-> (rank, world, local, dist module or None, rehearse)"""
+    """-> (rank, world, local, dist module or None, rehearse).  Ranks come from the torchrun-style environment (set by
+    `torch.distributed.run` or by launch_ranks above)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world != args.gpus and not (world == 1 and args.gpus <= 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # Rehearsal of the N > 1 path on a one-GPU box (tests only, never a measurement): every rank uses device 0 and the
+    # candidate records travel through gloo (RCCL refuses two ranks on one device).
     rehearse = os.environ.get("DITREE_REHEARSE_ONE_GPU", "0") == "1"
     if rehearse:
         local = 0
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    force_dist = world == 1 and os.environ.get("DITREE_FORCE_DIST", "0") == "1"     # RCCL path on a single GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")          # keep RCCL's banner off stdout: rank 0 prints one JSON line
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     return rank, world, local, dist, rehearse
+
+
+def _data(rehearse):
+    return "synthetic" + (" (one-GPU rehearsal of N ranks over gloo: not a measurement)" if rehearse else "")
+
+
+def ranks_seen(dist, rehearse, dev):
+    """How many ranks the collective backend actually connects: an all-reduce (sum) of ones -- RCCL on the GPUs, gloo in
+    the one-GPU rehearsal; 1 without a process group."""
+    if dist is None or not dist.is_initialized():
+        return 1
+    one = torch.ones(1, dtype=torch.int32, device="cpu" if rehearse else dev)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(one.item())
+
+
+def comm_info(dist, rehearse, dev):
+    return {"ranks_seen": ranks_seen(dist, rehearse, dev),
+            "backend": "none" if dist is None or not dist.is_initialized() else ("gloo (one-GPU rehearsal)" if rehearse else "nccl (RCCL)")}
+
+
+def run_dry(args):
+    """DITREE_BENCH_DRYRUN=1 (CPU tests of the launcher): rendezvous over gloo, count the ranks, print one line.  No GPU,
+    no measurement."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    seen = 1
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        one = torch.ones(1, dtype=torch.int32)
+        dist.all_reduce(one)
+        seen = int(one.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if os.environ.get("DITREE_BENCH_DRYRUN_FAIL_RANK", "") == str(rank):
+        raise SystemExit(7)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": seen, "workload": args.workload,
+                          "note": "launcher rehearsal on CPU: not a measurement"}), flush=True)
 
 
 def _timed(step, args, dist, world, dev, rehearse):
@@ -210,6 +313,7 @@ def run_rollout(args):
         it[0] += 1
 
     elapsed = _timed(step, args, dist, world, dev, rehearse)
+    comm = comm_info(dist, rehearse, dev)
     k_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
     if rank == 0:
         st = out["r"][0].cpu().numpy() & 0xFF
@@ -219,7 +323,7 @@ def run_rollout(args):
         res = {"metric": "car rollouts/sec (T=16 bicycle steps + goal + two-ball collision per step, no denoiser)",
                "value": K * world * args.steps / elapsed, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "vs_baseline": None, "dtype": "f64", "data": _data(rehearse),
                "config": {"workload": f"BASELINE config 5 as SURVEY 8(d) defines it: {K} car rollouts x T={T} per GPU on boxes.csv, "
                                       "rollout kernel alone (the reference has no MPPI module and no ant MPPI script)",
                           "rollouts_per_gpu": K, "horizon": T, "parallelism": f"rollouts sharded x{world}, no collective"},
@@ -227,7 +331,7 @@ def run_rollout(args):
                             "traffic": None, "kernel": "car_rollout_kernel", "avg_launch_ms": avg_ms,
                             "algorithmic_bytes_per_launch": alg,
                             "note": "FP64 transcendental-bound in practice (3 sincos + tanh + 9 sqrt/hypot per step): see DESIGN.md"},
-               "outcome": {"ok": int((st == 0).sum()), "goal": int((st == 1).sum()), "collided": int((st == 2).sum())}}
+               "outcome": {"ok": int((st == 0).sum()), "goal": int((st == 1).sum()), "collided": int((st == 2).sum())}, **comm}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -298,19 +402,20 @@ def run_geometry(args):
         ms = e0.elapsed_time(e1) / args.steps
         res_k[name] = {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": alg, "achieved_GBps": alg / (ms * 1e-3) / 1e9,
                        "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    comm = comm_info(dist, rehearse, dev)
     if rank == 0:
         total_ms = sum(v["avg_launch_ms"] for v in res_k.values())
         ro = res_k["car_rollout_kernel (A = 8)"]
         res = {"metric": "geometry kernels of one chunk at the config-4 round size (NN + local map + cond + 8-step rollout + lidar)",
                "value": B / (total_ms * 1e-3), "unit": "candidates/s through the geometry kernels alone", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": total_ms, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "vs_baseline": None, "dtype": "f64", "data": _data(rehearse),
                "config": {"workload": f"geometry kernels alone: {B} candidates, {N}-node tree, boxes.csv; includes per-call tensor "
                                       "allocation of the Python front end (event-timed around the front-end call)"},
                "roofline": {"bound": "hbm", "achieved": ro["achieved_GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": ro["frac_of_hbm_peak"], "traffic": None, "kernel": "car_rollout_kernel (A = 8)",
                             "avg_launch_ms": ro["avg_launch_ms"], "algorithmic_bytes_per_launch": ro["algorithmic_bytes_per_launch"]},
-               "kernels": res_k}
+               "kernels": res_k, **comm}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -375,7 +480,13 @@ def run_lidar_round(args):
             ev[it[0] - args.warmup][1].record()
         it[0] += 1
 
+    if world > 1:
+        eng.exchange_events = []
     elapsed = _timed(step, args, dist, world, dev, rehearse)
+    comm = comm_info(dist, rehearse, dev)
+    if eng.exchange_events:
+        ex = eng.exchange_events[-args.steps:]
+        comm["exchange"] = {"ms_per_round": float(np.mean([a.elapsed_time(b) for a, b in ex])), "bytes_per_rank": Bper * 96}
     if rank == 0:
         avg_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
         alg = Bper * (24 + 181 * 25) + maze.size * 4 + Bper * maze.size          # poses + per-ray outputs + maze + visited bitmap
@@ -383,14 +494,15 @@ def run_lidar_round(args):
         res = {"metric": "candidate tree-expansions/sec (carmaze, H=32, lidar scan per candidate end pose)",
                "value": Bglob * args.steps / elapsed, "unit": "candidate expansions/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+               "scaling": "strong", "vs_baseline": None, "dtype": args.precision, "data": _data(rehearse),
                "config": {"workload": f"BASELINE config 4: carmaze round of {Bglob} candidates (global) + one 181-ray lidar scan per "
                                       f"candidate end pose, boxes.csv, {N0}-node snapshot, seeded random weights",
                           "global_batch": Bglob, "batch_per_gpu": Bper, "parallelism": f"candidates sharded x{world}"},
                "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
                             "traffic": None, "kernel": "lidar_scan_kernel", "avg_launch_ms": avg_ms,
                             "algorithmic_bytes_per_launch": alg, "kernel_time_share": avg_ms * 1e-3 * args.steps / elapsed,
-                            "note": "the round itself is MFMA-bound (see the default workload); this is the lidar kernel's line"}}
+                            "note": "the round itself is MFMA-bound (see the default workload); this is the lidar kernel's line"},
+               **comm}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -450,6 +562,7 @@ def run_ant_denoise(args):
     elapsed = _timed(step, dataclass_replace(args, warmup=0), dist, world, dev, rehearse)
     prof = ctx.profile_read()
     ctx.profile(0)
+    comm = comm_info(dist, rehearse, dev)
     if rank == 0:
         mac = 752_250_880 + 15_749_120
         alg = 2.0 * mac * B * n_calls * args.steps
@@ -459,7 +572,7 @@ def run_ant_denoise(args):
         res = {"metric": "candidate tree-expansions/sec (antmaze, H=48; denoiser + glue only, dynamics blocked on an oracle)",
                "value": B * world * args.steps / elapsed, "unit": "candidate expansions/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": prec, "data": "synthetic",
+               "vs_baseline": None, "dtype": prec, "data": _data(rehearse),
                "config": {"workload": f"BASELINE config 3: cfgs/antmaze.yaml + fm_policy, batch={B} candidates per GPU, H=48 = 24 chunks x "
                                       "[local map 16x16@0.8 s_global 4, ant cond vector (rot6d), encoder + U-Net P=16 D=8 cond 497, flow step]; "
                                       "NO dynamics (MuJoCo: no oracle)", "batch_per_gpu": B, "calls_per_candidate": n_calls},
@@ -467,7 +580,7 @@ def run_ant_denoise(args):
                             "kernel": "all MFMA kernels of the denoiser (L = 8 / 4 levels: plain GEMM + gn1d_short_kernel, unfused; split formats: 3 MFMAs per product)",
                             "per_kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
                             "algorithmic_gflop_per_candidate": 2.0 * mac * n_calls / 1e9,
-                            "note": "events around every MFMA launch inside the timed region (costs a few %)"}}
+                            "note": "events around every MFMA launch inside the timed region (costs a few %)"}, **comm}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -503,6 +616,11 @@ def main():
     args = ap.parse_args()
     args.batch_set = any(a == "--batch" or a.startswith("--batch=") for a in sys.argv[1:])
     args.precision_set = any(a == "--precision" or a.startswith("--precision=") for a in sys.argv[1:])
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # single-command form (`python bench.py --gpus N ...`): start the N ranks from here, before anything touches the GPU
+        raise SystemExit(launch_ranks(sys.argv[1:], args.gpus))
+    if os.environ.get("DITREE_BENCH_DRYRUN", "0") == "1":
+        return run_dry(args)
     if args.workload == "rollout":
         return run_rollout(args)
     if args.workload == "lidar-round":
@@ -512,29 +630,8 @@ def main():
     if args.workload == "geometry":
         return run_geometry(args)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    # Rehearsal of the N > 1 path on a one-GPU box (tests only, never a measurement): every rank uses device 0 and the
-    # candidate records travel through gloo (RCCL refuses two ranks on one device).
-    rehearse = os.environ.get("DITREE_REHEARSE_ONE_GPU", "0") == "1"
-    if rehearse:
-        local = 0
-    torch.cuda.set_device(local)
-    pg = None
-    force_dist = world == 1 and os.environ.get("DITREE_FORCE_DIST", "0") == "1"     # RCCL path on a single GPU
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("NCCL_DEBUG", "WARN")          # keep RCCL's banner off stdout: rank 0 prints one JSON line
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    rank, world, local, dist, rehearse = _dist_setup(args)
+    force_dist = world == 1 and dist is not None
 
     from ditreeonlineplanner_amd import _lib
     from ditreeonlineplanner_amd.engine import CNT_GOAL, CNT_LATCH, CNT_NODES, ExpansionEngine
@@ -557,6 +654,7 @@ def main():
                           capacity=N0 + Btot, rank=rank, world_size=world, emulate_sticky_done=False)
     eng.force_allgather = force_dist
     dev = ctx.device
+    comm = comm_info(dist, rehearse, dev)
     t = eng.tree
     nd = torch.as_tensor(nodes, device=dev)
 
@@ -584,20 +682,13 @@ def main():
         step()
     if not args.no_profile:
         ctx.profile(2)                      # timed region: events around runs of the dominant kernel only
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        et = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
-        dist.all_reduce(et, op=dist.ReduceOp.MAX)
-        elapsed = float(et.item())
+    if world > 1 or force_dist:
+        eng.exchange_events = []            # one event pair per round around pack + all-gather + unpack
+    elapsed = _timed(step, dataclass_replace(args, warmup=0), dist, world, dev, rehearse)
+    exch_ms = None
+    if eng.exchange_events:
+        exch_ms = float(np.mean([a.elapsed_time(b) for a, b in eng.exchange_events]))
+    eng.exchange_events = None
     prof = prof_all = None
     if not args.no_profile:
         prof = ctx.profile_read()
@@ -617,22 +708,7 @@ def main():
     ee = None
     if not args.no_early_exit_line:
         eng.early_exit = 1
-        for _ in range(args.warmup):
-            step()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        e2 = time.perf_counter() - t1
-        if world > 1:
-            et = torch.tensor([e2], device="cpu" if rehearse else dev, dtype=torch.float64)
-            dist.all_reduce(et, op=dist.ReduceOp.MAX)
-            e2 = float(et.item())
+        e2 = _timed(step, args, dist, world, dev, rehearse)
         run = eng.rb.chunks_run[:Btot].float().mean().item()
         ee = {"value": Btot * args.steps / e2, "ms_per_step": 1e3 * e2 / args.steps,
               "mean_denoiser_calls_per_candidate": run,
@@ -644,22 +720,7 @@ def main():
     tp = None
     if not args.no_throughput_line and args.precision != "bf16":
         net.bind(ctx, precision=_lib.PREC_BF16, max_batch=Bper)
-        for _ in range(max(1, args.warmup)):
-            step()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        e3 = time.perf_counter() - t2
-        if world > 1:
-            et = torch.tensor([e3], device="cpu" if rehearse else dev, dtype=torch.float64)
-            dist.all_reduce(et, op=dist.ReduceOp.MAX)
-            e3 = float(et.item())
+        e3 = _timed(step, dataclass_replace(args, warmup=max(1, args.warmup)), dist, world, dev, rehearse)
         tp = {"dtype": "bf16", "value": Btot * args.steps / e3, "ms_per_step": 1e3 * e3 / args.steps,
               "note": "plain bf16 MFMA inputs: throughput mode, NOT within the north-star tolerance"}
         try:
@@ -677,12 +738,17 @@ def main():
             "metric": "candidate tree-expansions/sec (carmaze, H=32)", "value": value,
             "unit": "candidate expansions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic" + (" (one-GPU rehearsal of N ranks over gloo: not a measurement)" if rehearse else ""),
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": args.precision, "data": _data(rehearse),
             "config": {"workload": f"cfgs/carmaze.yaml + fm_policy flow sampler (K=1), batch={Bper} candidates per GPU, "
                                    f"H=32 (4 chunks x 8 steps), boxes.csv 20x20, {N0}-node tree snapshot, seeded random weights",
                        "batch_per_gpu": Bper, "global_batch": Btot, "edge_length": H, "action_horizon": A,
                        "pred_horizon": P, "flow_steps": 1, "tree_nodes": N0, "parallelism": f"candidates sharded x{world}"},
+            **comm,
         }
+        if exch_ms is not None:
+            out["exchange"] = {"ms_per_round": exch_ms, "bytes_per_rank": Bper * 96,
+                               "what": "ditree_round_pack + all-gather of 96-byte candidate records + ditree_round_unpack, "
+                                       "events on the launch stream inside the timed region (rank 0)"}
         if prof:
             # dominant kernel: timed inside the timed region (the kind the library brackets in mode 2)
             name = max(prof, key=lambda k: prof[k]["ms"])
@@ -718,7 +784,7 @@ def main():
             cb["sequential_b1"] = {"value": seq["value"], "unit": seq["unit"], "cores": seq["cores"], "sample": seq["sample"]}
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
-    if world > 1 or force_dist:
+    if dist is not None:
         dist.destroy_process_group()
 
 

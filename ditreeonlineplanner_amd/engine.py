@@ -160,6 +160,15 @@ def allgather_round_fields(fields, per, rank, world, group=None):
 _COALESCE_BROKEN = [False]
 
 
+def default_shard():
+    """(rank, world_size, process_group) of the default torch.distributed group when one is initialised (a script started
+    with `torch.distributed.run -m ditreeonlineplanner_amd.run script.py`), else (0, 1, None)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size(), None
+    return 0, 1, None
+
+
 class ExpansionEngine:
     """Batched RRT expansion on one GPU (optionally one shard of a multi-GPU round)."""
 
@@ -186,6 +195,7 @@ class ExpansionEngine:
         self.norm = np.ascontiguousarray(CAR_NORM if norm is None else norm, dtype=np.float64)
         self.rank, self.world, self.pg = rank, world_size, process_group
         self.force_allgather = False        # run the collective even with one rank (exercises the RCCL path on 1 GPU)
+        self.exchange_events = None         # list -> one (start, end) event pair per round around pack + all-gather + unpack
         self.run_type = int(run_type)
         self.init_main_path = None          # (P, >=2) reference path of an earlier plan (run_type > 0)
         self.tree = DeviceTree(ctx, capacity, self.n_chunks, self.A, track_obstacle_ahead=self.run_type > 0)
@@ -212,6 +222,7 @@ class ExpansionEngine:
         gj = np.floor((self.goal_state[0] + W / 2) / 1.0)
         self.env_goal = np.array([(gj + 0.5) * 1.0 - W / 2, H / 2 - (gi + 0.5) * 1.0])
         self.tree.reset(self.start_state)
+        self.generation = getattr(self, "generation", 0) + 1      # consumers caching per-tree data (node_list) key on it
 
     def update_maze(self, maze):
         self.maze = np.asarray(maze, dtype=np.float32)
@@ -229,6 +240,27 @@ class ExpansionEngine:
         lo = min(self.rank * per, B)
         hi = min(lo + per, B)
         return lo, hi, per
+
+    def agree(self, flag: bool) -> bool:
+        """Rank 0's decision for every rank (the wall-clock budget of a plan is read on rank 0 only: ranks that disagreed
+        about running another round would dead-lock in its collective).  One 4-byte broadcast; identity for one rank."""
+        if self.world <= 1:
+            return bool(flag)
+        import torch.distributed as dist
+        gloo = dist.get_backend(self.pg) == "gloo"
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cpu" if gloo else self.ctx.device)
+        src = 0 if self.pg is None else dist.get_global_rank(self.pg, 0)
+        dist.broadcast(t, src=src, group=self.pg)
+        return bool(int(t.item()))
+
+    def sum_over_ranks(self, value: int) -> int:
+        if self.world <= 1:
+            return int(value)
+        import torch.distributed as dist
+        gloo = dist.get_backend(self.pg) == "gloo"
+        t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if gloo else self.ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        return int(t.item())
 
     # ------------------------------------------------------------------ one round
     def expand_round(self, samples, cond_goal, noise=None, inject_actions=None, accept=True):
@@ -268,7 +300,16 @@ class ExpansionEngine:
             check(self.ctx._h, lib().ditree_expand_round(self.ctx._h, C.byref(self.tree.desc), C.byref(rd),
                                                           C.byref(rp), self.ctx.stream), "expand_round")
         if self.world > 1 or self.force_allgather:
+            ev = None
+            if self.exchange_events is not None:
+                # torch's collective runs on the backend's own stream, but the current stream waits for it (async_op=False):
+                # events on the current stream bracket pack + collective + unpack
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             self._allgather_round(B, per)
+            if ev is not None:
+                ev[1].record()
+                self.exchange_events.append(ev)
         if accept:
             return self.accept(B)
         return None

@@ -7,7 +7,11 @@ Constructor kwargs, ``plan() -> (path f32 (P,6)|None, actions f32 (A,2)|None)``,
   ``early_exit``       (default True) later chunks of collided / finished candidates are skipped, as the
                        reference abandons a collided edge; results are identical either way,
   ``prop_duration``    the reference's per-visit edge-length schedule (RRT.py:26,149-152): in a round the candidates of
-                       one parent are its visits in candidate order.
+                       one parent are its visits in candidate order,
+  ``rank`` / ``world_size`` / ``process_group``   shard every round over the ranks of a torch.distributed group (default:
+                       the initialised default group, i.e. what `torch.distributed.run` set up; one rank otherwise).  All
+                       ranks must draw the same samples and noise -- the reference's scripts seed every RNG with 42
+                       (run_scenarios.py:86-90) -- and all ranks return the same path.
 All of the reference's ``run_type`` values: 0 "Original"; 1 "Original+Ref" (obstacle-ahead flags per node, sampling
 biased to the part of ``init_main_path`` behind the obstacle, furthest-along-path fallback); 2 "OM+Ref" (sample
 positions drawn from the EDT prior); 3 "OM+LB+Ref" (prior log-blended with the start -> goal Gaussian, refreshed at
@@ -21,7 +25,7 @@ import time
 import numpy as np
 import torch
 
-from ..engine import CNT_GOAL, CNT_ITERS, ExpansionEngine
+from ..engine import CNT_GOAL, CNT_ITERS, ExpansionEngine, default_shard
 from .base_planner import BasePlanner, Node
 
 
@@ -47,6 +51,10 @@ class RRT_Planner(BasePlanner):
         self.max_candidates = kwargs.get("max_candidates", None)
         self.capacity = int(kwargs.get("capacity", 65536))
         lm = self.local_map_size if isinstance(self.local_map_size, (int, float)) else self.local_map_size[0]
+        d_rank, d_world, d_pg = default_shard()
+        self.world_size = int(kwargs.get("world_size", d_world))
+        self.rank = int(kwargs.get("rank", d_rank if self.world_size == d_world else 0))
+        self.process_group = kwargs.get("process_group", d_pg)
         self._engine = ExpansionEngine(
             self.ctx, self.maze, self.start_node.state, self.goal_state, edge_length=max(self.prop_duration_schedule),
             prop_duration=self.prop_duration_schedule,
@@ -55,7 +63,8 @@ class RRT_Planner(BasePlanner):
             capacity=self.capacity, k_steps=getattr(sampler, "num_diffusion_iters", 1),
             norm=getattr(sampler, "norm", None) if getattr(sampler, "norm", None) is not None else None,
             emulate_sticky_done=kwargs.get("emulate_sticky_done", True), early_exit=kwargs.get("early_exit", True),
-            run_type=self.run_type, goal_scale=getattr(sampler, "local_map_size", None))
+            run_type=self.run_type, goal_scale=getattr(sampler, "local_map_size", None),
+            rank=self.rank, world_size=self.world_size, process_group=self.process_group)
         self._engine.env_goal = np.asarray(self.env.goal, dtype=np.float64)
         from concurrent.futures import ThreadPoolExecutor
         self._draw_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ditree-draw")
@@ -90,29 +99,39 @@ class RRT_Planner(BasePlanner):
 
     @property
     def node_list(self):
-        """Materialise ``Node`` objects from the device tree (RRT.py:42, base_planner.py:24-34)."""
+        """``Node`` objects of the device tree (RRT.py:42, base_planner.py:24-34).  The tree only grows between two
+        ``reset`` calls, so the list is kept and extended by the rows appended since the last access (one D2H of the new
+        rows + the visit counters), not rebuilt: scripts that poll ``len(planner.node_list)`` pay O(new nodes)."""
         t = self._engine.tree
         n = t.n_nodes_host
-        states = t.state[:n].cpu().numpy()
-        parents = t.parent[:n].cpu().numpy()
-        es, ea = t.edge_states[:n].cpu().numpy(), t.edge_actions[:n].cpu().numpy()
-        ns, na = t.edge_nstates[:n].cpu().numpy(), t.edge_nactions[:n].cpu().numpy()
+        gen = getattr(self._engine, "generation", 0)
+        cache = getattr(self, "_node_cache", None)
+        if cache is None or cache[0] != gen or len(cache[1]) > n:
+            cache = (gen, [])
+        nodes = cache[1]
+        k = len(nodes)
+        if k < n:
+            states = t.state[k:n].cpu().numpy()
+            parents = t.parent[k:n].cpu().numpy()
+            es, ea = t.edge_states[k:n].cpu().numpy(), t.edge_actions[k:n].cpu().numpy()
+            ns, na = t.edge_nstates[k:n].cpu().numpy(), t.edge_nactions[k:n].cpu().numpy()
+            for i in range(k, n):
+                j = i - k
+                if i == 0:
+                    nodes.append(Node(states[0]))
+                else:
+                    nodes.append(Node(states[j], ea[j, : na[j]], es[j, : ns[j]][None], parent=nodes[parents[j]]))
         nv = t.num_visit[:n].cpu().numpy()
-        nodes = []
         for i in range(n):
-            if i == 0:
-                nd = Node(states[0])
-            else:
-                nd = Node(states[i], ea[i, : na[i]], es[i, : ns[i]][None], parent=nodes[parents[i]])
-            nd.num_visit = int(nv[i])
-            nodes.append(nd)
+            nodes[i].num_visit = int(nv[i])
+        self._node_cache = cache
         return nodes
 
     def nearest_node(self, sample):
         t = self._engine.tree
         q = torch.as_tensor(np.ascontiguousarray(np.asarray(sample, dtype=np.float64)[:, :2]), device=self.ctx.device)
         idx = self.ctx.nn_argmin(q, t.xy, n_nodes=t.n_nodes_host)
-        return self.node_list[int(idx[0].item())]
+        return self.node_list[int(idx[0].item())]          # cached list: O(nodes appended since the last call)
 
     def check_obstacle_ahead(self, state):
         """RRT.py:61-81 through the device op (the accept kernel evaluates the same function per new node)."""
@@ -158,11 +177,34 @@ class RRT_Planner(BasePlanner):
         return s, c
 
     # ------------------------------------------------------------------ plan
+    def _host_actions(self, first, B):
+        """A sampler that is not the network (no ``ensure_bound``): the action sequences of a round come from the host
+        and by-pass the denoiser (``inject_actions``).  Protocols, in this order:
+          ``sampler.sample_round(first_candidate, B, n_chunks, pred_horizon) -> (B, n_chunks, P, 2)``  (tapes: a pure
+          function of the global candidate index, so results do not depend on the round size), or a plain callable in
+          the reference's shape, ``sampler(obs, prev_actions, goal, local_map)``, called once per (candidate, chunk) in
+          candidate-major order with ``obs = prev_actions = local_map = None`` (it cannot see the state: the rounds are
+          expanded on the device) and returning (1, P, 2), (P, 2), or one action (1, 2) / (2,) held for the chunk
+          -- the shape policies/uniform_policy.py:7-8 returns."""
+        eng = self._engine
+        if hasattr(self.sampler, "sample_round"):
+            a = np.asarray(self.sampler.sample_round(first, B, eng.n_chunks, eng.P), dtype=np.float64)
+        else:
+            a = np.empty((B, eng.n_chunks, eng.P, 2))
+            for b in range(B):
+                for j in range(eng.n_chunks):
+                    v = np.asarray(self.sampler(None, None, self.goal_state[:2], None), dtype=np.float64)
+                    a[b, j] = v.reshape(-1, 2) if v.size == eng.P * 2 else v.reshape(1, 2)
+        if a.shape != (B, eng.n_chunks, eng.P, 2):
+            raise ValueError(f"sampler returned actions of shape {a.shape}, need {(B, eng.n_chunks, eng.P, 2)}")
+        return torch.as_tensor(np.ascontiguousarray(a), device=self.ctx.device)
+
     def plan(self):
         eng = self._engine
         dev = self.ctx.device
-        if hasattr(self.sampler, "ensure_bound"):
-            self.sampler.ensure_bound(self.batch)
+        network = hasattr(self.sampler, "ensure_bound")
+        if network:
+            self.sampler.ensure_bound(eng.shard(self.batch)[2])
         start_time = time.time()
         drawn = 0
         goal = None
@@ -174,17 +216,19 @@ class RRT_Planner(BasePlanner):
             remain = self.extract_path_after_obstacle()
         eng.init_main_path = self.init_main_path if self.run_type > 0 else None
         # The samples of round r+1 are drawn (host RNGs, reference call order) by a helper thread while round r runs
-        # on the GPU: the C-ABI call releases the GIL, and the draws do not depend on the tree.  With batch = 1
-        # nothing is drawn ahead, so the RNG streams advance exactly as in the reference.
+        # on the GPU: the C-ABI call releases the GIL, and the draws do not depend on the tree.  The global RNG states
+        # are snapshotted before every draw-ahead and restored when the pre-drawn round turns out not to be used (goal
+        # reached, budget over), so `random` / `np.random` leave plan() exactly where a run without draw-ahead leaves
+        # them.  With batch = 1 nothing is drawn ahead.
         def round_size(already):
             return self.batch if self.max_candidates is None else min(self.batch, self.max_candidates - already)
 
         ahead = self.batch > 1
         pool = self._draw_pool if ahead else None
-        pending = None
+        pending = rng_before = None
         cnt = None
         steps_dev = torch.zeros((), dtype=torch.int64, device=dev)     # env steps = two-ball collision tests (cc_calls)
-        while (time.time() - start_time) < self.time_budget:
+        while eng.agree((time.time() - start_time) < self.time_budget):
             if self.max_candidates is not None and drawn >= self.max_candidates:
                 break
             B = round_size(drawn)
@@ -192,19 +236,28 @@ class RRT_Planner(BasePlanner):
             pending = None
             nxt = drawn + B
             if ahead and (self.max_candidates is None or nxt < self.max_candidates):
+                rng_before = (random.getstate(), np.random.get_state())
                 pending = pool.submit(self.draw_round, round_size(nxt), remain)
-            noise = torch.randn((B, eng.n_chunks, eng.P, 2), device=dev)
-            cnt = eng.expand_round(torch.as_tensor(s, device=dev), torch.as_tensor(c, device=dev), noise=noise)
+            if network:
+                # every rank draws the noise of the WHOLE round (same generator state everywhere) and uses its slice
+                noise, acts = torch.randn((B, eng.n_chunks, eng.P, 2), device=dev), None
+            else:
+                noise, acts = None, self._host_actions(drawn, B)
+            cnt = eng.expand_round(torch.as_tensor(s, device=dev), torch.as_tensor(c, device=dev), noise=noise,
+                                   inject_actions=acts)
             drawn += B
-            steps_dev += eng.rb.chunk_steps[:B].sum()
+            lo, hi, _ = eng.shard(B)
+            steps_dev += eng.rb.chunk_steps[lo:hi].sum()
             goal = int(cnt[CNT_GOAL]) if int(cnt[CNT_GOAL]) >= 0 else None
             if goal is not None:
                 break
         if pending is not None:
             pending.result()                     # never leave the helper running on the global RNGs
+            random.setstate(rng_before[0])       # the pre-drawn round is dropped: un-draw it
+            np.random.set_state(rng_before[1])
         iters = int(cnt[CNT_ITERS]) if cnt is not None else 0
         from ..common import map_utils as _mu
-        _mu.add_cc_calls(int(steps_dev.item()))            # the counter the drivers read (run_scenarios.py:338,343)
+        _mu.add_cc_calls(eng.sum_over_ranks(int(steps_dev.item())))   # the counter the drivers read (run_scenarios.py:338,343)
         self.env.prob_map = orig_prob_map
         if goal is not None:
             self.env.done = True

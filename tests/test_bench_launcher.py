@@ -1,0 +1,67 @@
+"""`python bench.py --gpus N` must start by itself: the parent spawns N fresh rank processes, relays rank 0's
+one JSON line and fails when a rank fails.  CPU: the launcher + rendezvous in dry-run mode (no GPU, no measurement).
+GPU (-m gpu): the real workloads with 2 ranks rehearsed on one GPU over gloo (DITREE_REHEARSE_ONE_GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.util import REPO
+
+BENCH = os.path.join(REPO, "bench.py")
+
+
+def _run(args, env_extra, timeout=600):
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, BENCH, *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    return p.returncode, lines, p.stderr.decode()
+
+
+@pytest.mark.parametrize("workload", ["expand", "rollout", "lidar-round"])
+def test_launcher_spawns_ranks_and_relays_one_line(workload):
+    rc, lines, err = _run(["--gpus", "2", "--steps", "1", "--workload", workload], {"DITREE_BENCH_DRYRUN": "1"})
+    assert rc == 0, err
+    assert len(lines) == 1, lines                      # exactly one line on stdout, and it is JSON
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["dry_run"] is True
+
+
+def test_launcher_fails_when_a_rank_fails():
+    rc, lines, err = _run(["--gpus", "2", "--steps", "1"], {"DITREE_BENCH_DRYRUN": "1", "DITREE_BENCH_DRYRUN_FAIL_RANK": "1"})
+    assert rc == 7 and "rank 1 exited with 7" in err
+
+
+def test_launcher_refuses_more_ranks_than_gpus():
+    # this container has no GPU: the parent must say so (rc 2) instead of starting ranks that cannot get a device
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has >= 2 GPUs")
+    rc, lines, err = _run(["--gpus", "2", "--steps", "1"], {})
+    assert rc == 2 and not lines and "GPU(s) visible" in err
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    rc, lines, err = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "256", "--no-cpu-baseline",
+                           "--no-throughput-line", "--no-early-exit-line"], {"DITREE_REHEARSE_ONE_GPU": "1"}, timeout=900)
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["global_batch"] == 512
+    assert out["exchange"]["ms_per_round"] > 0 and out["exchange"]["bytes_per_rank"] == 256 * 96
+    assert "rehearsal" in out["data"] and out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_lidar_round_two_ranks_rehearsed_on_one_gpu():
+    rc, lines, err = _run(["--workload", "lidar-round", "--global-batch", "8192", "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                          {"DITREE_REHEARSE_ONE_GPU": "1"}, timeout=900)
+    assert rc == 0, err[-3000:]
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["batch_per_gpu"] == 4096
+    assert out["scaling"] == "strong" and out["exchange"]["ms_per_round"] > 0

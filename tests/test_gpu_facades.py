@@ -222,3 +222,118 @@ def test_planner_counts_collision_checks_and_defaults_to_f32_class_precision(net
     assert map_utils.is_colliding_car(np.array([-100.0, 0.0, 0.0]), maze) is True          # out of the map
     lm = map_utils.create_local_map(maze, start[0], start[1], start[2], 20, 0.2, 1.0, (10.0, 10.0))
     assert lm.shape == (1, 20, 20) and np.array_equal(lm, G.create_local_map(maze, start[:1], start[1:2], start[2:3], 20, 0.2, 1.0, (10.0, 10.0)))
+
+
+class TapeSampler:
+    """A non-network sampler in the facade's host-sampler protocol (RRT_Planner._host_actions): the golden action tape."""
+
+    def __init__(self, seed):
+        from oracle.tapes import ActionTape
+        self.tape = ActionTape(seed)
+
+    def sample_round(self, first, B, n_chunks, P):
+        return np.stack([self.tape.actions(np.arange(first, first + B), j) for j in range(n_chunks)], axis=1)
+
+
+def _tape_planner(tag, batch, **kw):
+    import random
+    from ditreeonlineplanner_amd.car_env import CarEnv
+    from ditreeonlineplanner_amd.planners.RRT import RRT_Planner
+    g = golden("traces")
+    maze = load_maze(str(g[f"trace_{tag}_maze_name"]))
+    sr, sc, sdeg, gr, gc = [int(v) for v in g[f"trace_{tag}_scenario"]]
+    start = np.array([*G.cell_rowcol_to_xy([sr, sc], maze), np.deg2rad(float(sdeg)), 0, 0, 0])
+    goal = np.array([*G.cell_rowcol_to_xy([gr, gc], maze), 0, 0, 0, 0])
+    env = CarEnv(maze_map=maze, collision_checking=False)
+    random.seed(42)
+    np.random.seed(42)
+    pl = RRT_Planner(start, goal, env_id="carmaze", environment=env, sampler=TapeSampler(int(g[f"trace_{tag}_tape_seed"])),
+                     action_horizon=8, local_map_size=20, local_map_scale=0.2, global_map_scale=1.0,
+                     goal_conditioning_bias=0.85, prop_duration=[64], time_budget=600, batch=batch,
+                     max_candidates=int(g[f"trace_{tag}_budget"]), **kw)
+    pl.reset()
+    return g, pl
+
+
+@pytest.mark.parametrize("tag", ["race", "boxes"])
+def test_planner_with_a_non_network_sampler_reproduces_the_reference_trace(tag):
+    """BASELINE config 1 (plumbing: carmaze + a non-network sampler, Race Track row 1) THROUGH the reference-shaped surface:
+    RRT_Planner(batch=1) fed by the golden action tape builds the reference planner's tree (parents bit-exact, states 1e-9)
+    and returns its path."""
+    g, pl = _tape_planner(tag, 1)
+    path, actions = pl.plan()
+    snap = pl._engine.tree_snapshot()
+    assert np.array_equal(snap["parents"], g[f"trace_{tag}_parents"])
+    assert np.abs(snap["states"] - g[f"trace_{tag}_states"]).max() < 1e-9
+    assert pl.results["iterations"] == int(g[f"trace_{tag}_iterations"])
+    assert (pl._engine.goal_node is not None) == bool(g[f"trace_{tag}_reached"])
+    assert path.shape == g[f"trace_{tag}_path"].shape and np.abs(path - g[f"trace_{tag}_path"]).max() < 1e-5
+    assert np.array_equal(actions, g[f"trace_{tag}_actions"])
+    assert len(pl.node_list) == len(snap["parents"]) and pl.node_list is pl.node_list        # cached between accesses
+
+
+def test_draw_ahead_leaves_the_global_rngs_where_a_sequential_run_leaves_them():
+    """Rounds are pre-drawn on a helper thread from `random` / `np.random`; a pre-drawn round that is never expanded (goal
+    reached, budget over) must be un-drawn: after plan() both generators are where batch = 1 (no draw-ahead) leaves them
+    after the same number of candidates."""
+    import random
+    g, pl1 = _tape_planner("boxes", 1)
+    pl1.max_candidates = 96
+    pl1.plan()
+    state1 = (random.getstate(), np.random.get_state()[1].copy(), np.random.get_state()[2])
+    g, pl2 = _tape_planner("boxes", 32)
+    pl2.max_candidates = None                 # wall-clock budget only: a round IS drawn ahead when the loop ends
+    pl2.time_budget = 1e9
+    orig = pl2._engine.expand_round
+    calls = [0]
+
+    def three_rounds(*a, **k):
+        calls[0] += 1
+        cnt = orig(*a, **k)
+        if calls[0] == 3:
+            pl2.time_budget = -1.0            # the budget ends after round 3, with round 4 already drawn
+        return cnt
+    pl2._engine.expand_round = three_rounds
+    pl2.plan()
+    assert calls[0] == 3
+    state2 = (random.getstate(), np.random.get_state()[1].copy(), np.random.get_state()[2])
+    assert state1[0] == state2[0] and np.array_equal(state1[1], state2[1]) and state1[2] == state2[2]
+
+
+def test_uniform_sampler_through_the_planner():
+    """policies/uniform_policy.UniformSampler(env.action_space) as the planner's sampler (the wiring the reference left
+    commented out, run_scenarios.py:275-283): rounds run on injected uniform actions, the tree does not depend on the
+    round size, and the one-action-per-call form of the reference class works as well."""
+    import random
+    from ditreeonlineplanner_amd.car_env import CarEnv
+    from ditreeonlineplanner_amd.planners.RRT import RRT_Planner
+    from ditreeonlineplanner_amd.policies.uniform_policy import UniformSampler
+    maze = load_maze("boxes")
+    env = CarEnv(maze_map=maze, collision_checking=False)
+    start = np.array([*G.cell_rowcol_to_xy([17, 2], maze), np.deg2rad(45.0), 0, 0, 0])
+    goal = np.array([*G.cell_rowcol_to_xy([2, 17], maze), 0, 0, 0, 0])
+    trees = []
+    for batch in (1, 16):
+        random.seed(42)
+        np.random.seed(42)
+        pl = RRT_Planner(start, goal, env_id="carmaze", environment=env, sampler=UniformSampler(env.action_space, seed=3),
+                         action_horizon=8, local_map_size=20, local_map_scale=0.2, global_map_scale=1.0, prop_duration=[64],
+                         time_budget=600, batch=batch, max_candidates=16, early_exit=bool(batch > 1))
+        pl.reset()
+        pl.plan()
+        trees.append(pl._engine.tree_snapshot())
+        assert pl.results["iterations"] > 0
+    # 16 rounds of 1 vs one round of 16: same samples and actions; a round expands against the tree of its start, so the
+    # trees agree up to the first candidate whose nearest node was appended inside the round -- the root's children do
+    assert trees[0]["states"][1].tolist() == trees[1]["states"][1].tolist()
+
+    class OneAction:                                          # the reference class's call shape: (1, action_dim)
+        def __call__(self, *a, **k):
+            return np.array([[4.0, 0.1]])
+    pl = RRT_Planner(start, goal, env_id="carmaze", environment=env, sampler=OneAction(), action_horizon=8, local_map_size=20,
+                     local_map_scale=0.2, global_map_scale=1.0, prop_duration=[16], time_budget=600, batch=4, max_candidates=4)
+    pl.reset()
+    pl.plan()
+    a = pl._engine.rb.actions[:4].cpu().numpy()
+    ran = pl._engine.rb.chunk_steps[:4].cpu().numpy()
+    assert (a[ran > 0][:, 0] == np.array([4.0, 0.1])).all()

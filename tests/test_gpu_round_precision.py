@@ -1,13 +1,25 @@
-"""Round-level deviation of every denoiser instantiation (include/ditree.h DITREE_PREC_*) against the oracle round.
+"""Round-level deviation of every denoiser instantiation (include/ditree.h DITREE_PREC_*) against the oracle round
+(reference: planners/RRT.py:131-217 -- sample, nearest node, chunks of [local map, sampler, 8 env steps], accept).
 
-One BASELINE-config-2-shaped round -- 256 candidates against a 1024-node tree snapshot on boxes.csv, H = 32
-(4 chunks x [local map, conditioning, denoiser, 8 bicycle steps with goal / collision tests]) -- on the engine and
-on the CPU oracle (numpy f64 geometry + torch-CPU fp32 denoiser), same seeded weights, samples and noise.  Recorded per
-instantiation (gpurun_out/round_precision.json, committed as profiles/r02_round_precision.json):
-  max |d state| over the trajectories of candidates whose status agrees, status flips, nearest-node parent mismatches,
-  tree parent-index mismatches after accept.
-The north star asks for flags / parents exact and states within 1e-5: the f32 MFMA and the f16x3 instantiations are held
-to that; bf16x3 / f16 / bf16 are the throughput modes and are held to their measured deviation (x2)."""
+Two workloads, both on the engine and on the CPU oracle (numpy f64 geometry + torch-CPU fp32 denoiser) with the same seeded
+weights, samples and noise:
+
+  "config2"  ONE round at BASELINE config 2's size: 1024 candidates against a 1024-node tree snapshot on boxes.csv, H = 32
+             (4 chunks x [local map, conditioning, denoiser, 8 bicycle steps with goal / collision tests]), then accept.
+  "growing"  THREE rounds of 256 candidates on a growing tree: the nodes accepted in round r are nearest-node candidates and
+             parents of round r + 1, so a wrong accept shows up in every later parent index.
+
+The tree snapshot keeps every node further than 3.5 cells from the goal (no candidate can end the plan inside the round:
+round 2's test accepted 4 of 256 candidates because the lowest goal-reaching index ends the round), so more than half of the
+candidates survive all four chunks and are appended: "tree parents bit-exact" rests on hundreds of nodes, not four.
+
+Per instantiation and workload (gpurun_out/round_precision.json, committed as profiles/r03_round_precision.json):
+  flips = candidates whose final status, number of chunks run, or executed steps of ANY chunk differ from the oracle's
+  (a candidate that collides one step earlier is a flip, not a silent drop-out); n_agree = candidates - flips;
+  max / median / 99th percentile of |d state| over the trajectories of the agreeing candidates; nearest-node mismatches;
+  tree parent-index mismatches after every accept.
+The north star asks for flags / parents exact and states within 1e-5: the f32 MFMA and the f16x3 instantiations are held to
+that with n_agree == candidates; bf16x3 / f16 / bf16 are the throughput modes and are held to their measured deviation."""
 import json
 import os
 
@@ -21,25 +33,20 @@ from oracle import sampler as OS
 from tests.util import REPO, load_maze
 
 pytestmark = pytest.mark.gpu
-B, H, A, P, N0 = 256, 32, 8, 64, 1024
-# precision -> (max |d state| allowed, status flips allowed among the 256 candidates, share of candidates that must stay
-# within 1e-5, 99th percentile of |d state| allowed).  Measured (profiles/r02_round_precision.json): f32 2.2e-6, f16x3 2.6e-6
-# at the maximum, no flips.  The pipeline is discontinuous (a state difference of 1e-5 can move a pose across a cell boundary
-# of the local map, and the map conditions the next chunk's denoiser call), so below f32-class accuracy the MAXIMUM over the
-# candidates is set by one or two outliers and moves by an order of magnitude with any change of summation order (bf16x3:
-# 1.1e-3 on one build, 2.4e-5 on the next; f16: 3.2e-3, then 2.8e-2) while median and 99th percentile stay put (bf16x3
-# 2.7e-6 / 2.3e-5, f16 2.3e-4 / 3e-3, bf16 1.2e-3 / 2.4e-2).  The throughput modes are therefore held to three times their
-# 99th percentile, and their maximum only to a sanity bound.
-BOUND = {1: (1e-5, 0, 1.0, 1e-5), 2: (1e-5, 0, 1.0, 1e-5), 3: (5e-3, 0, 0.7, 1e-4), 4: (1e-1, 2, 0.0, 1e-2),
-         0: (2e-1, 4, 0.0, 7.5e-2)}
+H, A, P, N0 = 32, 8, 64, 1024
+WORKLOADS = {"config2": (1024, 1), "growing": (256, 3)}          # name -> (candidates per round, rounds)
+# precision -> (max |d state| allowed, share of flipped candidates allowed, share of candidates that must stay within 1e-5,
+# 99th percentile of |d state| allowed).  The pipeline is discontinuous (a state difference of 1e-5 can move a pose across a
+# cell boundary of the local map, and the map conditions the next chunk's denoiser call), so below f32-class accuracy the
+# MAXIMUM over the candidates is set by one or two outliers and moves by an order of magnitude with any change of summation
+# order while median and 99th percentile stay put: the throughput modes are held to a multiple of their 99th percentile and
+# their maximum only to a sanity bound.
+BOUND = {1: (1e-5, 0.0, 1.0, 1e-5), 2: (1e-5, 0.0, 1.0, 1e-5), 3: (5e-3, 0.0, 0.7, 1e-4), 4: (1e-1, 0.01, 0.0, 1e-2),
+         0: (2e-1, 0.02, 0.0, 7.5e-2)}
 NAMES = {0: "bf16", 1: "f32", 2: "f16x3", 3: "bf16x3", 4: "f16"}
 
 
-@pytest.fixture(scope="module")
-def setup():
-    import bench
-    maze = load_maze("boxes")
-    nodes, goal, samples, cond, noise = bench.synth_inputs(maze, B, seed=20260105)
+def make_net():
     torch.manual_seed(0)
     onet = OD.init_noise_pred_net().eval()
     g = torch.Generator().manual_seed(1)
@@ -47,22 +54,48 @@ def setup():
         for n, p in onet.named_parameters():
             if p.dim() == 1:
                 p.add_(0.2 * torch.randn(p.shape, generator=g))
-    nz = noise.numpy()
+    return onet
 
-    def sampler(cand_idx, chunk, state, prev_action, has_prev, cond_goal, local_map):
-        cv = OS.car_cond_vector(state, prev_action, has_prev, cond_goal)
-        x1 = OS.flow_sample(onet, nz[cand_idx, chunk], OS.scale_local_map(local_map), cv, k_steps=1)
-        return OS.unnormalize_actions(x1)
 
-    pl = ORRT.OraclePlanner(maze, nodes[0], goal, sampler, edge_length=H, action_horizon=A, emulate_sticky_done=False)
-    t = pl.tree
-    for i in range(1, len(nodes)):
-        t.states.append(nodes[i].copy()); t.parents.append(max(i - 1, 0)); t.last_action.append(np.zeros(2))
-        t.has_prev.append(True); t.num_visit.append(0); t.edge_states.append(None); t.edge_actions.append(None)
+def make_inputs(n_cand, seed):
+    import bench
+    maze = load_maze("boxes")
+    nodes, goal, samples, cond, noise = bench.synth_inputs(maze, n_cand, seed=seed)
+    # no node within 3.5 cells of the goal: 32 steps at v <= 4 move a car at most 2.6 cells, nobody reaches the goal radius
+    near = np.hypot(nodes[:, 0] - goal[0], nodes[:, 1] - goal[1]) < 3.5
+    far = np.nonzero(~near)[0]
+    nodes[near] = nodes[far[np.arange(int(near.sum())) % len(far)]]
+    return maze, nodes, goal, samples, cond, noise
+
+
+@pytest.fixture(scope="module")
+def cases():
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    ref = pl.expand_round(samples, cond)
-    ref["tree_parents"] = np.array(t.parents)
-    return dict(maze=maze, nodes=nodes, goal=goal, samples=samples, cond=cond, noise=noise, onet=onet, ref=ref)
+    onet = make_net()
+    out = {}
+    for name, (Bc, rounds) in WORKLOADS.items():
+        maze, nodes, goal, samples, cond, noise = make_inputs(Bc * rounds, 20260105 + rounds)
+        nz = noise.numpy()
+
+        def sampler(cand_idx, chunk, state, prev_action, has_prev, cond_goal, local_map):
+            cv = OS.car_cond_vector(state, prev_action, has_prev, cond_goal)
+            x1 = OS.flow_sample(onet, nz[cand_idx, chunk], OS.scale_local_map(local_map), cv, k_steps=1)
+            return OS.unnormalize_actions(x1)
+
+        pl = ORRT.OraclePlanner(maze, nodes[0], goal, sampler, edge_length=H, action_horizon=A, emulate_sticky_done=False)
+        t = pl.tree
+        for i in range(1, len(nodes)):
+            t.states.append(nodes[i].copy()); t.parents.append(max(i - 1, 0)); t.last_action.append(np.zeros(2))
+            t.has_prev.append(True); t.num_visit.append(0); t.edge_states.append(None); t.edge_actions.append(None)
+        refs = []
+        for r in range(rounds):
+            ref = pl.expand_round(samples[r * Bc:(r + 1) * Bc], cond[r * Bc:(r + 1) * Bc])
+            assert pl.goal_node is None                       # the workload is built so that no round ends early
+            ref["tree_parents"] = np.array(t.parents)
+            ref["tree_states"] = np.array(t.states)
+            refs.append(ref)
+        out[name] = dict(maze=maze, nodes=nodes, goal=goal, samples=samples, cond=cond, noise=noise, refs=refs, B=Bc, rounds=rounds)
+    return onet, out
 
 
 @pytest.fixture(scope="module")
@@ -73,14 +106,15 @@ def ctx():
     c.close()
 
 
-def run_engine(ctx, st, prec):
+def run_engine(ctx, onet, st, prec):
     from ditreeonlineplanner_amd.engine import CNT_GOAL, CNT_LATCH, CNT_NODES, ExpansionEngine
     from ditreeonlineplanner_amd.model import NoisePredNet
+    Bc, rounds = st["B"], st["rounds"]
     net = NoisePredNet()
-    net.load_state_dict(st["onet"].state_dict())
-    net.bind(ctx, precision=prec, max_batch=B)
+    net.load_state_dict(onet.state_dict())
+    net.bind(ctx, precision=prec, max_batch=Bc)
     eng = ExpansionEngine(ctx, st["maze"], st["nodes"][0], st["goal"], edge_length=H, action_horizon=A, pred_horizon=P,
-                          batch=B, capacity=N0 + B, emulate_sticky_done=False)
+                          batch=Bc, capacity=N0 + Bc * rounds, emulate_sticky_done=False)
     dev = ctx.device
     t = eng.tree
     nd = torch.as_tensor(st["nodes"], device=dev)
@@ -93,59 +127,99 @@ def run_engine(ctx, st, prec):
     t.counters[CNT_GOAL] = -1
     t.counters[CNT_LATCH] = 0
     t.n_nodes_host = N0
-    eng.expand_round(torch.as_tensor(st["samples"], device=dev), torch.as_tensor(st["cond"], device=dev),
-                     noise=st["noise"].to(dev))
-    rb = eng.rb
-    return dict(status=rb.status[:B].cpu().numpy() & 0xFF, parent=rb.parent[:B].cpu().numpy(),
-                end_state=rb.end_state[:B].cpu().numpy(), states=rb.states[:B].cpu().numpy(),
-                chunks_run=rb.chunks_run[:B].cpu().numpy(), tree_parents=eng.tree_snapshot()["parents"])
+    got = []
+    for r in range(rounds):
+        sl = slice(r * Bc, (r + 1) * Bc)
+        eng.expand_round(torch.as_tensor(st["samples"][sl], device=dev), torch.as_tensor(st["cond"][sl], device=dev),
+                         noise=st["noise"][sl].to(dev))
+        rb = eng.rb
+        snap = eng.tree_snapshot()
+        got.append(dict(status=rb.status[:Bc].cpu().numpy() & 0xFF, parent=rb.parent[:Bc].cpu().numpy(),
+                        end_state=rb.end_state[:Bc].cpu().numpy(), states=rb.states[:Bc].cpu().numpy(),
+                        chunks_run=rb.chunks_run[:Bc].cpu().numpy(), chunk_steps=rb.chunk_steps[:Bc].cpu().numpy(),
+                        tree_parents=snap["parents"], tree_states=snap["states"]))
+    return got
 
 
 def deviation(got, ref):
-    same = got["status"] == ref["status"]
-    flips = int((~same).sum())
-    agree = same & (got["chunks_run"] == ref["chunks_run"])
-    d_end = float(np.abs(got["end_state"][agree] - ref["end_state"][agree]).max()) if agree.any() else 0.0
-    d_traj = 0.0
+    """One round.  A candidate AGREES when its final status, its number of chunks and the executed steps of every chunk equal
+    the oracle's; everything else is a flip (and its states are not compared: they belong to different trajectories)."""
+    Bc = len(ref["status"])
+    same_status = got["status"] == ref["status"]
+    same_chunks = got["chunks_run"] == ref["chunks_run"]
+    same_steps = (got["chunk_steps"] == ref["chunk_steps"]).all(axis=1)
+    agree = same_status & same_chunks & same_steps
     per_cand = []
     for b in np.nonzero(agree)[0]:
-        n = int(ref["chunks_run"][b])
-        live = ref["chunk_steps"][b, :n]
-        db = 0.0
-        for j in range(n):
-            k = int(live[j]) + 1
+        db = float(np.abs(got["end_state"][b] - ref["end_state"][b]).max())
+        for j in range(int(ref["chunks_run"][b])):
+            k = int(ref["chunk_steps"][b, j]) + 1
             db = max(db, float(np.abs(got["states"][b, j, :k] - ref["states"][b, j, :k]).max()))
         per_cand.append(db)
-        d_traj = max(d_traj, db)
     per_cand = np.array(per_cand) if per_cand else np.zeros(1)
     n = min(len(got["tree_parents"]), len(ref["tree_parents"]))
     tree_mis = int((got["tree_parents"][:n] != ref["tree_parents"][:n]).sum()) + abs(len(got["tree_parents"]) - len(ref["tree_parents"]))
-    return dict(status_flips=flips, nn_parent_mismatches=int((got["parent"] != ref["parent"]).sum()),
-                max_abs_end_state=d_end, max_abs_trajectory_state=d_traj, tree_parent_mismatches=tree_mis,
-                median_abs_trajectory_state=float(np.median(per_cand)), p99_abs_trajectory_state=float(np.quantile(per_cand, 0.99)),
-                share_within_1e5=float((per_cand < 1e-5).mean()),
-                candidates=B, accepted_nodes_ref=int(len(ref["tree_parents"]) - N0))
+    d_nodes = float(np.abs(got["tree_states"][:n] - ref["tree_states"][:n]).max())
+    return dict(candidates=Bc, n_agree=int(agree.sum()), flips=int((~agree).sum()), status_flips=int((~same_status).sum()),
+                chunks_run_mismatches=int((~same_chunks).sum()), chunk_steps_mismatches=int((~same_steps).sum()),
+                nn_parent_mismatches=int((got["parent"] != ref["parent"]).sum()),
+                max_abs_trajectory_state=float(per_cand.max()), median_abs_trajectory_state=float(np.median(per_cand)),
+                p99_abs_trajectory_state=float(np.quantile(per_cand, 0.99)), share_within_1e5=float((per_cand < 1e-5).mean()),
+                tree_parent_mismatches=tree_mis, max_abs_tree_node_state=d_nodes,
+                accepted_nodes_ref=int(len(ref["tree_parents"]) - N0), survived_all_chunks_ref=int((ref["status"] == 0).sum()),
+                collided_ref=int((ref["status"] == 2).sum()))
 
 
-@pytest.mark.parametrize("prec", [1, 2, 3, 4, 0])
-def test_round_deviation(ctx, setup, prec):
-    got = run_engine(ctx, setup, prec)
-    dev = deviation(got, setup["ref"])
+def _record(prec, name, devs):
     out = os.path.join(REPO, "gpurun_out", "round_precision.json")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     allr = {}
     if os.path.exists(out):
         with open(out) as f:
             allr = json.load(f)
-    allr[NAMES[prec]] = dev
+    allr.setdefault(NAMES[prec], {})[name] = devs
     with open(out, "w") as f:
         json.dump(allr, f, indent=1)
-    print(NAMES[prec], dev)
-    tol, flips, share, p99 = BOUND[prec]
-    assert dev["nn_parent_mismatches"] == 0                      # nearest node never depends on the denoiser
-    assert dev["status_flips"] <= flips, dev
-    assert max(dev["max_abs_end_state"], dev["max_abs_trajectory_state"]) < tol, dev
-    assert dev["share_within_1e5"] >= share, dev
-    assert dev["p99_abs_trajectory_state"] < p99, dev
-    if flips == 0:
-        assert dev["tree_parent_mismatches"] == 0, dev
+
+
+@pytest.mark.parametrize("name", ["config2", "growing"])
+def test_workload_has_a_thick_accept(cases, name):
+    """The evidence has to rest on many appended nodes: >= 30 % of every round's candidates are accepted by the oracle."""
+    _, out = cases
+    st = out[name]
+    grown = N0
+    for ref in st["refs"]:
+        acc = len(ref["tree_parents"]) - grown
+        grown = len(ref["tree_parents"])
+        assert acc >= 0.3 * st["B"], (name, acc)
+        assert (ref["status"] == 2).sum() >= 0.1 * st["B"]         # and collisions are exercised too
+    if name == "growing":      # later rounds really hang nodes under nodes of earlier rounds
+        assert (st["refs"][-1]["parent"] >= N0).sum() > 10
+
+
+@pytest.mark.parametrize("name", ["config2", "growing"])
+@pytest.mark.parametrize("prec", [1, 2, 3, 4, 0])
+def test_round_deviation(ctx, cases, prec, name):
+    onet, out = cases
+    st = out[name]
+    got = run_engine(ctx, onet, st, prec)
+    devs = [deviation(g, r) for g, r in zip(got, st["refs"])]
+    _record(prec, name, devs)
+    print(NAMES[prec], name, devs)
+    tol, flip_share, share, p99 = BOUND[prec]
+    f32_class = prec in (1, 2)
+    for r, dev in enumerate(devs):
+        assert dev["nn_parent_mismatches"] == 0 or r > 0, dev          # round 0: the nearest node never depends on the denoiser
+        if f32_class:
+            # flags, chunk counts and the colliding / goal step of EVERY candidate, parents of every appended node: exact
+            assert dev["n_agree"] == dev["candidates"] and dev["flips"] == 0, dev
+            assert dev["nn_parent_mismatches"] == 0 and dev["tree_parent_mismatches"] == 0, dev
+            assert dev["max_abs_tree_node_state"] < 1e-5, dev
+        else:
+            assert dev["flips"] <= flip_share * dev["candidates"], dev
+            if r == 0 and dev["flips"] == 0:
+                assert dev["tree_parent_mismatches"] == 0, dev
+        if r == 0 or f32_class:            # after a flip the trees differ: later rounds of a throughput mode are informational
+            assert dev["max_abs_trajectory_state"] < tol, dev
+            assert dev["share_within_1e5"] >= share, dev
+            assert dev["p99_abs_trajectory_state"] < p99, dev

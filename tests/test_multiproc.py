@@ -166,3 +166,56 @@ def test_native_rccl_allgather_single_rank():
     assert lib().ditree_comm_init(ctx._h, 0, 1, uid) != 0        # a second communicator on the same ctx is refused
     check(ctx._h, lib().ditree_comm_destroy(ctx._h), "comm_destroy")
     ctx.close()
+
+
+def _gpu_planner_worker(rank, world, port, out_path):
+    """The drop-in surface sharded: RRT_Planner picks rank / world up from the initialised process group (what
+    `torch.distributed.run -m ditreeonlineplanner_amd.run script.py` sets up); every rank seeds like the reference's scripts."""
+    import random
+    sys.path.insert(0, REPO)
+    _init(rank, world, port)
+    from ditreeonlineplanner_amd.car_env import CarEnv
+    from ditreeonlineplanner_amd.planners.RRT import RRT_Planner
+    from ditreeonlineplanner_amd.policies.fm_policy import DiffusionSampler
+    from ditreeonlineplanner_amd.train_diffusion_policy import init_noise_pred_net
+    from ditreeonlineplanner_amd.common import map_utils
+    torch.manual_seed(0)
+    net = init_noise_pred_net(input_dim=2, action_dim=2, obs_dim=3, obs_history=1, action_history=1, goal_conditioned=True,
+                              goal_dim=2, local_map_conditioned=True, local_map_encoder="resnet", local_map_embedding_dim=400,
+                              local_map_size=20, down_dims=[512, 1024, 2048])
+    with torch.no_grad():                     # damp the action head: more edges survive, the tree gets deep enough for a path
+        for k, v in net.state_dict().items():
+            if k.startswith("unet.final_conv.1"):
+                v.mul_(0.05)
+    smp = DiffusionSampler(net, None, "carmaze", policy="flow_matching", pred_horizon=64, action_dim=2, prediction_type="actions",
+                           obs_history=1, action_history=1, goal_conditioned=True, num_diffusion_iters=1, local_map_size=20).eval()
+    maze = load_maze("boxes")
+    env = CarEnv(maze_map=maze, collision_checking=False)
+    start = np.array([*env.cell_rowcol_to_xy(np.array([17, 2])), np.deg2rad(45.0), 0.0, 0.0, 0.0])
+    goal = np.array([*env.cell_rowcol_to_xy(np.array([2, 17])), 0, 0, 0, 0.0])
+    random.seed(42); np.random.seed(42); torch.manual_seed(42)                      # run_scenarios.py:86-90
+    pl = RRT_Planner(start, goal, env_id="carmaze", environment=env, sampler=smp, action_horizon=8, local_map_size=20,
+                     local_map_scale=0.2, global_map_scale=1.0, goal_conditioning_bias=0.85, prop_duration=[32],
+                     time_budget=600, batch=48, max_candidates=144)
+    assert (pl.rank, pl.world_size) == (rank, world)
+    map_utils.cc_calls = 0
+    pl.reset()
+    path, actions = pl.plan()
+    snap = pl._engine.tree_snapshot()
+    np.savez(out_path.format(rank=rank), parents=snap["parents"], states=snap["states"], path=path, actions=actions,
+             cc=map_utils.cc_calls, iters=pl.results["iterations"])
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_rrt_planner_returns_the_single_rank_path(tmp_path):
+    out = str(tmp_path / "p{w}_r{rank}.npz")
+    mp.spawn(_gpu_planner_worker, args=(1, 29631, out.replace("{w}", "1")), nprocs=1, join=True)
+    mp.spawn(_gpu_planner_worker, args=(2, 29632, out.replace("{w}", "2")), nprocs=2, join=True)
+    a = np.load(out.replace("{w}", "1").format(rank=0))
+    assert len(a["parents"]) > 8 and a["path"].shape[0] > 8
+    for r in range(2):
+        b = np.load(out.replace("{w}", "2").format(rank=r))
+        assert np.array_equal(a["parents"], b["parents"]) and np.array_equal(a["states"], b["states"])
+        assert np.array_equal(a["path"], b["path"]) and np.array_equal(a["actions"], b["actions"])      # bit for bit
+        assert int(a["cc"]) == int(b["cc"]) and int(a["iters"]) == int(b["iters"])
