@@ -55,12 +55,19 @@ class RoundParams(C.Structure):
                 ("chunk_budget", C.c_void_p)]
 
 
+class MppiParams(C.Structure):
+    _fields_ = [("T", C.c_int32), ("K", C.c_int32), ("lam", C.c_double), ("sigma", C.c_double * 2),
+                ("w_track", C.c_double), ("w_progress", C.c_double), ("w_collision", C.c_double), ("w_goal", C.c_double),
+                ("seed", C.c_uint64), ("window_back", C.c_int32), ("window_fwd", C.c_int32), ("lanes", C.c_int32)]
+
+
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 _pd, _pf = C.POINTER(C.c_double), C.POINTER(C.c_float)
 
 # name -> (restype, argtypes); must list every symbol include/ditree.h declares
 SIGNATURES = {
     "ditree_version": (_i32, []),
+    "ditree_build_id": (C.c_char_p, []),
     "ditree_ctx_create": (_i32, [_i32, C.POINTER(_vp)]),
     "ditree_ctx_destroy": (None, [_vp]),
     "ditree_last_error": (C.c_char_p, [_vp]),
@@ -83,11 +90,13 @@ SIGNATURES = {
     "ditree_comm_init": (_i32, [_vp, _i32, _i32, _vp]),
     "ditree_allgather_nodes": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "ditree_comm_destroy": (_i32, [_vp]),
+    "ditree_mppi_step": (_i32, [_vp, C.POINTER(MppiParams), _vp, _vp, _vp, _i32, _pd, _vp, C.c_uint64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ditree_load_weights": (_i32, [_vp, _vp, _i64, C.c_char_p, _vp]),
     "ditree_denoise_reserve": (_i32, [_vp, _i32, _i32]),
     "ditree_denoise": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _pf, _pf, _pd, _vp, _vp, _vp]),
     "ditree_denoise_eval": (_i32, [_vp, _vp, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp]),
     "ditree_denoise_dims": (_i32, [_vp, C.POINTER(_i32)]),
+    "ditree_denoise_status": (_i32, [_vp, C.POINTER(_i32), C.c_char_p, _i64, _i32, _vp]),
     "ditree_profile": (_i32, [_vp, _i32]),
     "ditree_profile_read": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ditree_denoise_debug_read": (_i32, [_vp, C.c_char_p, _i32, _vp, _i64, C.POINTER(_i32), _vp]),
@@ -109,6 +118,12 @@ def lib():
         raise DitreeLibraryError(
             f"{LIB_PATH} is missing: build it with `python -m ditreeonlineplanner_amd.build` "
             "(hipcc, gfx950).  There is no CPU fallback for the expansion path.")
+    # a library built from other sources than the ones next to it (a stale .so that travelled with a snapshot) is refused
+    from . import build as _build
+    have, want = _build.library_id(LIB_PATH), _build.source_id()
+    if have != want and os.environ.get("DITREE_ALLOW_STALE_LIB", "0") != "1":
+        raise DitreeLibraryError(f"{LIB_PATH} is stale: built from sources {have}, the sources here are {want}; "
+                                 "run `python -m ditreeonlineplanner_amd.build`")
     try:
         h = C.CDLL(LIB_PATH)
     except OSError as e:
@@ -122,6 +137,10 @@ def lib():
         fn.argtypes = args
     _LIB = h
     return h
+
+
+def build_id() -> str:
+    return lib().ditree_build_id().decode()
 
 
 def check(ctx_handle, rc: int, what: str = ""):

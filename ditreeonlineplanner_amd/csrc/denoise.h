@@ -56,17 +56,20 @@ struct ConvGemmParams {
   // contiguous range of K-steps and writes its partial f32 tile to Out + y * slab_stride elements
   int splitk;
   long long slab_stride;
+  // f16 range guard: device flag word of this layer (set to 1 by any thread that stores a value beyond +-65504; null = off).
+  // Only the f16 instantiations look at it.
+  int* sat;
 };
 
 void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s);
 bool conv2d_small_eligible(int fmt);                    // implicit Conv2d layers run on the 64 x 64-tile kernel
 int conv_gemm_kind(const ConvGemmParams& p, int fmt);   // 0 halo kernel, 1 gemm16 / generic, 2 implicit Conv2d
 bool conv_gemm_supported(const ConvGemmParams& p, int fmt);   // split formats: only shapes of the halo / gemm16 tiles
-void launch_prep_sample(const float* x, void* A0, int B, int P, int D, int fmt, long long plane, hipStream_t s);
+void launch_prep_sample(const float* x, void* A0, int B, int P, int D, int fmt, long long plane, hipStream_t s, int* sat = nullptr);
 void launch_time_embed(float t, const float* W1, const float* b1, const float* W2, const float* b2, float* out,
                        hipStream_t s);
 void launch_prep_cond(const float* temb, const float* map_emb, int E, int E_ld, const float* cond, int G, void* out, int B,
-                      int Kpad, int fmt, long long plane, hipStream_t s);
+                      int Kpad, int fmt, long long plane, hipStream_t s, int* sat = nullptr);
 void launch_final_proj_flow(const void* Y, int C, int Lp, long long plane, const float* W, const float* bias, int D, float* x,
                             float dt, const double* act_norm /*[mu[D], sigma[D]]*/, double* actions, int B, int P, int fmt,
                             hipStream_t s, int raw = 0);
@@ -76,14 +79,14 @@ struct TapList {          // live (kh, kw) taps of a Conv2d on a small map
 };
 void launch_gn1d(void* x, int ld, int Lp, int row_off, int coff, int L, int C, const float* gamma, const float* beta, float eps,
                  int mode, const float* film, int film_ld, int film_off, const void* res, int ldres, int res_Lp, int res_off,
-                 int B, int fmt, long long x_plane, long long res_plane, hipStream_t s);
+                 int B, int fmt, long long x_plane, long long res_plane, hipStream_t s, int* sat = nullptr);
 void launch_encoder_stem(const float* lm, int n, const float* W, const float* gamma, const float* beta, void* out, int B, float eps,
-                         int fmt, long long plane, hipStream_t s);
+                         int fmt, long long plane, hipStream_t s, int* sat = nullptr);
 void launch_im2col2d(const void* in, bool src_f32, void* out, int B, int H, int W, int C, const TapList& taps, int stride,
                      int pad, int OH, int OW, int Kpad, int fmt, hipStream_t s);
 void launch_gn2d(const float* in, int nslab, long long slab_stride, const float* gamma, const float* beta, const void* res,
                  int relu, void* out, int B, int HW, int C, float eps, int fmt, long long res_plane, long long out_plane,
-                 hipStream_t s);
+                 hipStream_t s, int* sat = nullptr);
 void launch_maxpool2d(const void* in, void* out, int B, int H, int W, int C, int OH, int OW, int fmt, hipStream_t s);
 void launch_avgpool2d(const void* in, void* out, int B, int HW, int C, int fmt, long long in_plane, long long out_plane,
                       hipStream_t s);

@@ -94,6 +94,20 @@ struct DenoiserState {
   Act final_h;                   // input of the final 1x1 projection
   const float* lm_ptr = nullptr; // caller's scaled local map of the current call
   void* zero_row = nullptr;      // 256 zero bytes: source of out-of-map taps in implicit Conv2d
+  // f16 range guard (denoise_kernels.hip sat_*): one device flag word per layer that stores f16 activations; a kernel ORs 1
+  // into its layer's word when it is handed a value beyond +-65504.  Sticky until ditree_denoise_status reads and clears.
+  static constexpr int SAT_SLOTS = 256;
+  int* sat_flags = nullptr;
+  int *sat_cond = nullptr, *sat_sample = nullptr;      // slots of the two input-preparation kernels
+  std::vector<std::string> sat_names;
+  int* sat_slot(const std::string& layer, int fmt) {
+    if (fmt_st(fmt) != ST_F16 || sat_flags == nullptr) return nullptr;
+    for (size_t i = 0; i < sat_names.size(); ++i)
+      if (sat_names[i] == layer) return sat_flags + i;
+    if ((int)sat_names.size() >= SAT_SLOTS) return sat_flags + SAT_SLOTS - 1;
+    sat_names.push_back(layer);
+    return sat_flags + sat_names.size() - 1;
+  }
   int last_splitk[4] = {1, 1, 1, 1};       // split-K layout of the conv output the next GroupNorm op reads, per region
   long long last_slab[4] = {0, 0, 0, 0};
   // optional per-launch timing of the dominant kernel (hipEvents on the launch stream)
@@ -119,6 +133,11 @@ struct DenoiserState {
   std::vector<ProfRec> prof_pairs;                           // (start event, end event, kind, flops) per launch
   void note_other() { close_run(); prof_chain = false; }     // call BEFORE enqueueing the other kernel
   void run_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
+    // shape contract of the tiles (split formats exist on the halo / gemm16 / small-Conv2d tiles only): an error, not an abort
+    if (!conv_gemm_supported(p, fmt))
+      throw std::runtime_error("denoiser layer of shape M " + std::to_string(p.M) + " x N " + std::to_string(p.N) + " x K " +
+                               std::to_string(p.taps) + "*" + std::to_string(p.Cin) + " (L " + std::to_string(p.L) +
+                               ") fits no tile of this precision");
     if (!prof_on) { launch_conv_gemm(p, fmt, s); return; }
     if (prof_used + 2 > prof_ev.size()) {
       const size_t old = prof_ev.size();
@@ -202,6 +221,8 @@ struct DenoiserState {
     enc_ops.clear();
     unet_ops.clear();
     film_op = nullptr;
+    sat_flags = sat_cond = sat_sample = nullptr;
+    sat_names.clear();
     prec = -1;
     Bmax = 0;
     temb_t = -1.0f;
@@ -317,6 +338,7 @@ struct DenoiserState {
     ConvGemmParams p{};
     p.A = aptr(in); p.lda = in.ld; p.in_Lp = in.Lp(); p.in_stride = 1; p.in_off = 0; p.taps = 3; p.Cin = Cin;
     set_w(p, wp); set_in(p, in); set_out(p, out);
+    p.sat = sat_slot(wname, ufmt);
     p.Out = (void*)aptr(out); p.ldc = out.ld; p.out_Lp = out.Lp(); p.out_stride = 1; p.out_off = 1; p.out_coff = 0;
     p.L = in.L; p.N = Cout; p.bias = vec(wname + ".bias"); p.mode = mode; p.eps = 1e-5f;
     if (mode >= MODE_GN_MISH) {
@@ -346,12 +368,13 @@ struct DenoiserState {
       void* xo = (void*)out.p;
       const int ld = out.ld, oLp = out.Lp(), ocoff = out.coff;
       const long long xpl = out.plane, rpl = p.res_plane;
+      int* gsat = p.sat;                 // the normalisation pass reports under the layer's name as well
       ops.push_back([=, this](int, int Bp, hipStream_t s) mutable {
         q.M = Bp * L;
         run_gemm(q, uf, s);
         note_other();
         launch_gn1d(xo, ld, oLp, 1, ocoff, L, Cout, ga, be, 1e-5f, mode, film_p, film_ld_, film_off_, resp, ldres, res_Lp,
-                    res_off, Bp, uf, xpl, rpl, s);
+                    res_off, Bp, uf, xpl, rpl, s, gsat);
       });
       return;
     }
@@ -371,6 +394,7 @@ struct DenoiserState {
     ConvGemmParams p{};
     p.A = aptr(in); p.lda = in.ld; p.in_Lp = in.Lp(); p.in_stride = 1; p.in_off = 1; p.taps = 1; p.Cin = Cin;
     set_w(p, wp); set_in(p, in); set_out(p, out);
+    p.sat = sat_slot(wname, ufmt);
     p.Out = (void*)aptr(out); p.ldc = out.ld; p.out_Lp = out.Lp(); p.out_stride = 1; p.out_off = 1;
     p.L = in.L; p.N = Cout; p.bias = vec(wname + ".bias"); p.mode = MODE_BIAS;
     const int L = in.L, uf = ufmt;
@@ -389,6 +413,7 @@ struct DenoiserState {
     ConvGemmParams p{};
     p.A = aptr(in); p.lda = in.ld; p.in_Lp = in.Lp(); p.in_stride = 2; p.in_off = 0; p.taps = 3; p.Cin = Cin;
     set_w(p, wp); set_in(p, in); set_out(p, out);
+    p.sat = sat_slot(wname, ufmt);
     p.Out = (void*)aptr(out); p.ldc = out.ld; p.out_Lp = out.Lp(); p.out_stride = 1; p.out_off = 1;
     p.L = out.L; p.N = Cout; p.bias = vec(wname + ".bias"); p.mode = MODE_BIAS;
     const int L = out.L, uf = ufmt;
@@ -412,6 +437,7 @@ struct DenoiserState {
       ConvGemmParams p{};
       p.A = aptr(in); p.lda = in.ld; p.in_Lp = in.Lp(); p.in_stride = 1; p.in_off = par; p.taps = 2; p.Cin = Cin;
       set_w(p, wp); set_in(p, in); set_out(p, out);
+      p.sat = sat_slot(wname, ufmt);
       p.Out = (void*)aptr(out); p.ldc = out.ld; p.out_Lp = out.Lp(); p.out_stride = 2; p.out_off = 1 + par;
       p.L = in.L; p.N = Cout; p.bias = vec(wname + ".bias"); p.mode = MODE_BIAS;
       const int L = in.L, uf = ufmt;
@@ -453,6 +479,9 @@ void DenoiserState::build(int prec_, int Bmax_) {
     case DITREE_PREC_F16: ufmt = fmt_make(ST_F16, false); efmt = ST_F16; break;
     default: throw std::runtime_error("unknown precision");
   }
+  sat_flags = (int*)dalloc(SAT_SLOTS * sizeof(int));
+  sat_cond = sat_slot("cond_encoder input: Mish(time | map embedding | observation)", ufmt);
+  sat_sample = sat_slot("sample (the noisy action sequence)", ufmt);
   const int C0 = dims[0], C1 = dims[1], C2 = dims[2];
   const int L0 = P, L1 = P / 2, L2 = P / 4;
   if (P % 16 != 0 || P < 16 || P > 256 || (256 % P) != 0) throw std::runtime_error("pred_horizon must be 16, 32, 64, 128 or 256");
@@ -539,6 +568,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
     ConvGemmParams p{};
     p.A = a0.p; p.lda = 64; p.in_Lp = L0; p.in_stride = 1; p.in_off = 0; p.taps = 1; p.Cin = 64;
     set_w(p, wp); set_in(p, a0); set_out(p, h);
+    p.sat = sat_slot(pre + ".blocks.0.block.0", ufmt);
     p.Out = h.p; p.ldc = h.ld; p.out_Lp = h.Lp(); p.out_stride = 1; p.out_off = 1;
     p.L = L0; p.N = C0; p.bias = vec(pre + ".blocks.0.block.0.bias"); p.mode = MODE_GN_MISH_FILM; p.eps = 1e-5f;
     p.gamma = vec(pre + ".blocks.0.block.1.weight"); p.beta = vec(pre + ".blocks.0.block.1.bias"); p.group_ch = C0 / 8;
@@ -555,6 +585,7 @@ void DenoiserState::build(int prec_, int Bmax_) {
     ConvGemmParams q{};
     q.A = a0.p; q.lda = 64; q.in_Lp = L0; q.in_stride = 1; q.in_off = 0; q.taps = 1; q.Cin = 64;
     set_w(q, wrp); set_in(q, a0); set_out(q, res);
+    q.sat = sat_slot(pre + ".residual_conv", ufmt);
     q.Out = res.p; q.ldc = res.ld; q.out_Lp = res.Lp(); q.out_stride = 1; q.out_off = 1;
     q.L = L0; q.N = C0; q.bias = vec(pre + ".residual_conv.bias"); q.mode = MODE_BIAS;
     const int uf = ufmt;
@@ -755,11 +786,12 @@ void DenoiserState::build(int prec_, int Bmax_) {
         if (pp == 0 || (HW + pp - 1) / pp > 7)
           throw std::runtime_error("encoder GroupNorm: unsupported map (" + std::to_string(HW) + " pixels x " + std::to_string(C) + " channels)");
       }
+      int* gsat = sat_slot(gname, efmt);
       enc_ops.push_back([=, this](int b0, int Bn, int reg, hipStream_t s) {
         note_other();
         const size_t off = (size_t)b0 * HW * C * E_;
         launch_gn2d(gout + (size_t)reg * goutreg, last_splitk[reg], last_slab[reg], ga, be, rp ? rp + off : nullptr,
-                    relu ? 1 : 0, op + off, Bn, HW, C, 1e-5f, pr, rpl, opl, s);
+                    relu ? 1 : 0, op + off, Bn, HW, C, 1e-5f, pr, rpl, opl, s, gsat);
       });
     };
     const int H0 = lm;
@@ -785,9 +817,10 @@ void DenoiserState::build(int prec_, int Bmax_) {
       char* op = (char*)pool.p;
       const float** lm_slot = &lm_ptr;
       const long long ppl = pool.plane;
+      int* ssat = sat_slot(R + "conv1", efmt);
       enc_ops.push_back([=, this](int b0, int Bn, int, hipStream_t s) {
         note_other();
-        launch_encoder_stem(*lm_slot + (size_t)b0 * H0 * H0, H0, wdev, ga, be, op + (size_t)b0 * H2 * H2 * 64 * E_, Bn, 1e-5f, pr, ppl, s);
+        launch_encoder_stem(*lm_slot + (size_t)b0 * H0 * H0, H0, wdev, ga, be, op + (size_t)b0 * H2 * H2 * 64 * E_, Bn, 1e-5f, pr, ppl, s, ssat);
       });
     } else {
     conv2d(R + "conv1", nullptr, 0, H0, 1, 64, 7, 2, 3, H1, true);
@@ -869,6 +902,20 @@ void DenoiserState::build(int prec_, int Bmax_) {
     }
   }
   if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("sync after build failed");
+  // Validation pass: every op of the plan once, on the zeroed workspace, for the smallest batch unit.  Any layer whose shape
+  // fits no kernel (a future kernel_size / n_groups / embedding width) throws HERE, i.e. ditree_denoise_reserve returns an
+  // error -- not the first denoise call, and never an abort of the host process.
+  {
+    std::vector<float> zeros((size_t)bgran * lm * lm, 0.0f);
+    float* lm_dev = (float*)dalloc(zeros.size() * 4);
+    lm_ptr = lm_dev;
+    for (auto& op : enc_ops) op(0, bgran, 0, nullptr);
+    film_op(bgran, bgran, nullptr);
+    for (auto& op : unet_ops) op(bgran, bgran, nullptr);
+    lm_ptr = nullptr;
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) throw std::runtime_error("validation pass of the denoiser plan failed");
+    if (hipMemset(sat_flags, 0, SAT_SLOTS * sizeof(int)) != hipSuccess) throw std::runtime_error("hipMemset failed");
+  }
 }
 
 // ------------------------------------------------------------------------------------- glue
@@ -956,6 +1003,7 @@ static int denoise_core(ditree_ctx* ctx, const float* noise, int64_t noise_strid
                                     hipMemcpyDeviceToDevice, s));
   }
   st->lm_ptr = local_map;
+  try {
   if (!reuse_encoder) {
     // encoder: up to ENC_SUBS sub-batches on separate streams (fork/join with events on `s`)
     // measured on MI355X (B = 1024): 4 concurrent sub-batches cost more in extra launches than the
@@ -993,16 +1041,21 @@ static int denoise_core(ditree_ctx* ctx, const float* noise, int64_t noise_strid
       st->temb_t = K == 1 ? t : -1.0f;                                  // several steps share one buffer: recompute
     }
     st->note_other();
-    launch_prep_cond(st->temb, st->map_emb, st->E, st->E_ld, cond, st->G, st->condA, B, st->condK, uf, st->cond_plane, s);
+    launch_prep_cond(st->temb, st->map_emb, st->E, st->E_ld, cond, st->G, st->condA, B, st->condK, uf, st->cond_plane, s,
+                     st->sat_cond);
     st->film_op(B, Bp, s);
     st->note_other();
-    launch_prep_sample(st->x_cur, st->named["a0"].p, Bp, st->P, st->D, uf, st->named["a0"].plane, s);
+    launch_prep_sample(st->x_cur, st->named["a0"].p, Bp, st->P, st->D, uf, st->named["a0"].plane, s,
+                       st->sat_sample);
     for (auto& op : st->unet_ops) op(B, Bp, s);
     const bool last = (k == K - 1);
     st->note_other();
     launch_final_proj_flow(st->final_h.p, st->final_h.C, st->final_h.Lp(), st->final_h.plane, st->dev_f["unet.final_conv.1.weight"],
                            st->dev_f["unet.final_conv.1.bias"], st->D, st->x_cur, dt[k], act_norm,
                            (last && actions) ? actions : nullptr, B, st->P, uf, s, raw);
+  }
+  } catch (const std::exception& e) {
+    return set_err(ctx, DITREE_E_ARG, std::string("denoise: ") + e.what());
   }
   if (x_out) HIP_TRY(ctx, hipMemcpyAsync(x_out, st->x_cur, (size_t)B * st->P * st->D * 4, hipMemcpyDeviceToDevice, s));
   HIP_TRY(ctx, hipGetLastError());
@@ -1107,6 +1160,34 @@ int32_t ditree_denoise_dims(ditree_ctx* ctx, int32_t* dims5) {
   DenoiserState* st = ctx->dn;
   if (!st || !st->loaded || !dims5) return set_err(ctx, DITREE_E_STATE, "denoise_dims: weights not loaded");
   dims5[0] = st->P; dims5[1] = st->D; dims5[2] = st->lm; dims5[3] = st->G; dims5[4] = st->E;
+  return DITREE_OK;
+}
+
+int32_t ditree_denoise_status(ditree_ctx* ctx, int32_t* n_saturated, char* names, int64_t names_cap, int32_t clear,
+                              void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  DenoiserState* st = ctx->dn;
+  if (!n_saturated || (names_cap > 0 && !names)) return set_err(ctx, DITREE_E_ARG, "denoise_status: bad argument");
+  *n_saturated = 0;
+  if (names_cap > 0) names[0] = '\0';
+  if (!st || st->prec < 0 || st->sat_flags == nullptr || st->sat_names.empty()) return DITREE_OK;   // nothing can saturate
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<int> host(st->sat_names.size());
+  HIP_TRY(ctx, hipMemcpyAsync(host.data(), st->sat_flags, host.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  std::string text;
+  for (size_t i = 0; i < host.size(); ++i)
+    if (host[i] != 0) {
+      ++*n_saturated;
+      if (!text.empty()) text += "\n";
+      text += st->sat_names[i];
+    }
+  if (names_cap > 0) {
+    const size_t n = std::min((size_t)names_cap - 1, text.size());
+    std::memcpy(names, text.data(), n);
+    names[n] = '\0';
+  }
+  if (clear && *n_saturated) HIP_TRY(ctx, hipMemsetAsync(st->sat_flags, 0, host.size() * sizeof(int), s));
   return DITREE_OK;
 }
 

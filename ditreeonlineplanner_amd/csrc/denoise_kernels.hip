@@ -26,6 +26,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <stdexcept>
+
 #include "denoise.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -55,7 +57,30 @@ __device__ __forceinline__ unsigned short f2h(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 __device__ __forceinline__ float h2f(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
-
+// f16 range guard.  The f16 instantiations saturate at +-65504 silently (v_med3 above / in the epilogues); so that a
+// checkpoint whose activations leave the f16 range is REPORTED instead of returning wrong actions with rc 0, every thread
+// that converts values to f16 keeps the largest magnitude it was handed (one v_max3_f32 with |.| source modifiers per two
+// values; a NaN drops out of the maximum, an infinity does not) and ORs 1 into the launch's flag word when it exceeds the
+// range.  The flag of each layer is read by ditree_denoise_status (denoise_host.hip).
+__device__ __forceinline__ void sat_see2(float& m, float a, float b) {
+  m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(a)), __builtin_fabsf(b));
+}
+__device__ __forceinline__ void sat_see(float& m, float a) { m = __builtin_fmaxf(m, __builtin_fabsf(a)); }
+__device__ __forceinline__ void sat_flush(int* flag, float m) {
+  if (flag != nullptr && m > 65504.0f) atomicOr(flag, 1);
+}
+// The MFMA epilogues have no VGPR to spare for a running maximum (256 of 256 in use: carrying one spilled 70 registers,
+// and so did carrying the wave's compare mask): there the maximum of a ROW is formed in a transient register, compared once,
+// and the flag is written right away behind a wave-uniform branch that is never taken in a healthy network.
+__device__ __forceinline__ void sat_check_row(int* flag, const float (&v)[8]) {
+  float t = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fabsf(v[2]));
+  t = __builtin_fmaxf(__builtin_fmaxf(t, __builtin_fabsf(v[3])), __builtin_fabsf(v[4]));
+  t = __builtin_fmaxf(__builtin_fmaxf(t, __builtin_fabsf(v[5])), __builtin_fabsf(v[6]));
+  t = __builtin_fmaxf(t, __builtin_fabsf(v[7]));
+  if (__builtin_amdgcn_ballot_w64(t > 65504.0f) != 0ull) {
+    if (flag != nullptr && t > 65504.0f) atomicOr(flag, 1);
+  }
+}
 // 16-bit element types of the MFMA operands.  ET 0: bf16 (8 significand bits, f32 range), ET 1: f16 (11 bits, +-65504).
 // SPLIT instantiations carry every operand as two 16-bit planes hi + lo (lo = rnd(x - hi)) and form a product from
 // three MFMAs hi*hi + hi*lo + lo*hi with f32 accumulation: 16 (bf16) / 22 (f16) significand bits per operand at a
@@ -160,6 +185,7 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
                                               long long out_extra_bytes = 0) {
 
   constexpr int ET = PREC == 2 ? 1 : 0;
+  float satm = 0.0f;                                          // f16 range guard (sat_see2)
   const int c_l = wn * 128 + 4 * r5;                          // lane's 4 consecutive channels in the tile
   const int n0 = tn * 256 + c_l;
   const bool n_ok = n0 < p.N;
@@ -343,12 +369,14 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
           *(f32x4_t*)((char*)p.Out + out_extra_bytes + oidx * 4) = o;
         } else {
           short4_t o;
+          if constexpr (ET == 1) { sat_see2(satm, v[0], v[1]); sat_see2(satm, v[2], v[3]); }
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = (short)f2e<ET>(v[j]);
           *(short4_t*)((char*)p.Out + out_extra_bytes + oidx * 2) = o;
         }
       }
     }
+    if constexpr (ET == 1) sat_flush(p.sat, satm);
     return;
   }
 
@@ -370,12 +398,14 @@ __device__ __forceinline__ void gemm_epilogue(const ConvGemmParams& p, f32x16_t 
         *(f32x4_t*)((char*)p.Out + out_extra_bytes + oidx * 4) = o;
       } else {
         short4_t o;
+        if constexpr (ET == 1) { sat_see2(satm, acc[blk >> 1][0][ii], acc[blk >> 1][1][ii]); sat_see2(satm, acc[blk >> 1][2][ii], acc[blk >> 1][3][ii]); }
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (short)f2e<ET>(acc[blk >> 1][j][ii]);
         *(short4_t*)((char*)p.Out + out_extra_bytes + oidx * 2) = o;
       }
     }
   }
+  if constexpr (ET == 1) sat_flush(p.sat, satm);
 }
 
 template <int PREC, bool C2D = false>
@@ -635,6 +665,7 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
   auto store_row = [&](char* o, const float (&v)[8]) {
     short8_t hi, lo;
     if constexpr (ET == 1) {
+      sat_check_row(p.sat, v);                                // f16 range guard
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const f32x2_t c = {__builtin_amdgcn_fmed3f(v[2 * jj], -65504.0f, 65504.0f),
@@ -1912,7 +1943,7 @@ void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
     }
     return;
   }
-  if (split) abort();      // host contract (conv_gemm_supported): a split GEMM always fits the halo / gemm16 / small-Conv2d tiles
+  if (split) throw std::runtime_error("conv_gemm: a split GEMM of this shape fits no tile (conv_gemm_supported is the contract)");
   if (p.c2d) {
     const dim3 grid2(ntm * ntn, p.splitk > 1 ? p.splitk : 1);
     if (st == ST_F32) hipLaunchKernelGGL((conv_gemm_kernel<1, true>), grid2, block, 131072, s, p);
@@ -1939,6 +1970,12 @@ __device__ __forceinline__ void store_elem(void* base, long long idx, float v, l
     if constexpr ((FMT & 4) != 0) ((unsigned short*)((char*)base + plane))[idx] = f2e<ET>(v - e2f<ET>(hi));
   }
 }
+// the same, feeding the f16 range guard of the calling thread
+template <int FMT>
+__device__ __forceinline__ void store_elem(void* base, long long idx, float v, long long plane, float& satm) {
+  if constexpr ((FMT & 3) == ST_F16) sat_see(satm, v);
+  store_elem<FMT>(base, idx, v, plane);
+}
 template <int FMT>
 __device__ __forceinline__ float load_elem(const void* base, long long idx, long long plane = 0) {
   constexpr int ST = FMT & 3;
@@ -1961,14 +1998,14 @@ __device__ __forceinline__ float load_elem(const void* base, long long idx, long
     case 2: CALL(2); break;                                       \
     case 4: CALL(4); break;                                       \
     case 6: CALL(6); break;                                       \
-    default: abort();                                             \
+    default: throw std::runtime_error("denoiser kernels: unknown activation format"); \
   }
 #define DISPATCH_ST(fmt, CALL)                                    \
   switch (fmt) {                                                  \
     case 0: CALL(0); break;                                       \
     case 1: CALL(1); break;                                       \
     case 2: CALL(2); break;                                       \
-    default: abort();                                             \
+    default: throw std::runtime_error("denoiser kernels: unknown activation format"); \
   }
 
 // x (B, P, D) f32 -> A0 rows (b, l): [x[l-1,:], x[l,:], x[l+1,:], 0 ...] (K padded to 64): the
@@ -1983,8 +2020,9 @@ __global__ void __launch_bounds__(256) gn1d_kernel(void* __restrict__ x, int ld,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                    int mode, const float* __restrict__ film, int film_ld, int film_off,
                                                    const void* __restrict__ res, int ldres, int res_Lp, int res_off,
-                                                   long long x_plane, long long res_plane) {
+                                                   long long x_plane, long long res_plane, int* __restrict__ sat) {
   __shared__ float red[8];
+  float satm = 0.0f;
   const int b = blockIdx.x >> 3, g = blockIdx.x & 7;
   const int gc = C >> 3, vpr = gc >> 3, nvec = L * vpr;          // channels per group, 8-channel vectors per row
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -2032,9 +2070,10 @@ __global__ void __launch_bounds__(256) gn1d_kernel(void* __restrict__ x, int ld,
       } else if (mode == MODE_GN_MISH_RES) {
         y += load_elem<PREC>(res, ((long long)b * res_Lp + l + res_off) * ldres + c + j, res_plane);
       }
-      store_elem<PREC>(x, idx + j, y, x_plane);
+      store_elem<PREC>(x, idx + j, y, x_plane, satm);
     }
   }
+  if constexpr ((PREC & 3) == ST_F16) sat_flush(sat, satm);
 }
 // The same for short sequences in the 16-bit formats (the ant config's L = 8 and 4 levels: a (sample, group) is 128
 // 8-channel vectors): one WAVE per (sample, group), its vectors (up to four per lane) stay in registers -- one 16-byte load
@@ -2045,9 +2084,11 @@ __global__ void __launch_bounds__(256) gn1d_short_kernel(void* __restrict__ x, i
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float eps, int mode, const float* __restrict__ film, int film_ld,
                                                          int film_off, const void* __restrict__ res, int ldres, int res_Lp,
-                                                         int res_off, long long x_plane, long long res_plane, int n_sg) {
+                                                         int res_off, long long x_plane, long long res_plane, int n_sg,
+                                                         int* __restrict__ sat) {
   constexpr int ET = (FMT & 3) == ST_F16 ? 1 : 0;
   constexpr bool SPL = (FMT & 4) != 0;
+  float satm = 0.0f;
   const int lane = threadIdx.x & 63;
   const int sg = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (sg >= n_sg) return;
@@ -2119,6 +2160,10 @@ __global__ void __launch_bounds__(256) gn1d_short_kernel(void* __restrict__ x, i
         }
       }
       short8_t oh, ol;
+      if constexpr (ET == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) sat_see2(satm, y[j], y[j + 1]);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const unsigned short hh = f2e<ET>(y[j]);
@@ -2128,28 +2173,29 @@ __global__ void __launch_bounds__(256) gn1d_short_kernel(void* __restrict__ x, i
       *(short8_t*)((char*)x + idx[k] * 2) = oh;
       if constexpr (SPL) *(short8_t*)((char*)x + x_plane + idx[k] * 2) = ol;
     }
+  if constexpr (ET == 1) sat_flush(sat, satm);
 }
 void launch_gn1d(void* x, int ld, int Lp, int row_off, int coff, int L, int C, const float* gamma, const float* beta, float eps,
                  int mode, const float* film, int film_ld, int film_off, const void* res, int ldres, int res_Lp, int res_off,
-                 int B, int fmt, long long x_plane, long long res_plane, hipStream_t s) {
+                 int B, int fmt, long long x_plane, long long res_plane, hipStream_t s, int* sat) {
   // short (sample, group)s in a 16-bit format, 16-byte aligned vectors: the one-wave form
   if (fmt_st(fmt) != ST_F32 && L * (C >> 6) <= 256 && (C & 63) == 0 && (ld & 7) == 0 && (coff & 7) == 0 &&
       (mode != MODE_GN_MISH_RES || (ldres & 7) == 0) && (mode != MODE_GN_MISH_FILM || ((film_ld | film_off) & 3) == 0)) {
     const int n_sg = B * 8;
 #define CALLS(F) hipLaunchKernelGGL(gn1d_short_kernel<F>, dim3((n_sg + 3) / 4), dim3(256), 0, s, x, ld, Lp, row_off, coff, L, C, gamma, \
-                                    beta, eps, mode, film, film_ld, film_off, res, ldres, res_Lp, res_off, x_plane, res_plane, n_sg)
+                                    beta, eps, mode, film, film_ld, film_off, res, ldres, res_Lp, res_off, x_plane, res_plane, n_sg, sat)
     switch (fmt) {
       case 0: CALLS(0); break;
       case 2: CALLS(2); break;
       case 4: CALLS(4); break;
       case 6: CALLS(6); break;
-      default: abort();
+      default: throw std::runtime_error("gn1d: unknown 16-bit format");
     }
 #undef CALLS
     return;
   }
 #define CALL(F) hipLaunchKernelGGL(gn1d_kernel<F>, dim3(B * 8), dim3(256), 0, s, x, ld, Lp, row_off, coff, L, C, gamma, beta, eps, \
-                                   mode, film, film_ld, film_off, res, ldres, res_Lp, res_off, x_plane, res_plane)
+                                   mode, film, film_ld, film_off, res, ldres, res_Lp, res_off, x_plane, res_plane, sat)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
 }
@@ -2165,12 +2211,14 @@ template <int PREC, int N>
 __global__ void __launch_bounds__(256) encoder_stem_kernel(const float* __restrict__ lm /*[B][N][N]*/,
                                                            const float* __restrict__ W /*[49][64]: tap-major, coalesced per lane*/,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           void* __restrict__ out /*[B][PH*PH][64]*/, float eps, long long plane) {
+                                                           void* __restrict__ out /*[B][PH*PH][64]*/, float eps, long long plane,
+                                                           int* __restrict__ sat) {
   // N = 20 (car): 26 x 26 padded map, 10 x 10 conv outputs, 5 x 5 after the pool;  N = 16 (ant): 22, 8 x 8, 4 x 4
   constexpr int PD = N + 6, OH = N / 2, NP = OH * OH, J = NP / 4, PH = (OH - 1) / 2 + 1;
   __shared__ float s_map[PD * PD];
   __shared__ float s_act[NP * 64];
   __shared__ float s_red[2][4][4];                    // [pass][position quarter][group]
+  float satm = 0.0f;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int c = tid & 63, q = tid >> 6, g = c >> 4;
   for (int i = tid; i < PD * PD; i += 256) {
@@ -2229,23 +2277,25 @@ __global__ void __launch_bounds__(256) encoder_stem_kernel(const float* __restri
         const int ih = oh * 2 + kh - 1, iw = ow * 2 + kw - 1;
         if (ih >= 0 && ih < OH && iw >= 0 && iw < OH) best = fmaxf(best, s_act[(ih * OH + iw) * 64 + oc]);
       }
-    store_elem<PREC>(out, (long long)b * (PH * PH * 64) + o, best, plane);
+    store_elem<PREC>(out, (long long)b * (PH * PH * 64) + o, best, plane, satm);
   }
+  if constexpr ((PREC & 3) == ST_F16) sat_flush(sat, satm);
 }
 void launch_encoder_stem(const float* lm, int n, const float* W, const float* gamma, const float* beta, void* out, int B, float eps,
-                         int fmt, long long plane, hipStream_t s) {
-  if (n != 20 && n != 16) abort();
+                         int fmt, long long plane, hipStream_t s, int* sat) {
+  if (n != 20 && n != 16) throw std::runtime_error("encoder stem: local map must be 20 x 20 or 16 x 16");
 #define CALL(F)                                                                                                                    \
   do {                                                                                                                             \
-    if (n == 20) hipLaunchKernelGGL((encoder_stem_kernel<F, 20>), dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps, plane);  \
-    else hipLaunchKernelGGL((encoder_stem_kernel<F, 16>), dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps, plane);          \
+    if (n == 20) hipLaunchKernelGGL((encoder_stem_kernel<F, 20>), dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps, plane, sat);  \
+    else hipLaunchKernelGGL((encoder_stem_kernel<F, 16>), dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps, plane, sat);          \
   } while (0)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
 }
 
 template <int PREC>
-__global__ void prep_sample_kernel(const float* __restrict__ x, void* __restrict__ A0, int B, int P, int D, long long plane) {
+__global__ void prep_sample_kernel(const float* __restrict__ x, void* __restrict__ A0, int B, int P, int D, long long plane,
+                                   int* __restrict__ sat) {
   const long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= (long long)B * P) return;
@@ -2256,12 +2306,14 @@ __global__ void prep_sample_kernel(const float* __restrict__ x, void* __restrict
     const int ls = l + t - 1;
     if (ls >= 0 && ls < P) v = x[((long long)b * P + ls) * D + d];
   }
-  store_elem<PREC>(A0, row * 64 + lane, v, plane);
+  float satm = 0.0f;
+  store_elem<PREC>(A0, row * 64 + lane, v, plane, satm);
+  if constexpr ((PREC & 3) == ST_F16) sat_flush(sat, satm);
 }
-void launch_prep_sample(const float* x, void* A0, int B, int P, int D, int fmt, long long plane, hipStream_t s) {
+void launch_prep_sample(const float* x, void* A0, int B, int P, int D, int fmt, long long plane, hipStream_t s, int* sat) {
   long long rows = (long long)B * P;
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define CALL(F) hipLaunchKernelGGL(prep_sample_kernel<F>, grid, block, 0, s, x, A0, B, P, D, plane)
+#define CALL(F) hipLaunchKernelGGL(prep_sample_kernel<F>, grid, block, 0, s, x, A0, B, P, D, plane, sat)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
 }
@@ -2306,8 +2358,10 @@ void launch_time_embed(float t, const float* W1, const float* b1, const float* W
 // (conditional_unet1d.py:59-64 cond_encoder = Mish -> Linear, :293 global_feature).
 template <int PREC>
 __global__ void prep_cond_kernel(const float* __restrict__ temb, const float* __restrict__ map_emb, int E, int E_ld,
-                                 const float* __restrict__ cond, int G, void* __restrict__ out, int B, int Kpad, long long plane) {
+                                 const float* __restrict__ cond, int G, void* __restrict__ out, int B, int Kpad, long long plane,
+                                 int* __restrict__ sat) {
   const int b = blockIdx.x;
+  float satm = 0.0f;
   for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
     float v = 0.f;
     bool live = true;
@@ -2315,12 +2369,13 @@ __global__ void prep_cond_kernel(const float* __restrict__ temb, const float* __
     else if (k < 256 + E) v = map_emb[(long long)b * E_ld + (k - 256)];
     else if (k < 256 + E + G) v = cond[(long long)b * G + (k - 256 - E)];
     else live = false;
-    store_elem<PREC>(out, (long long)b * Kpad + k, live ? MISH_OF(PREC)(v) : 0.f, plane);
+    store_elem<PREC>(out, (long long)b * Kpad + k, live ? MISH_OF(PREC)(v) : 0.f, plane, satm);
   }
+  if constexpr ((PREC & 3) == ST_F16) sat_flush(sat, satm);
 }
 void launch_prep_cond(const float* temb, const float* map_emb, int E, int E_ld, const float* cond, int G, void* out, int B,
-                      int Kpad, int fmt, long long plane, hipStream_t s) {
-#define CALL(F) hipLaunchKernelGGL(prep_cond_kernel<F>, dim3(B), dim3(256), 0, s, temb, map_emb, E, E_ld, cond, G, out, B, Kpad, plane)
+                      int Kpad, int fmt, long long plane, hipStream_t s, int* sat) {
+#define CALL(F) hipLaunchKernelGGL(prep_cond_kernel<F>, dim3(B), dim3(256), 0, s, temb, map_emb, E, E_ld, cond, G, out, B, Kpad, plane, sat)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
 }
@@ -2395,7 +2450,7 @@ void launch_final_proj_flow(const void* Y, int C, int Lp, long long plane, const
   ActNormArg nm{};
   for (int d = 0; d < D && d < 8; ++d) { nm.mu[d] = act_norm[d]; nm.sg[d] = act_norm[D + d]; }
 #define CALLD(F, DD) hipLaunchKernelGGL((final_proj_flow_kernel<F, DD>), grid, block, 0, s, Y, C, Lp, plane, W, bias, x, dt, nm, actions, B, P, raw)
-#define CALL(F) do { if (D == 2) CALLD(F, 2); else if (D == 8) CALLD(F, 8); else abort(); } while (0)
+#define CALL(F) do { if (D == 2) CALLD(F, 2); else if (D == 8) CALLD(F, 8); else throw std::runtime_error("final projection: action_dim must be 2 or 8"); } while (0)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
 #undef CALLD
@@ -2446,7 +2501,8 @@ template <int PREC>
 __global__ void __launch_bounds__(256) gn2d_kernel(const float* __restrict__ in, int nslab, long long slab_stride,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const void* __restrict__ res, int relu, void* __restrict__ out, int HW,
-                                                   int C, float eps, long long res_plane, long long out_plane) {
+                                                   int C, float eps, long long res_plane, long long out_plane, int* __restrict__ sat) {
+  float satm = 0.0f;
   __shared__ float red[2][64];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int T = C >> 2, PP = 256 / T, G = C >> 4;
@@ -2527,6 +2583,7 @@ __global__ void __launch_bounds__(256) gn2d_kernel(const float* __restrict__ in,
       *(f32x4_t*)((float*)out + idx) = o;
     } else {
       short4_t o;
+      if constexpr (ET == 1) { sat_see2(satm, y[0], y[1]); sat_see2(satm, y[2], y[3]); }
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = (short)f2e<ET>(y[j]);
       *(short4_t*)((unsigned short*)out + idx) = o;
@@ -2538,15 +2595,17 @@ __global__ void __launch_bounds__(256) gn2d_kernel(const float* __restrict__ in,
       }
     }
   }
+  if constexpr ((PREC & 3) == ST_F16) sat_flush(sat, satm);
 }
 void launch_gn2d(const float* in, int nslab, long long slab_stride, const float* gamma, const float* beta, const void* res,
                  int relu, void* out, int B, int HW, int C, float eps, int fmt, long long res_plane, long long out_plane,
-                 hipStream_t s) {
+                 hipStream_t s, int* sat) {
   // host-side shape contract of the kernel (ResNet-18 stages on maps up to 10 x 10)
-  if (C < 64 || C > 1024 || (C & (C - 1)) != 0 || (HW + 256 / (C >> 2) - 1) / (256 / (C >> 2)) > GN2D_MAXP) abort();
+  if (C < 64 || C > 1024 || (C & (C - 1)) != 0 || (HW + 256 / (C >> 2) - 1) / (256 / (C >> 2)) > GN2D_MAXP)
+    throw std::runtime_error("encoder GroupNorm: unsupported map shape");
   dim3 grid((unsigned)B), block(256);
 #define CALL(F) hipLaunchKernelGGL(gn2d_kernel<F>, grid, block, 0, s, in, nslab, slab_stride, gamma, beta, res, relu, out, HW, C, eps, \
-                                   res_plane, out_plane)
+                                   res_plane, out_plane, sat)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
 }

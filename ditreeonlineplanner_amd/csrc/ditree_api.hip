@@ -27,6 +27,13 @@ extern "C" {
 
 int32_t ditree_version(void) { return DITREE_VERSION; }
 
+#ifndef DITREE_BUILD_ID_STR
+#define DITREE_BUILD_ID_STR "0000000000000000"          // a build outside ditreeonlineplanner_amd/build.py
+#endif
+// the marker is what build.py greps for in the binary; the id itself starts behind the '='
+static const char k_build_marker[] = "DITREE_BUILD_ID=" DITREE_BUILD_ID_STR;
+const char* ditree_build_id(void) { return k_build_marker + sizeof("DITREE_BUILD_ID=") - 1; }
+
 int32_t ditree_ctx_create(int32_t device, ditree_ctx** out) {
   if (!out) return DITREE_E_ARG;
   *out = nullptr;
@@ -56,6 +63,7 @@ void ditree_ctx_destroy(ditree_ctx* ctx) {
   if (ctx->alive_cnt) hipFree(ctx->alive_cnt);
   if (ctx->alive_cnt_host) hipHostFree(ctx->alive_cnt_host);
   if (ctx->path_dev) hipFree(ctx->path_dev);
+  if (ctx->mppi_partial) hipFree(ctx->mppi_partial);
   delete ctx;
 }
 

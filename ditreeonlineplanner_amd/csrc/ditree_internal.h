@@ -45,6 +45,7 @@ struct ditree_ctx {
   int32_t* alive_cnt_host = nullptr;  // pinned host copy
   double* path_dev = nullptr;       // reference path xy for the fallback selection
   int path_cap = 0;
+  double* mppi_partial = nullptr;   // partial sums of the MPPI update (ditree_mppi_step)
   DenoiserState* dn = nullptr;
   // optional RCCL communicator (ditree_comm_*): librccl opened at run time
   void* rccl_lib = nullptr;

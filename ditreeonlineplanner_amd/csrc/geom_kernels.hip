@@ -13,6 +13,7 @@
 //                  common/map_utils.py:103-115,221-329
 //   lidar_scan     lidar_sim/lidar_2d_sim.py:18-98
 //   accept/commit  planners/RRT.py:179-217
+#include "car_device.h"
 #include "ditree_internal.h"
 
 #define WAVE 64
@@ -231,68 +232,6 @@ void launch_cond_vector_ant(const double* obs, int n_hist, const double* prev_ac
                             const double* cond_goal, int B, const AntNormArg& nm, double lm_size, float* out, hipStream_t s) {
   hipLaunchKernelGGL(cond_vector_ant_kernel, dim3((B + 127) / 128), dim3(128), 0, s, obs, n_hist, prev_action, has_prev,
                      cond_goal, B, nm, lm_size, out);
-}
-
-// ------------------------------------------------------------------------- collision
-// common/map_utils.py:221-329 for one ball (maze_size_scaling = 1, radius 0.1).
-__device__ __forceinline__ bool ball_collides(double x, double y, const unsigned char* mz, int H, int W) {
-  const double s = 1.0, r = 0.1;
-  const double xc = (double)W / 2.0 * s, yc = (double)H / 2.0 * s;
-  double fr = floor((yc - y) / s), fc = floor((x + xc) / s);
-  // numpy's astype(int) maps NaN/inf to INT64_MIN -> out of bounds -> collision (:255-259)
-  if (!(fr >= 0.0) || !(fr < (double)H) || !(fc >= 0.0) || !(fc < (double)W)) return true;
-  const int row = (int)fr, col = (int)fc;
-  bool coll = mz[row * W + col] == 1;                                            // :262
-  const double cell_x = ((double)col + 0.5) * s - xc, cell_y = yc - ((double)row + 0.5) * s;
-  const double half = s / 2.0;
-  const double x_min = cell_x - half, x_max = cell_x + half, y_min = cell_y - half, y_max = cell_y + half;
-  const int cr = min(col + 1, W - 1), cl = max(col - 1, 0), rt = max(row - 1, 0), rb = min(row + 1, H - 1);
-  coll |= (x + r > x_max) && (mz[row * W + cr] == 1);                            // right  :288-292
-  coll |= (x - r < x_min) && (mz[row * W + cl] == 1);                            // left   :294-298
-  coll |= (y + r > y_max) && (mz[rt * W + col] == 1);                            // top    :300-304
-  coll |= (y - r < y_min) && (mz[rb * W + col] == 1);                            // bottom :306-310
-  // corners :315-327; invalid neighbour => collision; column clipped with map_length (sic, :326)
-  const int ci[4] = {row - 1, row - 1, row + 1, row + 1};
-  const int cj[4] = {col + 1, col - 1, col + 1, col - 1};
-  const double kx[4] = {x_max, x_min, x_max, x_min};
-  const double ky[4] = {y_max, y_max, y_min, y_min};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    bool invalid = ci[k] < 0 || ci[k] >= H || cj[k] < 0 || cj[k] >= W;
-    int i2 = min(max(ci[k], 0), H - 1);
-    int j2 = min(min(max(cj[k], 0), H - 1), W - 1);
-    double dist = hypot(kx[k] - x, ky[k] - y);
-    coll |= invalid || ((dist < r) && (mz[i2 * W + j2] == 1));
-  }
-  return coll;
-}
-
-// common/map_utils.py:103-115: two balls +-0.075 m along the heading.
-__device__ __forceinline__ bool car_collides(double x, double y, double psi, const unsigned char* mz, int H, int W) {
-  const double off = 0.15 * 0.5;
-  double ox = off * cos(psi), oy = off * sin(psi);
-  bool f = ball_collides(x + ox, y + oy, mz, H, W);
-  bool b = ball_collides(x - ox, y - oy, mz, H, W);
-  return f || b;
-}
-
-// car_env.py:356-396 _update_state: clip the action, explicit dynamics, one Euler step of 1/50 s.
-__device__ __forceinline__ void car_euler_step(double* s, double a0r, double a1r) {
-  // car_env.py:32,47-53
-  const double dt = 1.0 / 50.0, m = 0.043, C1 = 0.5, C2 = 15.5, Cm1 = 0.28, Cm2 = 0.05, Cr0 = 0.011, Cr2 = 0.006;
-  // np.clip(action, [-10,-2], [10,2]) car_env.py:371; NaN propagates like numpy
-  double a0 = a0r < -10.0 ? -10.0 : (a0r > 10.0 ? 10.0 : a0r);
-  double a1 = a1r < -2.0 ? -2.0 : (a1r > 2.0 ? 2.0 : a1r);
-  const double psi = s[2], v = s[3], D = s[4], dl = s[5];
-  double Fxd = (Cm1 - Cm2 * v) * D - Cr2 * (v * v) - Cr0 * tanh(5.0 * v);     // :380
-  double ang = psi + C1 * dl;
-  double d0 = v * cos(ang), d1 = v * sin(ang), d2 = v * C2 * dl, d3 = (Fxd / m) * cos(C1 * dl);
-  s[0] = s[0] + dt * d0;
-  s[1] = s[1] + dt * d1;
-  s[2] = s[2] + dt * d2;
-  s[3] = s[3] + dt * d3;
-  s[4] = s[4] + dt * a0;
-  s[5] = s[5] + dt * a1;
 }
 
 // ------------------------------------------------------------------------- rollout

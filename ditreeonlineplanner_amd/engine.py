@@ -310,6 +310,7 @@ class ExpansionEngine:
             if ev is not None:
                 ev[1].record()
                 self.exchange_events.append(ev)
+        self._used_denoiser = noise is not None
         if accept:
             return self.accept(B)
         return None
@@ -348,7 +349,10 @@ class ExpansionEngine:
             rd = self.rb.desc(0, B)
         check(self.ctx._h, lib().ditree_accept(self.ctx._h, C.byref(self.tree.desc), C.byref(rd), self.sticky,
                                                 self.ctx.stream), "accept")
-        return self.tree.read_counters()          # one small D2H per round: n_nodes / goal
+        cnt = self.tree.read_counters()           # one small D2H per round: n_nodes / goal
+        if getattr(self, "_used_denoiser", False):
+            self.ctx.check_range()                # f16 range guard: the stream is drained already, one more tiny D2H
+        return cnt
 
     # ------------------------------------------------------------------ results
     @property

@@ -1,13 +1,119 @@
-"""`MPPI.mppi.MPPI` -- the controller `run_scenarios_with_lidar_MPPI.py:10,339-449` imports.  The reference repository
-does not contain this module ("MPPI: module absent from the reference, no oracle exists at
-all"), so there are no semantics to reproduce.  What BASELINE config 5 asks of the hot path -- 65 536 rollouts of T = 16
-bicycle steps with collision / goal tests -- is the rollout kernel measured alone (`bench.py --workload rollout`).
-The class exists so the script's import block resolves; constructing it says what is missing."""
+"""`MPPI.mppi.MPPI` -- the controller `run_scenarios_with_lidar_MPPI.py:10,339-449` constructs as
+`MPPI(maze_data, T, K, nx, nu)` and drives through `.reset / .step / .is_done / .set_ref_path / .reference_path /
+.update_maze / .env` (`:392-394,402,410,414,417,422,442,447-449`).
+
+The reference repository does NOT contain this module ("no oracle exists at all"), so there are no
+semantics to be faithful to: the controller below is the build's own -- information-theoretic MPPI (Williams et al. 2017)
+on the reference's car dynamics, two-ball collision test and goal radius, every controller step on the GPU
+(`ditree_mppi_step`: K x T rollouts with on-device noise, soft-min weights by wavefront reductions, weighted control update,
+one executed env step).  The cost function is stated in include/ditree.h and DESIGN.md; **parity with the reference is
+unpinned**, the kernels are held to the build's numpy restatement (oracle/mppi.py) and to invariants
+(tests/test_gpu_mppi.py).  There is no CPU path.
+
+`step(state) -> (next_state, action, done)` keeps the driver's contract: `done is None` when the executed step collides
+with the KNOWN maze (the state does not advance, the nominal controls restart from rest and the next call draws fresh
+noise: the driver retries up to ALLOWED_TRIALS times), `True` inside the goal radius, else `False`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .car_env import CarEnv
+from .ops import default_context
 
 
 class MPPI:
-    def __init__(self, maze_data=None, T=16, K=10, nx=6, nu=2, **kw):
-        raise NotImplementedError(
-            "MPPI.mppi is imported by run_scenarios_with_lidar_MPPI.py but is not part of the reference repository: there "
-            "is no cost function, sampling scheme or update rule to be faithful to.  The rollout workload it would drive is "
-            "`ExpansionEngine` / `Context.car_rollout` (K x T bicycle steps per launch, bench.py --workload rollout).")
+    def __init__(self, maze_data=None, T=16, K=1024, nx=6, nu=2, lam=1.0, sigma=(3.0, 0.6), w_track=20.0, w_progress=0.5,
+                 w_collision=1.0e3, w_goal=50.0, window_back=8, window_fwd=56, seed=0, lanes=0, ctx=None, env=None, **kw):
+        if maze_data is None:
+            raise ValueError("MPPI needs the known maze (maze_data)")
+        if nx != 6 or nu != 2:
+            raise NotImplementedError("the controller drives the car model: nx = 6 (x, y, psi, v, D, delta), nu = 2 (dD, ddelta)")
+        if not (1 <= int(T) <= 64) or int(K) < 1:
+            raise ValueError("1 <= T <= 64, K >= 1")
+        self.T, self.K, self.nx, self.nu = int(T), int(K), nx, nu
+        self.ctx = ctx or default_context()
+        self.env = env if env is not None else CarEnv(maze_map=np.asarray(maze_data), collision_checking=False, ctx=self.ctx)
+        self.maze = np.float32(maze_data)
+        self.params = _lib.MppiParams(self.T, self.K, float(lam), (C.c_double * 2)(float(sigma[0]), float(sigma[1])),
+                                      float(w_track), float(w_progress), float(w_collision), float(w_goal), int(seed),
+                                      int(window_back), int(window_fwd), int(lanes))
+        dev = self.ctx.device
+        f64 = torch.float64
+        self._state = torch.zeros(6, dtype=f64, device=dev)
+        self._U = torch.zeros(self.T, 2, dtype=f64, device=dev)
+        self._costs = torch.zeros(self.K, dtype=f64, device=dev)
+        self._flags = torch.zeros(self.K, dtype=torch.int32, device=dev)
+        self._result = torch.zeros(8, dtype=f64, device=dev)
+        self._path = None
+        self.reference_path = None
+        self.goal_state = None
+        self.counter = 0                   # one noise stream per step() call (also the retried ones)
+        self.last = {}
+        self.ctx.upload_maze(self.maze, owner=self)
+
+    # ------------------------------------------------------------------ the surface the driver uses
+    def reset(self, start_state=None, goal_state=None):
+        if start_state is not None:
+            start_state = np.asarray(start_state, dtype=np.float64)
+            self.goal_state = np.asarray(goal_state, dtype=np.float64)
+            opts = {"reset_cell": self.env.cell_xy_to_rowcol(start_state[:2]), "reset_deg": np.rad2deg(start_state[2]),
+                    "goal_cell": self.env.cell_xy_to_rowcol(self.goal_state[:2])}
+            self.env.reset(options=opts)
+            self.env.set_state(start_state.copy())
+        self._U.zero_()
+        self.counter = 0
+
+    def update_maze(self, new_maze):
+        self.maze = np.float32(new_maze)
+        self.env.maze_map = new_maze
+        self.ctx.upload_maze(self.maze, owner=self)
+
+    def set_ref_path(self, path):
+        """The plan to track: (P, >= 2) states; more than 4096 points are thinned uniformly (the kernel stages the path in LDS)."""
+        path = np.asarray(path, dtype=np.float64)
+        if path.ndim != 2 or path.shape[1] < 2 or len(path) < 1:
+            raise ValueError("reference path must be (P, >= 2)")
+        self.reference_path = path
+        xy = np.ascontiguousarray(path[:, :2])
+        if len(xy) > 4096:
+            xy = np.ascontiguousarray(xy[np.round(np.linspace(0, len(xy) - 1, 4096)).astype(int)])
+        self._path = torch.as_tensor(xy, device=self.ctx.device)
+
+    def is_done(self, state):
+        return self.env.is_done(state)
+
+    def step(self, state, noise=None):
+        """One controller step from `state` (6,): -> (next_state (6,) f64, action (2,) f64, done in {False, True, None})."""
+        if self._path is None:
+            raise _lib.DitreeError("MPPI.step: set_ref_path(path) first")
+        if self.ctx.maze_owner is not self:
+            self.ctx.upload_maze(self.maze, owner=self)
+        self._state.copy_(torch.as_tensor(np.asarray(state, dtype=np.float64)))
+        self.launch(7, noise=noise)
+        res = self._result.cpu().numpy()
+        self.counter += 1
+        status = int(res[2])
+        self.last = {"beta": float(res[3]), "eta": float(res[4]), "nearest_path_index": int(res[5]),
+                     "collided_rollouts": int(res[6]), "effective_samples": float(res[7])}
+        nxt = self._state.cpu().numpy().copy()
+        action = res[:2].copy()
+        if status == 2:
+            return nxt, action, None
+        self.env.set_state(nxt.copy())
+        if status == 1:
+            self.env.done = True
+        return nxt, action, status == 1
+
+    # ------------------------------------------------------------------ one C-ABI call (stages: 1 rollouts, 2 update, 4 execute)
+    def launch(self, stages, noise=None, weights=None):
+        goal = (C.c_double * 2)(float(self.env.goal[0]), float(self.env.goal[1]))
+        _lib.check(self.ctx._h, _lib.lib().ditree_mppi_step(
+            self.ctx._h, C.byref(self.params), self._state.data_ptr(), self._U.data_ptr(), self._path.data_ptr(),
+            int(self._path.shape[0]), goal, None if noise is None else noise.data_ptr(), self.counter, int(stages),
+            self._costs.data_ptr(), None if weights is None else weights.data_ptr(), self._flags.data_ptr(),
+            self._result.data_ptr(), self.ctx.stream), "mppi_step")

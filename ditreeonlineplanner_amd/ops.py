@@ -257,9 +257,31 @@ def _ctx_denoise_reserve(self, max_batch, precision=_lib.PREC_BF16):
     check(self._h, lib().ditree_denoise_reserve(self._h, int(max_batch), int(precision)), "denoise_reserve")
 
 
-def _ctx_denoise(self, noise, local_map, cond, t0=None, dt=None, act_norm=None, want_actions=True):
+def _ctx_denoise_status(self, clear=True):
+    """Layers of the f16 instantiations (PREC_F16X3 / PREC_F16) that were handed activations beyond +-65504 since the last
+    clear, as state-dict names; [] for a healthy network and always for bf16 / f32.  Waits for the stream."""
+    n = C.c_int32(0)
+    buf = C.create_string_buffer(16384)
+    check(self._h, lib().ditree_denoise_status(self._h, C.byref(n), buf, len(buf), int(bool(clear)), self.stream), "denoise_status")
+    return buf.value.decode().split("\n") if n.value else []
+
+
+def _ctx_check_range(self):
+    """Raise when the f16 range guard fired: the clamped activations make the returned actions wrong, not approximate."""
+    layers = self.denoise_status(clear=True)
+    if layers:
+        raise _lib.DitreeError(
+            "f16 range guard: activations beyond +-65504 were clamped in " + ", ".join(layers[:6]) +
+            (f" and {len(layers) - 6} more layers" if len(layers) > 6 else "") +
+            ".  This checkpoint does not fit the f16x3 / f16 instantiation: bind it with precision=PREC_BF16X3 "
+            "(f32 exponent range, 16 significand bits) or PREC_F32.")
+
+
+def _ctx_denoise(self, noise, local_map, cond, t0=None, dt=None, act_norm=None, want_actions=True, check_range=True):
     """noise (B,P,D) f32, local_map (B,n,n) f32 scaled to {-1,1}, cond (B,G) f32 [device].
-    Returns actions (B,P,D) f64 when want_actions else the normalised sample x_K (f32)."""
+    Returns actions (B,P,D) f64 when want_actions else the normalised sample x_K (f32).  check_range: wait for the call
+    and raise DitreeError when a layer left the f16 range (no-op cost for bf16 / f32 instantiations apart from the wait;
+    pass False inside a throughput loop and call ``check_range()`` once at its end)."""
     dev = self.device
     _chk(noise, torch.float32, "noise", dev)
     _chk(local_map, torch.float32, "local_map", dev)
@@ -277,10 +299,12 @@ def _ctx_denoise(self, noise, local_map, cond, t0=None, dt=None, act_norm=None, 
     xout = None if want_actions else torch.empty_like(noise)
     check(self._h, lib().ditree_denoise(self._h, _ptr(noise), _ptr(local_map), _ptr(cond), B, len(t0a), t0p, dtp,
                                         anp, _ptr(actions), _ptr(xout), self.stream), "denoise")
+    if check_range:
+        self.check_range()
     return actions if want_actions else xout
 
 
-def _ctx_denoise_eval(self, sample, local_map, cond, timestep, reuse_encoder=False):
+def _ctx_denoise_eval(self, sample, local_map, cond, timestep, reuse_encoder=False, check_range=True):
     """One raw network evaluation net(sample, map, timestep, cond) -> (B,P,D) f32 (the DDPM branch's model call)."""
     dev = self.device
     _chk(sample, torch.float32, "sample", dev)
@@ -290,6 +314,8 @@ def _ctx_denoise_eval(self, sample, local_map, cond, timestep, reuse_encoder=Fal
     out = torch.empty_like(sample)
     check(self._h, lib().ditree_denoise_eval(self._h, _ptr(sample), _ptr(local_map), _ptr(cond), sample.shape[0],
                                              float(timestep), int(bool(reuse_encoder)), _ptr(out), self.stream), "denoise_eval")
+    if check_range:
+        self.check_range()
     return out
 
 
@@ -327,6 +353,8 @@ Context.denoise = _ctx_denoise
 Context.denoise_eval = _ctx_denoise_eval
 Context.debug_read = _ctx_debug_read
 Context.denoise_dims = _ctx_denoise_dims
+Context.denoise_status = _ctx_denoise_status
+Context.check_range = _ctx_check_range
 Context._check_denoiser_shapes = _ctx_check_denoiser_shapes
 
 

@@ -48,6 +48,9 @@ extern "C" {
 typedef struct ditree_ctx ditree_ctx;
 
 int32_t ditree_version(void);
+/* 16 hex digits: sha256 over the library's own sources (the csrc directory, this header) and compile flags, embedded at build time by
+ * ditreeonlineplanner_amd/build.py; the Python binding refuses a library whose id differs from the sources next to it. */
+const char* ditree_build_id(void);
 int32_t ditree_ctx_create(int32_t device, ditree_ctx** out);
 void ditree_ctx_destroy(ditree_ctx* ctx);
 const char* ditree_last_error(ditree_ctx* ctx);
@@ -240,6 +243,44 @@ int32_t ditree_follow_plan(ditree_ctx* ctx, double* state_io, const float* actio
                            const float* true_maze, float* scanned_maze, const double* goal_xy /*[host] 2*/,
                            double dt, double scan_time, double* executed, int32_t* result, void* stream);
 
+/* ------------------------------------------------------------------ MPPI controller */
+
+/* One step of the MPPI controller `run_scenarios_with_lidar_MPPI.py:10,339-449` drives (`MPPI.mppi.MPPI(maze_data, T, K, nx,
+ * nu)`: .reset / .step / .is_done / .set_ref_path / .reference_path / .update_maze / .env).  The reference repository does
+ * not ship that module, so the algorithm is this build's own (DESIGN.md "MPPI"; PARITY UNPINNED): information-theoretic MPPI
+ * on the reference's car dynamics (car_env.py:356-396), two-ball collision test (common/map_utils.py:103-115) and goal
+ * radius (car_env.py:341-354), all against the maze uploaded with ditree_upload_maze.
+ *   rollout k, step t:  u = U[t] + eps[k, t] (rollout 0: eps = 0), x <- car_step(x, u);
+ *     cost += w_track * d2(x, path) + lambda * sum_d U[t, d] eps[k, t, d] / sigma_d^2;  d2 = squared distance to the nearest
+ *     path point with index in [i - window_back, i + window_fwd] around the previous step's nearest index i (the first step
+ *     starts from the nearest index of the current state over the whole path);
+ *     collision: cost += w_collision, rollout ends;  goal radius: cost -= w_goal, rollout ends;
+ *     terminal: cost += w_progress * (P - 1 - i_last).
+ *   beta = min_k S_k;  w_k = exp(-(S_k - beta) / lambda);  U[t] += sum_k w_k eps[k, t] / sum_k w_k.
+ *   execute: a = clip(U[0]) -> one env step; collision: state unchanged, U <- 0, status 2; else state <- x', U shifted by
+ *   one step (last control held), status 1 inside the goal radius, else 0.
+ * stages (bit mask): 1 = rollouts (fills costs [, flags]), 2 = weights + control update, 4 = execute + shift; 7 = one
+ * controller step.  noise [dev] (K, T, 2) f64 or NULL = generated on the device, a pure function of (seed, counter, k, t)
+ * (splitmix64 -> Box-Muller) that never touches HBM.
+ *   state_io [dev] 6 f64; U_io [dev] (T, 2) f64 nominal controls; path_xy [dev] (P, 2) f64, P <= 4096; goal_xy [host] 2;
+ *   costs [dev] (K) f64; weights [dev] (K) f64 or NULL (normalised w_k); flags [dev] (K) i32 or NULL (0, 1 goal, 2 collided);
+ *   result [dev] 8 f64: executed action (2), status, beta, eta = sum_k w_k, nearest path index of the input state, number of
+ *   collided rollouts (needs flags), effective sample size eta^2 / sum w^2. */
+typedef struct {
+  int32_t T, K;                      /* horizon (<= 64), rollouts */
+  double lambda;                     /* temperature */
+  double sigma[2];                   /* noise standard deviation of (dD, ddelta) */
+  double w_track, w_progress, w_collision, w_goal;
+  uint64_t seed;
+  int32_t window_back, window_fwd;   /* nearest-path-index search window per step */
+  int32_t lanes;                     /* lanes of a wavefront that share one rollout: 0 (default) or 4 = a quad (one ball and a
+                                        quarter of the path window per lane: four waves per SIMD at K = 65 536), 1 = one lane.
+                                        Same results either way. */
+} ditree_mppi_params;
+int32_t ditree_mppi_step(ditree_ctx* ctx, const ditree_mppi_params* p, double* state_io, double* U_io, const double* path_xy,
+                         int32_t P, const double* goal_xy, const double* noise, uint64_t counter, int32_t stages,
+                         double* costs, double* weights, int32_t* flags, double* result, void* stream);
+
 /* ------------------------------------------------------------------ denoiser */
 
 /* Upload the denoiser weights (reference: run_scenarios.py:157-185, state-dict keys
@@ -255,9 +296,21 @@ int32_t ditree_denoise_reserve(ditree_ctx* ctx, int32_t max_batch, int32_t preci
 #define DITREE_PREC_BF16 0          /* bf16 MFMA inputs, fp32 accumulate (throughput path; 8 significand bits) */
 #define DITREE_PREC_F32 1           /* fp32 MFMA (v_mfma_f32_32x32x2_f32): the reference's arithmetic, 1/16 of the bf16 rate */
 #define DITREE_PREC_F16X3 2         /* f32-class: every operand as f16 hi + lo planes, 3 f16 MFMAs per product (22 bits),
-                                       f32 accumulate, encoder in f32; 1/3 of the 16-bit rate.  f16 range: |x| <= 65504 */
+                                       f32 accumulate, the encoder split the same way; 1/3 of the 16-bit rate.  f16 range:
+                                       activations beyond +-65504 are clamped AND reported (ditree_denoise_status) */
 #define DITREE_PREC_BF16X3 3        /* the same split on bf16 (16 significand bits, f32 range) */
 #define DITREE_PREC_F16 4           /* plain f16 MFMA inputs (11 significand bits) at the bf16 rate */
+
+/* Range guard of the f16 instantiations (DITREE_PREC_F16X3 / _F16).  The reference computes in fp32
+ * (model/diffusion/conditional_unet1d.py:110-117: `scale * out + bias` of a FiLM layer has no bound); f16 activations
+ * saturate at +-65504.  Every layer that stores f16 activations raises a sticky device flag when it is handed a value
+ * beyond that range.  This call WAITS for `stream` (the one exception to "nothing synchronises"), reads the flags and
+ * returns the number of layers that saturated since the last clear; their state-dict names (e.g.
+ * "unet.mid_modules.0.blocks.0.block.0"), newline-separated and NUL-terminated, go to names [host] (names_cap bytes, may
+ * be 0).  clear != 0 resets the flags.  A result > 0 means the actions of those calls are NOT the network's: re-reserve
+ * with DITREE_PREC_BF16X3 (f32 exponent range) or DITREE_PREC_F32.  Always 0 for the bf16 / f32 instantiations. */
+int32_t ditree_denoise_status(ditree_ctx* ctx, int32_t* n_saturated /*[host]*/, char* names /*[host]*/, int64_t names_cap,
+                              int32_t clear, void* stream);
 
 /* Dimensions of the loaded denoiser: dims5 = {pred_horizon, action_dim, local_map_size, obs-cond width, map embedding}. */
 int32_t ditree_denoise_dims(ditree_ctx* ctx, int32_t* dims5);

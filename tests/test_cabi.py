@@ -71,3 +71,16 @@ def test_halo_kernel_loop_has_no_scratch_traffic(tmp_path):
         assert any("vmcnt(2)" in l for l in loop)
         offenders = [l.strip() for l in loop if "scratch_" in l or re.search(r"\b(global|flat)_(load|store)", l)]
         assert not offenders, (et, split, offenders)
+
+
+def test_library_carries_the_build_id_of_its_sources(monkeypatch):
+    """A stale libditree_hip.so (built from other sources than the ones next to it, e.g. shipped with a snapshot) must not
+    load: the id is a content hash of csrc + include/ditree.h + flags, embedded in the binary and exported."""
+    import pytest
+    from ditreeonlineplanner_amd import _lib, build
+    assert build.library_id() == build.source_id() == _lib.build_id()
+    assert re.fullmatch(r"[0-9a-f]{16}", _lib.build_id())
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(build, "source_id", lambda: "0123456789abcdef")
+    with pytest.raises(_lib.DitreeLibraryError, match="stale"):
+        _lib.lib()

@@ -337,3 +337,44 @@ def test_other_denoiser_sizes(ctx, inputs, size, dims, prec):
     x_ref = OS.flow_sample(onet, noise[:B], lm[:B], cond[:B], k_steps=1)
     x = ctx.denoise(noise[:B].cuda().contiguous(), lm[:B].cuda().contiguous(), cond[:B].cuda().contiguous(), want_actions=False)
     assert rel(x.cpu().numpy(), x_ref) < tol, (size, prec, rel(x.cpu().numpy(), x_ref))
+
+
+def test_f16_range_guard_reports_a_clamped_layer(ctx, oracle_net, inputs):
+    """f16x3 stores activations as f16 hi + lo and saturates at +-65504.  The reference's FiLM layer `scale * out + bias`
+    (model/diffusion/conditional_unet1d.py:110-117) has no bound, so a checkpoint may leave that range: the library must SAY
+    so (ditree_denoise_status names the layer, Context.denoise raises) instead of returning wrong actions with rc 0, and
+    the range-safe split (bf16x3) must stay within its bound on the same weights."""
+    import copy
+    from ditreeonlineplanner_amd import _lib
+    noise, lm, cond = inputs
+    B = noise.shape[0]
+    dev = ctx.device
+    args = (noise.to(dev), lm.to(dev), cond.to(dev))
+    # healthy network: the guard stays silent in every instantiation
+    for prec in (2, 4):
+        _bind(ctx, oracle_net, prec, B)
+        ctx.denoise(*args, want_actions=False)
+        assert ctx.denoise_status() == []
+    big = copy.deepcopy(oracle_net)
+    key = "unet.mid_modules.0.cond_encoder.1"
+    with torch.no_grad():
+        sd = big.state_dict()
+        sd[key + ".weight"].mul_(3e5)              # FiLM scale / bias of mid block 1: O(1) -> O(1e5)
+        sd[key + ".bias"].mul_(3e5)
+    x_ref = OS.flow_sample(big, noise.numpy(), lm.numpy(), cond.numpy(), k_steps=1)
+    assert np.isfinite(x_ref).all()
+    for prec in (2, 4):
+        _bind(ctx, big, prec, B)
+        x = ctx.denoise(*args, want_actions=False, check_range=False)      # rc 0: the launch itself is fine
+        layers = ctx.denoise_status(clear=False)
+        assert "unet.mid_modules.0.blocks.0.block.0" in layers, layers     # the layer whose epilogue applies the FiLM row
+        assert ctx.denoise_status(clear=True) == layers                     # sticky until cleared
+        assert ctx.denoise_status() == []
+        with pytest.raises(_lib.DitreeError, match="f16 range guard.*unet.mid_modules.0.blocks.0.block.0"):
+            ctx.denoise(*args, want_actions=False)
+        assert rel(x.cpu().numpy(), x_ref) > 1e-3                           # and the clamped result IS wrong (measured 7e-3)
+    # the range-safe split on the same weights: within its usual bound, guard silent
+    _bind(ctx, big, 3, B)
+    x = ctx.denoise(*args, want_actions=False)
+    assert ctx.denoise_status() == []
+    assert rel(x.cpu().numpy(), x_ref) < TOL[3]["l2"] * 4, rel(x.cpu().numpy(), x_ref)
