@@ -178,6 +178,22 @@ def launch_ranks(argv, n):
     return rc
 
 
+def recorded_traffic(tag, precision=None, kernel=None):
+    """`roofline.traffic` of the side workloads: HBM-side bytes per launch recorded by a separate rocprofv3 --pmc pass of the
+    same command (profiles/run_profiles.sh; FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), committed under profiles/.  Counters
+    cannot be read inside a timed run, so the field says "recorded" and names its file; null when no pass is committed."""
+    name = f"r03_{tag}" + (f"_{precision}" if precision else "") + "_pmc_traffic.json"
+    path = os.path.join(REPO, "profiles", name)
+    try:
+        with open(path) as f:
+            ks = json.load(f)["kernels"]
+        k = ks[kernel] if kernel else max(ks.values(), key=lambda v: v.get("hbm_bytes_per_launch", 0) * v.get("launches", 1))
+        return {"traffic": k["hbm_bytes_per_launch"], "traffic_kind": "recorded", "traffic_source": "profiles/" + name,
+                "traffic_unit": "bytes per launch (L2-miss side: FETCH_SIZE*2 + WRITE_SIZE)"}
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+
+
 def _dist_setup(args):
     """-> (rank, world, local, dist module or None, rehearse).  Ranks come from the torchrun-style environment (set by
     `torch.distributed.run` or by launch_ranks above)."""
@@ -448,7 +464,7 @@ def run_lidar_round(args):
     t.xy[:N0] = nd[:, :2]
     t.parent[:N0] = torch.arange(-1, N0 - 1, device=dev, dtype=torch.int32).clamp(min=0)
     t.parent[0] = -1
-    t.has_prev[:N0] = 1
+    t.has_prev[1:N0] = 1          # the root has no previous action (as the oracle tree)
 
     def reset_tree():
         t.counters[CNT_NODES] = N0
@@ -511,15 +527,16 @@ def run_lidar_round(args):
 def run_ant_denoise(args):
     """BASELINE config 3 (cfgs/antmaze.yaml + fm_policy, B = 4096 candidates, H = 48): the part of it that has an oracle --
     per candidate 24 chunks (action_horizon 2) x [16 x 16 @ 0.8 local map (s_global 4), ant conditioning vector incl.
-    quaternion -> rot6d, ResNet-18-GN encoder on 16 x 16, FiLM U-Net at input_dim 8 / pred_horizon 16 / cond 497, flow
-    step, un-normalise] = 24 x 1.536 GFLOP = 36.86 GFLOP.  The MuJoCo dynamics between the chunks have no oracle here and
-    are not built: the candidate states stay where they are, i.e. this is "denoiser + glue only"."""
+    quaternion -> rot6d and the 3-step history, ResNet-18-GN encoder on 16 x 16, FiLM U-Net at input_dim 8 / pred_horizon 16 /
+    cond 497, flow step, un-normalise] = 24 x 1.536 GFLOP = 36.86 GFLOP, sequenced on the device by ditree_expand_round_ant
+    (history and previous action carried between the chunks).  The MuJoCo dynamics between the chunks have no oracle here and
+    are NOT built: the observations after every env step come from a synthetic tape."""
     rank, world, local, dist, rehearse = _dist_setup(args)
     from ditreeonlineplanner_amd import _lib
     from ditreeonlineplanner_amd.model import NoisePredNet
     from ditreeonlineplanner_amd.ops import Context
     B = args.batch if args.batch_set else 4096
-    n_calls = 48 // 2
+    n_calls, A_ant = 48 // 2, 2
     prec = args.precision
     maze = load_maze("boxes")
     ctx = Context(local)
@@ -529,32 +546,31 @@ def run_ant_denoise(args):
     net.bind(ctx, precision=_lib.PREC_NAMES[prec], max_batch=B)
     rng = np.random.default_rng(20260104 + rank)
     Hh, W = maze.shape
-    obs = rng.normal(0.0, 1.0, (B, 3, 29))
     free = np.argwhere(maze[1:-1, 1:-1] == 0) + 1
     cell = free[rng.integers(0, len(free), B)]
-    obs[:, :, 0] = (((cell[:, 1] + 0.5) - W / 2) * 4.0)[:, None]
-    obs[:, :, 1] = ((Hh / 2 - (cell[:, 0] + 0.5)) * 4.0)[:, None]
-    obs[..., 2] = rng.uniform(0.4, 0.8, (B, 3))
-    q = rng.normal(size=(B, 3, 4))
-    obs[..., 3:7] = q / np.linalg.norm(q, axis=-1, keepdims=True)
-    obs_d = torch.as_tensor(obs, device=dev)
-    last = obs_d[:, -1, :].contiguous()
+    xy0 = np.stack([((cell[:, 1] + 0.5) - W / 2) * 4.0, (Hh / 2 - (cell[:, 0] + 0.5)) * 4.0], axis=1)
+
+    def obs_rows(n):
+        o = rng.normal(0.0, 1.0, (B, n, 29))
+        o[..., 0] = xy0[:, None, 0] + np.cumsum(rng.normal(0.0, 0.05, (B, n)), axis=1)
+        o[..., 1] = xy0[:, None, 1] + np.cumsum(rng.normal(0.0, 0.05, (B, n)), axis=1)
+        o[..., 2] = rng.uniform(0.4, 0.8, (B, n))
+        q = rng.normal(size=(B, n, 4))
+        o[..., 3:7] = q / np.linalg.norm(q, axis=-1, keepdims=True)
+        return o
+    hist = torch.as_tensor(obs_rows(3), device=dev)
+    tape = torch.as_tensor(obs_rows(n_calls * A_ant).reshape(B, n_calls, A_ant, 29), device=dev)
     prev = torch.as_tensor(rng.uniform(-1, 1, (B, 8)), device=dev)
     hasp = torch.ones(B, dtype=torch.uint8, device=dev)
     goal = torch.as_tensor(rng.uniform(-30, 30, (B, 2)), device=dev)
     g = torch.Generator(device="cpu").manual_seed(20260104)
-    noise = torch.randn(n_calls, B, 16, 8, generator=g).to(dev)
+    noise = torch.randn(B, n_calls, 16, 8, generator=g).to(dev)
     with open(os.path.join(REPO, "ditreeonlineplanner_amd", "data", "metadata_antmaze.json")) as f:
         md = json.load(f)
     norm = np.array(md["Observations_mean"] + md["Observations_std"] + md["Actions_mean"] + md["Actions_std"])
-    act_norm = np.array(md["Actions_mean"] + md["Actions_std"])
-    lm = torch.empty(B, 16, 16, dtype=torch.float32, device=dev)
 
     def step():
-        for j in range(n_calls):
-            ctx.local_map(last, n=16, scale=0.8, s_global=4.0, scaled=True, out=lm)
-            cond = ctx.cond_vector_ant(obs_d, prev, hasp, goal, 16, norm)
-            ctx.denoise(noise[j], lm, cond, act_norm=act_norm, want_actions=True)
+        ctx.expand_round_ant(hist, prev, hasp, goal, noise, tape, norm, action_horizon=A_ant, check_range=False)
 
     for _ in range(args.warmup):
         step()
@@ -562,6 +578,7 @@ def run_ant_denoise(args):
     elapsed = _timed(step, dataclass_replace(args, warmup=0), dist, world, dev, rehearse)
     prof = ctx.profile_read()
     ctx.profile(0)
+    ctx.check_range()                                     # f16 range guard, once for the whole loop
     comm = comm_info(dist, rehearse, dev)
     if rank == 0:
         mac = 752_250_880 + 15_749_120
@@ -569,14 +586,16 @@ def run_ant_denoise(args):
         all_ms = sum(v["ms"] for v in prof.values())
         peak = 157.3 if prec == "f32" else (PEAK_BF16_TFLOPS / 3.0 if prec in ("f16x3", "bf16x3") else PEAK_BF16_TFLOPS)
         ach = alg / (all_ms * 1e-3) / 1e12
-        res = {"metric": "candidate tree-expansions/sec (antmaze, H=48; denoiser + glue only, dynamics blocked on an oracle)",
+        res = {"metric": "candidate tree-expansions/sec (antmaze, H=48; denoiser + glue + chunk sequencing, dynamics NOT built: next observations from a tape)",
                "value": B * world * args.steps / elapsed, "unit": "candidate expansions/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": prec, "data": _data(rehearse),
                "config": {"workload": f"BASELINE config 3: cfgs/antmaze.yaml + fm_policy, batch={B} candidates per GPU, H=48 = 24 chunks x "
-                                      "[local map 16x16@0.8 s_global 4, ant cond vector (rot6d), encoder + U-Net P=16 D=8 cond 497, flow step]; "
-                                      "NO dynamics (MuJoCo: no oracle)", "batch_per_gpu": B, "calls_per_candidate": n_calls},
-               "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                                      "[local map 16x16@0.8 s_global 4, ant cond vector (rot6d, 3-step history), encoder + U-Net P=16 D=8 cond 497, "
+                                      "flow step, 2 of 16 actions kept], sequenced by ditree_expand_round_ant; NO dynamics (MuJoCo: no oracle), "
+                                      "next observations from a synthetic tape", "batch_per_gpu": B, "calls_per_candidate": n_calls},
+               "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                            **recorded_traffic("ant_denoise", prec),
                             "kernel": "all MFMA kernels of the denoiser (L = 8 / 4 levels: plain GEMM + gn1d_short_kernel, unfused; split formats: 3 MFMAs per product)",
                             "per_kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
                             "algorithmic_gflop_per_candidate": 2.0 * mac * n_calls / 1e9,
@@ -667,7 +686,7 @@ def main():
     t.xy[:N0] = nd[:, :2]
     t.parent[:N0] = torch.arange(-1, N0 - 1, device=dev, dtype=torch.int32).clamp(min=0)
     t.parent[0] = -1
-    t.has_prev[:N0] = 1
+    t.has_prev[1:N0] = 1          # the root has no previous action (as the oracle tree)
     reset_tree()
     s_dev = torch.as_tensor(samples, device=dev)
     c_dev = torch.as_tensor(cond, device=dev)

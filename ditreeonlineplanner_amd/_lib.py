@@ -55,6 +55,14 @@ class RoundParams(C.Structure):
                 ("chunk_budget", C.c_void_p)]
 
 
+class AntRoundParams(C.Structure):
+    _fields_ = [("obs_hist", C.c_void_p), ("n_hist", C.c_int32), ("prev_action", C.c_void_p), ("has_prev", C.c_void_p),
+                ("cond_goal", C.c_void_p), ("noise", C.c_void_p), ("next_obs_tape", C.c_void_p), ("n_chunks", C.c_int32),
+                ("A", C.c_int32), ("K", C.c_int32), ("t0", C.POINTER(C.c_float)), ("dt", C.POINTER(C.c_float)),
+                ("norm", C.POINTER(C.c_double)), ("act_norm", C.POINTER(C.c_double)), ("axis", C.POINTER(C.c_double)),
+                ("lm_n", C.c_int32), ("lm_size", C.c_double), ("s_global", C.c_double)]
+
+
 class MppiParams(C.Structure):
     _fields_ = [("T", C.c_int32), ("K", C.c_int32), ("lam", C.c_double), ("sigma", C.c_double * 2),
                 ("w_track", C.c_double), ("w_progress", C.c_double), ("w_collision", C.c_double), ("w_goal", C.c_double),
@@ -100,6 +108,7 @@ SIGNATURES = {
     "ditree_profile": (_i32, [_vp, _i32]),
     "ditree_profile_read": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ditree_denoise_debug_read": (_i32, [_vp, C.c_char_p, _i32, _vp, _i64, C.POINTER(_i32), _vp]),
+    "ditree_expand_round_ant": (_i32, [_vp, C.POINTER(AntRoundParams), _i32, _vp, _vp, _vp, _vp]),
     "ditree_expand_round": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), C.POINTER(RoundParams), _vp]),
 }
 

@@ -2,6 +2,8 @@
 // reference call sites each entry point replaces).
 #include <dlfcn.h>
 
+#include <algorithm>
+
 #include <cstdio>
 #include <cstring>
 
@@ -64,6 +66,8 @@ void ditree_ctx_destroy(ditree_ctx* ctx) {
   if (ctx->alive_cnt_host) hipHostFree(ctx->alive_cnt_host);
   if (ctx->path_dev) hipFree(ctx->path_dev);
   if (ctx->mppi_partial) hipFree(ctx->mppi_partial);
+  void* ant[] = {ctx->ant_hist[0], ctx->ant_hist[1], ctx->ant_prev, ctx->ant_hasprev, ctx->ant_cond, ctx->ant_lmap, ctx->ant_act};
+  for (void* q : ant) if (q) hipFree(q);
   delete ctx;
 }
 
@@ -430,6 +434,75 @@ static int ensure_scratch(ditree_ctx* ctx, int B, int lm_n, int P) {
   ctx->scratch_B = nb;
   ctx->scratch_lm = nl;
   ctx->scratch_P = np;
+  return DITREE_OK;
+}
+
+// BASELINE config 3's round without its physics: per chunk [local map -> ant conditioning vector -> denoiser -> A 8-d actions],
+// the observation history / previous action carried on the device between the chunks, next observations from a tape.
+int32_t ditree_expand_round_ant(ditree_ctx* ctx, const ditree_ant_round_params* p, int32_t B, double* actions_out,
+                                double* end_obs, float* cond_out, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!ctx->maze) return set_err(ctx, DITREE_E_STATE, "expand_round_ant: no maze uploaded");
+  if (B == 0) return DITREE_OK;
+  if (!p || !p->obs_hist || !p->prev_action || !p->has_prev || !p->cond_goal || !p->noise || !p->next_obs_tape || !p->t0 ||
+      !p->dt || !p->norm || !p->act_norm || !p->axis || !actions_out || B < 0 || p->n_hist < 1 || p->n_hist > 3 ||
+      p->n_chunks < 1 || p->A < 2 || p->K < 1)
+    return set_err(ctx, DITREE_E_ARG, "expand_round_ant: bad parameters (1 <= n_hist <= 3, action_horizon >= 2)");
+  int32_t d5[5];
+  if (ditree_denoise_dims(ctx, d5) != DITREE_OK) return DITREE_E_STATE;
+  const int P = d5[0], D = d5[1], lm = d5[2], G = d5[3];
+  if (D != 8 || G != 97 || p->lm_n != lm || p->A > P)
+    return set_err(ctx, DITREE_E_ARG, "expand_round_ant: the loaded denoiser is not the ant network (action_dim " + std::to_string(D) +
+                   ", cond " + std::to_string(G) + ", map " + std::to_string(lm) + "; need 8 / 97 / lm_n, action_horizon <= pred_horizon)");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (B > ctx->ant_B || P > ctx->ant_P || lm > ctx->ant_lm) {
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    void** ptrs[] = {(void**)&ctx->ant_hist[0], (void**)&ctx->ant_hist[1], (void**)&ctx->ant_prev, (void**)&ctx->ant_hasprev,
+                     (void**)&ctx->ant_cond, (void**)&ctx->ant_lmap, (void**)&ctx->ant_act};
+    for (auto q : ptrs) { if (*q) HIP_TRY(ctx, hipFree(*q)); *q = nullptr; }
+    const size_t nb = (size_t)std::max(B, ctx->ant_B), np = (size_t)std::max(P, ctx->ant_P), nl = (size_t)std::max(lm, ctx->ant_lm);
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_hist[0], nb * 87 * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_hist[1], nb * 87 * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_prev, nb * 8 * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_hasprev, nb));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_cond, nb * 97 * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_lmap, nb * nl * nl * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_act, nb * np * 8 * sizeof(double)));
+    ctx->ant_B = (int)nb; ctx->ant_P = (int)np; ctx->ant_lm = (int)nl;
+  }
+  AxisArg ax;
+  int rc = fill_axis(ctx, p->axis, p->lm_n, &ax);
+  if (rc) return rc;
+  AntNormArg nm;
+  for (int i = 0; i < 27; ++i) { nm.obs_mean[i] = p->norm[i]; nm.obs_std[i] = p->norm[27 + i]; }
+  for (int i = 0; i < 8; ++i) { nm.act_mean[i] = p->norm[54 + i]; nm.act_std[i] = p->norm[62 + i]; }
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->ant_prev, p->prev_action, (size_t)B * 8 * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->ant_hasprev, p->has_prev, (size_t)B, hipMemcpyDeviceToDevice, s));
+  const int nC = p->n_chunks, A = p->A;
+  const double* hist = p->obs_hist;              // (B, n, 29) view the chunk's sampler call sees
+  int n = p->n_hist;
+  for (int j = 0; j < nC; ++j) {
+    // RRT.py:158-166: the local map is cut at the chunk's start state = last row of the history (x, y, element 2)
+    launch_local_map(ctx->maze, ctx->rows, ctx->cols, hist + (size_t)(n - 1) * 29, nullptr, nullptr, B, p->lm_n, ax, p->s_global, 1,
+                     ctx->ant_lmap, s, n * 29);
+    launch_cond_vector_ant(hist, n, ctx->ant_prev, ctx->ant_hasprev, p->cond_goal, B, nm, p->lm_size, ctx->ant_cond, s);
+    if (cond_out)
+      HIP_TRY(ctx, hipMemcpy2DAsync(cond_out + (size_t)j * 97, (size_t)nC * 97 * sizeof(float), ctx->ant_cond, 97 * sizeof(float),
+                                    97 * sizeof(float), (size_t)B, hipMemcpyDeviceToDevice, s));
+    rc = denoise_run(ctx, p->noise + (size_t)j * P * 8, (int64_t)nC * P * 8, nullptr, ctx->ant_lmap, ctx->ant_cond, B, p->K, p->t0,
+                     p->dt, p->act_norm, ctx->ant_act, nullptr, s);
+    if (rc) return rc;
+    double* nxt = ctx->ant_hist[j & 1];
+    launch_ant_advance(hist, n, p->next_obs_tape + (size_t)j * A * 29, (int64_t)nC * A * 29, A, ctx->ant_act, P, nxt, ctx->ant_prev,
+                       ctx->ant_hasprev, actions_out + (size_t)j * A * 8, (int64_t)nC * A * 8, B, s);
+    hist = nxt;
+    n = 3;
+  }
+  if (end_obs)
+    HIP_TRY(ctx, hipMemcpy2DAsync(end_obs, 29 * sizeof(double), hist + 2 * 29, 87 * sizeof(double), 29 * sizeof(double), (size_t)B,
+                                  hipMemcpyDeviceToDevice, s));
+  HIP_TRY(ctx, hipGetLastError());
   return DITREE_OK;
 }
 

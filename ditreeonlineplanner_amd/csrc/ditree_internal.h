@@ -45,6 +45,15 @@ struct ditree_ctx {
   int32_t* alive_cnt_host = nullptr;  // pinned host copy
   double* path_dev = nullptr;       // reference path xy for the fallback selection
   int path_cap = 0;
+  // ant round scratch (ditree_expand_round_ant): two (B, 3, 29) history buffers, (B, 8) previous action, flags, (B, 97) cond
+  int ant_B = 0;
+  double* ant_hist[2] = {nullptr, nullptr};
+  double* ant_prev = nullptr;
+  uint8_t* ant_hasprev = nullptr;
+  float* ant_cond = nullptr;
+  float* ant_lmap = nullptr;
+  double* ant_act = nullptr;
+  int ant_P = 0, ant_lm = 0;
   double* mppi_partial = nullptr;   // partial sums of the MPPI update (ditree_mppi_step)
   DenoiserState* dn = nullptr;
   // optional RCCL communicator (ditree_comm_*): librccl opened at run time
@@ -75,6 +84,9 @@ void launch_cond_vector_ant(const double* obs, int n_hist, const double* prev_ac
 void launch_cond_vector(const double* state, const double* prev_action, const uint8_t* has_prev,
                         const double* cond_goal, const int32_t* idx, int B, const NormArg& nm, double lm_size,
                         float* out, hipStream_t s);
+void launch_ant_advance(const double* hist_in, int n_in, const double* tape, int64_t tape_stride, int A, const double* act64, int P,
+                        double* hist_out, double* prev_action, uint8_t* has_prev, double* actions_out, int64_t actout_stride,
+                        int B, hipStream_t s);
 void launch_compact_alive(const int32_t* status, int B, int32_t* idx_out, int32_t* count, hipStream_t s,
                           const int32_t* budget = nullptr, int next_chunk = 0);
 void launch_chunk_budget(const int32_t* parent, int B, const int32_t* num_visit, const int32_t* chunks, int n,

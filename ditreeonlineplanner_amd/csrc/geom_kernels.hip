@@ -234,6 +234,42 @@ void launch_cond_vector_ant(const double* obs, int n_hist, const double* prev_ac
                      cond_goal, B, nm, lm_size, out);
 }
 
+// ------------------------------------------------------------------------- ant round: advance one chunk
+// The part of planners/RRT.py:176-188 an ant chunk has besides the MuJoCo step, which has no oracle here and is not built:
+// `prev_states = curr_states_seq` (the chunk's A + 1 states; the sampler keeps the last three, fm_policy.py:96-102),
+// `prev_actions = curr_action_seq` (its last row conditions the next call, :113-123), and the edge's action rows.  The next
+// observations come from a TAPE (test infrastructure, the ant analogue of inject_actions).
+//   hist_in (B, n_in, 29): history the chunk's sampler call saw, its last row is the chunk's start state;
+//   tape (B, tape_stride): A rows of 29 for this chunk;  hist_out (B, 3, 29): last three rows of [start, tape rows];
+//   n_out = min(3, A + 1) valid rows are written at the END of hist_out's 3 slots when A + 1 < 3 -- the caller passes
+//   hist_out + (3 - n_out) * 29 as the next (B, n_out, 29) view with stride 3 * 29 ... kept simple: A >= 2 is required.
+__global__ void ant_advance_kernel(const double* __restrict__ hist_in, int n_in, const double* __restrict__ tape,
+                                   int64_t tape_stride, int A, const double* __restrict__ act64, int P, double* __restrict__ hist_out,
+                                   double* __restrict__ prev_action, uint8_t* __restrict__ has_prev,
+                                   double* __restrict__ actions_out, int64_t actout_stride, int B) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const double* start = hist_in + ((size_t)b * n_in + (n_in - 1)) * 29;
+  const double* tp = tape + (size_t)b * tape_stride;
+  // rows of the chunk's state sequence: r = 0 start, r = 1..A tape rows; keep r = A - 2 .. A
+  for (int e = threadIdx.x; e < 3 * 29; e += blockDim.x) {
+    const int slot = e / 29, k = e - slot * 29;
+    const int r = A - 2 + slot;
+    const double v = r == 0 ? start[k] : tp[(size_t)(r - 1) * 29 + k];
+    hist_out[(size_t)b * 87 + e] = v;
+  }
+  for (int e = threadIdx.x; e < A * 8; e += blockDim.x)
+    actions_out[(size_t)b * actout_stride + e] = act64[(size_t)b * P * 8 + e];
+  if (threadIdx.x < 8) prev_action[(size_t)b * 8 + threadIdx.x] = act64[(size_t)b * P * 8 + (size_t)(A - 1) * 8 + threadIdx.x];
+  if (threadIdx.x == 0) has_prev[b] = 1;
+}
+void launch_ant_advance(const double* hist_in, int n_in, const double* tape, int64_t tape_stride, int A, const double* act64, int P,
+                        double* hist_out, double* prev_action, uint8_t* has_prev, double* actions_out, int64_t actout_stride,
+                        int B, hipStream_t s) {
+  hipLaunchKernelGGL(ant_advance_kernel, dim3(B), dim3(128), 0, s, hist_in, n_in, tape, tape_stride, A, act64, P, hist_out,
+                     prev_action, has_prev, actions_out, actout_stride, B);
+}
+
 // ------------------------------------------------------------------------- rollout
 // planners/base_planner.py:257-320 + car_env.py:240-282,341-396 + common/map_utils.py:103-115 for a batch of candidates.
 // One lane per candidate: the A Euler steps with their goal + two-ball collision tests are a sequential FP64 chain of

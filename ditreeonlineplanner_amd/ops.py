@@ -304,6 +304,50 @@ def _ctx_denoise(self, noise, local_map, cond, t0=None, dt=None, act_norm=None, 
     return actions if want_actions else xout
 
 
+def _ctx_expand_round_ant(self, obs_hist, prev_action, has_prev, cond_goal, noise, next_obs_tape, norm, act_norm=None,
+                          action_horizon=2, local_map_size=16, local_map_scale=0.8, s_global=4.0, t0=None, dt=None,
+                          want_cond=False, check_range=True):
+    """The ant chunk loop WITHOUT its physics (include/ditree.h ditree_expand_round_ant): obs_hist (B, 1..3, 29) f64,
+    prev_action (B, 8) f64, has_prev (B,) u8, cond_goal (B, 2) f64, noise (B, n_chunks, P, 8) f32, next_obs_tape
+    (B, n_chunks, A, 29) f64 [device tensors].  -> (actions (B, n_chunks, A, 8) f64, end_obs (B, 29) f64[, cond (B, n_chunks, 97)])."""
+    dev = self.device
+    for nm, t, dt_ in (("obs_hist", obs_hist, torch.float64), ("prev_action", prev_action, torch.float64),
+                       ("has_prev", has_prev, torch.uint8), ("cond_goal", cond_goal, torch.float64),
+                       ("noise", noise, torch.float32), ("next_obs_tape", next_obs_tape, torch.float64)):
+        _chk(t, dt_, nm, dev)
+    B = obs_hist.shape[0]
+    P, D, lm, G, _ = self.denoise_dims()
+    nC, A = int(noise.shape[1]), int(action_horizon)
+    if obs_hist.dim() != 3 or obs_hist.shape[2] != 29 or not 1 <= obs_hist.shape[1] <= 3:
+        raise ValueError("obs_hist must be (B, 1..3, 29)")
+    if tuple(noise.shape) != (B, nC, P, 8) or tuple(next_obs_tape.shape) != (B, nC, A, 29) or tuple(prev_action.shape) != (B, 8):
+        raise ValueError(f"noise must be ({B}, n_chunks, {P}, 8), next_obs_tape ({B}, n_chunks, {A}, 29), prev_action ({B}, 8)")
+    p = _lib.AntRoundParams()
+    p.obs_hist, p.n_hist = obs_hist.data_ptr(), int(obs_hist.shape[1])
+    p.prev_action, p.has_prev, p.cond_goal = prev_action.data_ptr(), has_prev.data_ptr(), cond_goal.data_ptr()
+    p.noise, p.next_obs_tape = noise.data_ptr(), next_obs_tape.data_ptr()
+    p.n_chunks, p.A = nC, A
+    t0 = np.zeros(1, dtype=np.float32) if t0 is None else t0
+    dt = np.ones(1, dtype=np.float32) if dt is None else dt
+    t0a, p.t0 = _flt(t0)
+    dta, p.dt = _flt(dt)
+    p.K = len(t0a)
+    nma, p.norm = _dbl(norm)
+    if nma.size != 70:
+        raise ValueError("norm: 27 + 27 + 8 + 8 doubles")
+    ana, p.act_norm = _dbl(nma[54:70] if act_norm is None else act_norm)
+    axa, p.axis = _dbl(local_axis(local_map_size, local_map_scale))
+    p.lm_n, p.lm_size, p.s_global = int(local_map_size), float(local_map_size), float(s_global)
+    actions = torch.empty(B, nC, A, 8, dtype=torch.float64, device=dev)
+    end_obs = torch.empty(B, 29, dtype=torch.float64, device=dev)
+    cond = torch.empty(B, nC, 97, dtype=torch.float32, device=dev) if want_cond else None
+    check(self._h, lib().ditree_expand_round_ant(self._h, C.byref(p), B, _ptr(actions), _ptr(end_obs), _ptr(cond), self.stream),
+          "expand_round_ant")
+    if check_range:
+        self.check_range()
+    return (actions, end_obs, cond) if want_cond else (actions, end_obs)
+
+
 def _ctx_denoise_eval(self, sample, local_map, cond, timestep, reuse_encoder=False, check_range=True):
     """One raw network evaluation net(sample, map, timestep, cond) -> (B,P,D) f32 (the DDPM branch's model call)."""
     dev = self.device
@@ -353,6 +397,7 @@ Context.denoise = _ctx_denoise
 Context.denoise_eval = _ctx_denoise_eval
 Context.debug_read = _ctx_debug_read
 Context.denoise_dims = _ctx_denoise_dims
+Context.expand_round_ant = _ctx_expand_round_ant
 Context.denoise_status = _ctx_denoise_status
 Context.check_range = _ctx_check_range
 Context._check_denoiser_shapes = _ctx_check_denoiser_shapes

@@ -390,6 +390,40 @@ int32_t ditree_chunk_budget(ditree_ctx* ctx, const ditree_tree* tree, const doub
 int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
                             const ditree_round_params* p, void* stream);
 
+/* The chunk loop of planners/RRT.py:157-194 for the ANT (cfgs/antmaze.yaml: action_horizon 2, edge length 48 = 24 chunks,
+ * pred_horizon 16, obs_history 3; run_scenarios.py:123-132) WITHOUT its physics: the env step is MuJoCo through
+ * gymnasium-robotics (planners/base_planner.py:81-92,278-298), which has no oracle in this build and is NOT implemented.
+ * What is: per chunk [create_local_map at the chunk's start state (stride-29 observations, 16 x 16 @ 0.8, s_global 4) ->
+ * ant conditioning vector incl. quaternion -> rot6d and the 3-step history (policies/fm_policy.py:77-143) -> denoiser
+ * (input_dim 8) -> un-normalised 8-d actions, the first action_horizon rows kept], with `prev_states = curr_states_seq` and
+ * `prev_actions = curr_action_seq` (RRT.py:186-188) carried on the device.  The observations after every env step come
+ * from `next_obs_tape` -- test / measurement infrastructure, the ant analogue of ditree_round_params.inject_actions.
+ * The loaded denoiser must be the ant network (action_dim 8, cond 97).  No collision / goal tests (they need the physics):
+ * every candidate runs all chunks. */
+typedef struct {
+  const double* obs_hist;        /* [dev] (B, n_hist, 29): states the first sampler call sees (parent edge's last rows) */
+  int32_t n_hist;                /* 1..3 */
+  const double* prev_action;     /* [dev] (B, 8) last action of the parent edge */
+  const uint8_t* has_prev;       /* [dev] (B,) */
+  const double* cond_goal;       /* [dev] (B, 2) */
+  const float* noise;            /* [dev] (B, n_chunks, P, 8) f32 */
+  const double* next_obs_tape;   /* [dev] (B, n_chunks, A, 29) f64: the observation after every env step */
+  int32_t n_chunks, A;           /* edge_length / action_horizon, action_horizon (>= 2) */
+  int32_t K;                     /* flow steps */
+  const float* t0;               /* [host] K */
+  const float* dt;               /* [host] K */
+  const double* norm;            /* [host] 70: obs_mean[27], obs_std[27], act_mean[8], act_std[8] (ditree_cond_vector_ant) */
+  const double* act_norm;        /* [host] 16: act_mean[8], act_std[8] of the un-normalisation */
+  const double* axis;            /* [host] local-map axis, lm_n doubles */
+  int32_t lm_n;                  /* local_map_size (16) */
+  double lm_size;                /* divisor of the goal conditioning */
+  double s_global;               /* 4 */
+} ditree_ant_round_params;
+/* actions_out [dev] (B, n_chunks, A, 8) f64; end_obs [dev] (B, 29) or NULL; cond_out [dev] (B, n_chunks, 97) f32 or NULL (the
+ * conditioning vector of every sampler call, for tests). */
+int32_t ditree_expand_round_ant(ditree_ctx* ctx, const ditree_ant_round_params* p, int32_t B, double* actions_out,
+                                double* end_obs, float* cond_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -163,7 +163,7 @@ def run_engine(ctx, onet, st, prec):
     t.xy[:N0] = nd[:, :2]
     t.parent[:N0] = torch.arange(-1, N0 - 1, device=dev, dtype=torch.int32).clamp(min=0)
     t.parent[0] = -1
-    t.has_prev[:N0] = 1
+    t.has_prev[1:N0] = 1          # the root has no previous action (as the oracle tree)
     t.counters[CNT_NODES] = N0
     t.counters[CNT_GOAL] = -1
     t.counters[CNT_LATCH] = 0
