@@ -14,6 +14,8 @@ when N > 1).  Per-GPU batch is fixed (weak scaling); every candidate runs all 4 
 
 Other workloads of BASELINE.json's config list (each prints its own one-line JSON with `roofline`):
     --workload rollout       config 5: 65 536 car rollouts x T = 16 steps, the rollout kernel alone (no denoiser)
+    --workload mppi          config 5: 65 536 MPPI rollouts (the build's own controller: costs, soft-min update, executed step),
+                             sharded over --gpus N with two tiny all-reduces per controller step
     --workload lidar-round   config 4: a round of 8 192 candidates + one 181-ray lidar scan per candidate end pose
     --workload ant-denoise   config 3: the ant-sized denoiser + glue, 4 096 candidates x 24 calls (dynamics blocked on an oracle)
     --workload geometry      the geometry kernels alone (NN, local map, cond vector, rollout chunk, lidar) with GB/s each
@@ -353,6 +355,101 @@ def run_rollout(args):
         dist.destroy_process_group()
 
 
+def run_mppi(args):
+    """BASELINE config 5 -- "65 536 MPPI rollouts sharded over 8 x MI355X, pure-rollout stress, no diffusion" -- with the
+    build's own MPPI controller (the reference ships none: PARITY UNPINNED, include/ditree.h ditree_mppi_step).  One step =
+    one controller step: K rollouts x T = 16 [car dynamics, two-ball collision, goal test, nearest reference-path point],
+    costs, soft-min weights, weighted control update, one executed env step.  --gpus N shards the K GLOBAL rollouts over the
+    ranks (two all-reduces of 1 and 3 + 2T doubles per step: strong scaling); default K = 65 536 per node.
+    Roofline of the dominant kernel (mppi_rollout_kernel): it is an FP64 chain with on-device noise -- algorithmic HBM bytes
+    are the K costs + flags it writes (12 B per rollout) -- so the `hbm` fraction is tiny by design; the governing unit is the
+    FP64 vector pipe, reported next to it as `fp64`."""
+    rank, world, local, dist, rehearse = _dist_setup(args)
+    from ditreeonlineplanner_amd import _lib
+    from ditreeonlineplanner_amd.mppi import MPPI
+    from ditreeonlineplanner_amd.ops import Context
+    K = args.global_batch or (args.batch if args.batch_set else 65536)
+    T = args.horizon or 16
+    maze = load_maze("boxes")
+    ctx = Context(local)
+    dev = ctx.device
+    Hh, W = maze.shape
+    xy = lambda r, c: np.array([(c + 0.5) - W / 2, Hh / 2 - (r + 0.5)])              # noqa: E731
+    a_, b_, c_ = xy(18, 1), xy(18, 18), xy(1, 18)
+    seg1 = a_ + (b_ - a_) * np.linspace(0, 1, 850)[:, None]
+    seg2 = b_ + (c_ - b_) * np.linspace(0, 1, 850)[1:, None]
+    path = np.concatenate([seg1, seg2])
+    m = MPPI(maze_data=maze, T=T, K=K, nx=6, nu=2, seed=20260104, ctx=ctx, rank=rank, world_size=world)
+    start = np.array([path[0, 0], path[0, 1], 0.0, 0.0, 0.0, 0.0])
+    m.reset(start_state=start, goal_state=np.array([c_[0], c_[1], 0, 0, 0, 0.0]))
+    m.set_ref_path(path)
+    state = [start]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    it = [0]
+
+    def allred(t, op):                                   # RCCL on the device; through the host in the one-GPU rehearsal (gloo)
+        if rehearse:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+
+    def step():
+        # the driver's loop: step() returns the next state to the host (one 64-byte D2H + sync per controller step)
+        timed = it[0] >= args.warmup
+        m._state.copy_(torch.as_tensor(state[0]))
+        if timed:
+            ev[it[0] - args.warmup][0].record()
+        m.launch(_lib.MPPI_ROLLOUTS)                       # the dominant kernel, bracketed on its own
+        if timed:
+            ev[it[0] - args.warmup][1].record()
+        if world > 1:
+            m.launch(_lib.MPPI_MIN)
+            allred(m._result[3:4], dist.ReduceOp.MIN)
+            m.launch(_lib.MPPI_SUMS)
+            allred(m._sums, dist.ReduceOp.SUM)
+            m.launch(_lib.MPPI_APPLY | _lib.MPPI_EXECUTE)
+        else:
+            m.launch(_lib.MPPI_MIN | _lib.MPPI_SUMS | _lib.MPPI_APPLY | _lib.MPPI_EXECUTE)
+        m.counter += 1
+        res = m._result.cpu().numpy()
+        if int(res[2]) != 2:
+            state[0] = m._state.cpu().numpy().copy()
+        it[0] += 1
+
+    elapsed = _timed(step, args, dist, world, dev, rehearse)
+    comm = comm_info(dist, rehearse, dev)
+    if rank == 0:
+        k_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+        Kloc = m.K_local
+        alg = Kloc * 12 + 48 + 32 * T + len(path) * 16
+        ach = alg / (k_ms * 1e-3) / 1e9
+        # FP64 work of a rollout step (counted from the kernel source, fma = 2): dynamics ~60 + 3 sin/cos pairs + tanh (~40 each)
+        # + two-ball collision ~2 x 60 + goal 6 + path window 64 points x 7 + noise hash / Box-Muller ~120  ->  ~900 flop
+        flop = Kloc * T * 900.0
+        res = {"metric": "MPPI rollouts/sec (controller step: K x T=16 car rollouts with collision / goal / path-tracking cost, soft-min update, one executed step)",
+               "value": K * args.steps / elapsed, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f64", "data": _data(rehearse),
+               "config": {"workload": f"BASELINE config 5: {K} MPPI rollouts (global) x T={T}, car model on boxes.csv, L-shaped reference path of "
+                                      f"{len(path)} points, on-device noise; the build's own controller (the reference ships no MPPI module: parity unpinned)",
+                          "rollouts_global": K, "rollouts_per_gpu": Kloc, "horizon": T,
+                          "parallelism": f"rollouts sharded x{world}; all-reduce MIN (1 double) + SUM ({3 + 2 * T} doubles) per step"},
+               "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                            **recorded_traffic("mppi", kernel="mppi_rollout_kernel"), "kernel": "mppi_rollout_kernel<4>",
+                            "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": alg, "kernel_time_share": k_ms * 1e-3 * args.steps / elapsed,
+                            "fp64": {"achieved_tflops": flop / (k_ms * 1e-3) / 1e12, "peak_tflops": 78.6,
+                                     "frac": flop / (k_ms * 1e-3) / 1e12 / 78.6, "flop_per_rollout_step": 900,
+                                     "note": "the governing unit: a sequential FP64 chain per rollout (4 lanes share one rollout); flop count from the source, fma = 2"},
+                            "note": "noise is generated on the device: the kernel writes 12 B per rollout and reads ~30 KB of shared inputs per work-group out of L2"},
+               "controller": {"state_xy": [float(state[0][0]), float(state[0][1])], **m.last}, **comm}
+        res["controller"].update({"collided_rollouts_last_step": int(m._result[6].item()), "effective_samples_last_step": float(m._result[7].item())})
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def run_geometry(args):
     """The geometry kernels of the path measured alone (HBM-bound nominally): nearest node, local map,
     conditioning vector, lidar scan, rollout chunk (A = 8), accept -- at the config-4 round size (8192 candidates, 65 536-node
@@ -615,7 +712,7 @@ def dataclass_replace(args, **kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="expand", choices=["expand", "rollout", "lidar-round", "ant-denoise", "geometry"])
+    ap.add_argument("--workload", default="expand", choices=["expand", "rollout", "mppi", "lidar-round", "ant-denoise", "geometry"])
     ap.add_argument("--global-batch", type=int, default=0,
                     help="fixed GLOBAL round size split over the GPUs (strong scaling); default: --batch per GPU (weak)")
     ap.add_argument("--horizon", type=int, default=0, help="rollout workload: steps per rollout (default 16)")
@@ -642,6 +739,8 @@ def main():
         return run_dry(args)
     if args.workload == "rollout":
         return run_rollout(args)
+    if args.workload == "mppi":
+        return run_mppi(args)
     if args.workload == "lidar-round":
         return run_lidar_round(args)
     if args.workload == "ant-denoise":

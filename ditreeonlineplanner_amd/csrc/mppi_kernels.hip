@@ -37,7 +37,7 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
 }
 
 // eps[k, t, :] ~ N(0, diag(sigma^2)): counter-based, a pure function of (seed, counter, k, t)
-__device__ __forceinline__ void mppi_noise(unsigned long long seed, unsigned long long counter, int k, int t, double s0,
+__device__ __forceinline__ void mppi_noise(unsigned long long seed, unsigned long long counter, long long k, int t, double s0,
                                            double s1, double& e0, double& e1) {
   unsigned long long h = splitmix64(seed ^ splitmix64(counter));
   h = splitmix64(h ^ ((unsigned long long)k * 0xD1B54A32D192ED03ull));
@@ -57,6 +57,7 @@ struct MppiArgs {
   unsigned long long seed, counter;
   int wback, wfwd;
   double gx, gy;
+  long long k0;                       // global index of this rank's first rollout (sharded controller)
 };
 
 template <int G> __device__ __forceinline__ double quad_min(double v) {
@@ -154,9 +155,9 @@ mppi_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, 
   int flag = 0;                                        // 1 = reached the goal, 2 = collided
   for (int t = 0; t < a.T; ++t) {
     double e0 = 0.0, e1 = 0.0;
-    if (k > 0) {                                       // rollout 0 is the noise-free nominal sequence
+    if (a.k0 + k > 0) {                                // GLOBAL rollout 0 is the noise-free nominal sequence
       if (noise != nullptr) { e0 = noise[((size_t)k * a.T + t) * 2]; e1 = noise[((size_t)k * a.T + t) * 2 + 1]; }
-      else mppi_noise(a.seed, a.counter, k, t, a.s0, a.s1, e0, e1);
+      else mppi_noise(a.seed, a.counter, a.k0 + k, t, a.s0, a.s1, e0, e1);
     }
     const double u0 = s_U[2 * t], u1 = s_U[2 * t + 1];
     car_euler_step(s, u0 + e0, u1 + e1);
@@ -230,9 +231,9 @@ mppi_partial_kernel(const double* __restrict__ costs, const double* __restrict__
     if (lane0) { red[wv][0] += sw; red[wv][1] += sw2; }
     for (int t = 0; t < a.T; ++t) {
       double e0 = 0.0, e1 = 0.0;
-      if (valid && k > 0) {
+      if (valid && a.k0 + k > 0) {
         if (noise != nullptr) { e0 = noise[((size_t)k * a.T + t) * 2]; e1 = noise[((size_t)k * a.T + t) * 2 + 1]; }
-        else mppi_noise(a.seed, a.counter, k, t, a.s0, a.s1, e0, e1);
+        else mppi_noise(a.seed, a.counter, a.k0 + k, t, a.s0, a.s1, e0, e1);
       }
       const double v0 = wave_sum(w * e0), v1 = wave_sum(w * e1);
       if (lane0) { red[wv][2 + 2 * t] += v0; red[wv][3 + 2 * t] += v1; }
@@ -243,36 +244,41 @@ mppi_partial_kernel(const double* __restrict__ costs, const double* __restrict__
     partial[(size_t)blockIdx.x * nacc + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
 }
 
+// sums [3 + 2T] = {eta = sum w, sum w^2, collided rollouts, sum_k w_k eps[k, t, d]}: the quantities a sharded controller
+// all-reduces (SUM) between its ranks.  do_sums: ordered sum of the slices -> sums;  do_apply: U += sums[3..] / eta, weights
+// normalised, result[4], [6], [7];  do_execute: one env step with U[0], shift.
 __global__ void __launch_bounds__(256)
 mppi_finish_kernel(const unsigned char* __restrict__ maze, int rows, int cols, const double* __restrict__ partial, int slices,
                    MppiArgs a, double* __restrict__ state_io, double* __restrict__ U, double* __restrict__ weights,
-                   const int32_t* __restrict__ flags, double* __restrict__ result, int do_update, int do_execute) {
-  __shared__ double tot[2 + 2 * MPPI_MAX_T];
+                   const int32_t* __restrict__ flags, double* __restrict__ sums, double* __restrict__ result, int do_sums,
+                   int do_apply, int do_execute) {
   __shared__ int cnt;
   const int nacc = 2 + 2 * a.T;
-  if (do_update) {
+  if (do_sums) {
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
     for (int j = threadIdx.x; j < nacc; j += 256) {
       double v = 0.0;
       for (int s = 0; s < slices; ++s) v += partial[(size_t)s * nacc + j];     // slice order
-      tot[j] = v;
+      sums[j < 2 ? j : j + 1] = v;
     }
+    int c = 0;
+    if (flags != nullptr)
+      for (int k = threadIdx.x; k < a.K; k += 256) c += flags[k] == 2;
+    atomicAdd(&cnt, c);
     __syncthreads();
-    const double eta = tot[0];
-    for (int j = threadIdx.x; j < 2 * a.T; j += 256) U[j] = U[j] + tot[2 + j] / eta;
+    if (threadIdx.x == 0) sums[2] = (double)cnt;
+    __syncthreads();
+  }
+  if (do_apply) {
+    const double eta = sums[0];
+    for (int j = threadIdx.x; j < 2 * a.T; j += 256) U[j] = U[j] + sums[3 + j] / eta;
     if (weights != nullptr)
       for (int k = threadIdx.x; k < a.K; k += 256) weights[k] = weights[k] / eta;
     if (threadIdx.x == 0) {
       result[4] = eta;
-      result[7] = (eta * eta) / tot[1];                                         // effective sample size
-    }
-    if (flags != nullptr) {
-      if (threadIdx.x == 0) cnt = 0;
-      __syncthreads();
-      int c = 0;
-      for (int k = threadIdx.x; k < a.K; k += 256) c += flags[k] == 2;
-      atomicAdd(&cnt, c);
-      __syncthreads();
-      if (threadIdx.x == 0) result[6] = (double)cnt;
+      result[6] = sums[2];
+      result[7] = (eta * eta) / sums[1];                                        // effective sample size
     }
     __syncthreads();
   }
@@ -303,13 +309,14 @@ mppi_finish_kernel(const unsigned char* __restrict__ maze, int rows, int cols, c
 extern "C" int32_t ditree_mppi_step(ditree_ctx* ctx, const ditree_mppi_params* p, double* state_io, double* U_io,
                                     const double* path_xy, int32_t P, const double* goal_xy, const double* noise,
                                     uint64_t counter, int32_t stages, double* costs, double* weights, int32_t* flags,
-                                    double* result, void* stream) {
+                                    double* sums, double* result, void* stream) {
   if (!ctx) return DITREE_E_ARG;
   if (!ctx->maze) return set_err(ctx, DITREE_E_STATE, "mppi_step: no maze uploaded");
-  if (!p || !state_io || !U_io || !path_xy || !goal_xy || !costs || !result || p->T < 1 || p->T > MPPI_MAX_T || p->K < 1 ||
-      P < 1 || P > MPPI_MAX_P || !(p->lambda > 0.0) || !(p->sigma[0] > 0.0) || !(p->sigma[1] > 0.0) || p->window_back < 0 ||
-      p->window_fwd < 0 || (stages & ~7) != 0 || stages == 0)
-    return set_err(ctx, DITREE_E_ARG, "mppi_step: bad argument (1 <= T <= 64, 1 <= P <= 4096, lambda, sigma > 0, stages 1..7)");
+  if (!p || !state_io || !U_io || !path_xy || !goal_xy || !costs || !result || !sums || p->T < 1 || p->T > MPPI_MAX_T ||
+      p->K < 1 || P < 1 || P > MPPI_MAX_P || !(p->lambda > 0.0) || !(p->sigma[0] > 0.0) || !(p->sigma[1] > 0.0) ||
+      p->window_back < 0 || p->window_fwd < 0 || (stages & ~DITREE_MPPI_ALL) != 0 || stages == 0 || p->k_offset < 0)
+    return set_err(ctx, DITREE_E_ARG, "mppi_step: bad argument (1 <= T <= 64, 1 <= P <= 4096, lambda, sigma > 0, stages 1..31)");
+  if (p->lanes != 0 && p->lanes != 1 && p->lanes != 4) return set_err(ctx, DITREE_E_ARG, "mppi_step: lanes must be 0, 1 or 4");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   MppiArgs a;
@@ -319,14 +326,11 @@ extern "C" int32_t ditree_mppi_step(ditree_ctx* ctx, const ditree_mppi_params* p
   a.seed = p->seed; a.counter = counter;
   a.wback = p->window_back; a.wfwd = p->window_fwd;
   a.gx = goal_xy[0]; a.gy = goal_xy[1];
-  const int nacc = 2 + 2 * a.T;
+  a.k0 = p->k_offset;
   const int slices = std::min(MPPI_SLICES, (a.K + 255) / 256);      // 256 rollouts per slice up to 65 536, more beyond
-  if (stages & 6) {
-    const size_t need = (size_t)MPPI_SLICES * (2 + 2 * MPPI_MAX_T) * sizeof(double);
-    if (!ctx->mppi_partial) HIP_TRY(ctx, hipMalloc((void**)&ctx->mppi_partial, need));
-  }
-  if (stages & 1) {
-    if (p->lanes != 0 && p->lanes != 1 && p->lanes != 4) return set_err(ctx, DITREE_E_ARG, "mppi_step: lanes must be 0, 1 or 4");
+  if ((stages & (DITREE_MPPI_SUMS)) && !ctx->mppi_partial)
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->mppi_partial, (size_t)MPPI_SLICES * (2 + 2 * MPPI_MAX_T) * sizeof(double)));
+  if (stages & DITREE_MPPI_ROLLOUTS) {
     const size_t lds = (size_t)P * 16 + (size_t)a.T * 16 + 128 + (((size_t)ctx->rows * ctx->cols + 15) & ~(size_t)15);
     if (lds > 160 * 1024) return set_err(ctx, DITREE_E_ARG, "mppi_step: path + maze exceed the LDS");
     const int G = p->lanes == 1 ? 1 : 4;
@@ -345,13 +349,13 @@ extern "C" int32_t ditree_mppi_step(ditree_ctx* ctx, const ditree_mppi_params* p
       hipLaunchKernelGGL(mppi_rollout_kernel<1>, grid, block, lds, s, ctx->maze, ctx->rows, ctx->cols, state_io, U_io,
                          (const double2*)path_xy, noise, a, costs, flags, result);
   }
-  if (stages & 2) {
-    hipLaunchKernelGGL(mppi_min_kernel, dim3(1), dim3(256), 0, s, costs, a.K, result);
+  if (stages & DITREE_MPPI_MIN) hipLaunchKernelGGL(mppi_min_kernel, dim3(1), dim3(256), 0, s, costs, a.K, result);
+  if (stages & DITREE_MPPI_SUMS)
     hipLaunchKernelGGL(mppi_partial_kernel, dim3(slices), dim3(256), 0, s, costs, noise, a, result, ctx->mppi_partial, weights);
-  }
-  if (stages & 6)
+  if (stages & (DITREE_MPPI_SUMS | DITREE_MPPI_APPLY | DITREE_MPPI_EXECUTE))
     hipLaunchKernelGGL(mppi_finish_kernel, dim3(1), dim3(256), 0, s, ctx->maze, ctx->rows, ctx->cols, ctx->mppi_partial, slices,
-                       a, state_io, U_io, weights, flags, result, (stages & 2) ? 1 : 0, (stages & 4) ? 1 : 0);
+                       a, state_io, U_io, weights, flags, sums, result, (stages & DITREE_MPPI_SUMS) ? 1 : 0,
+                       (stages & DITREE_MPPI_APPLY) ? 1 : 0, (stages & DITREE_MPPI_EXECUTE) ? 1 : 0);
   HIP_TRY(ctx, hipGetLastError());
   return DITREE_OK;
 }

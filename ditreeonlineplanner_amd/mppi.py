@@ -28,7 +28,8 @@ from .ops import default_context
 
 class MPPI:
     def __init__(self, maze_data=None, T=16, K=1024, nx=6, nu=2, lam=1.0, sigma=(3.0, 0.6), w_track=20.0, w_progress=0.5,
-                 w_collision=1.0e3, w_goal=50.0, window_back=8, window_fwd=56, seed=0, lanes=0, ctx=None, env=None, **kw):
+                 w_collision=1.0e3, w_goal=50.0, window_back=8, window_fwd=56, seed=0, lanes=0, ctx=None, env=None,
+                 rank=None, world_size=None, process_group=None, **kw):
         if maze_data is None:
             raise ValueError("MPPI needs the known maze (maze_data)")
         if nx != 6 or nu != 2:
@@ -36,19 +37,31 @@ class MPPI:
         if not (1 <= int(T) <= 64) or int(K) < 1:
             raise ValueError("1 <= T <= 64, K >= 1")
         self.T, self.K, self.nx, self.nu = int(T), int(K), nx, nu
+        # K is the GLOBAL number of rollouts; with world_size > 1 (one process per GPU) every rank runs a contiguous block
+        from .engine import default_shard
+        d_rank, d_world, d_pg = default_shard()
+        self.world = int(d_world if world_size is None else world_size)
+        self.rank = int((d_rank if self.world == d_world else 0) if rank is None else rank)
+        self.pg = d_pg if process_group is None else process_group
+        per = (self.K + self.world - 1) // self.world
+        self.k_lo = min(self.rank * per, self.K)
+        self.K_local = max(min(self.k_lo + per, self.K) - self.k_lo, 0)
+        if self.K_local < 1:
+            raise ValueError("fewer rollouts than ranks")
         self.ctx = ctx or default_context()
         self.env = env if env is not None else CarEnv(maze_map=np.asarray(maze_data), collision_checking=False, ctx=self.ctx)
         self.maze = np.float32(maze_data)
-        self.params = _lib.MppiParams(self.T, self.K, float(lam), (C.c_double * 2)(float(sigma[0]), float(sigma[1])),
+        self.params = _lib.MppiParams(self.T, self.K_local, float(lam), (C.c_double * 2)(float(sigma[0]), float(sigma[1])),
                                       float(w_track), float(w_progress), float(w_collision), float(w_goal), int(seed),
-                                      int(window_back), int(window_fwd), int(lanes))
+                                      int(window_back), int(window_fwd), int(lanes), int(self.k_lo))
         dev = self.ctx.device
         f64 = torch.float64
         self._state = torch.zeros(6, dtype=f64, device=dev)
         self._U = torch.zeros(self.T, 2, dtype=f64, device=dev)
-        self._costs = torch.zeros(self.K, dtype=f64, device=dev)
-        self._flags = torch.zeros(self.K, dtype=torch.int32, device=dev)
+        self._costs = torch.zeros(self.K_local, dtype=f64, device=dev)
+        self._flags = torch.zeros(self.K_local, dtype=torch.int32, device=dev)
         self._result = torch.zeros(8, dtype=f64, device=dev)
+        self._sums = torch.zeros(3 + 2 * self.T, dtype=f64, device=dev)
         self._path = None
         self.reference_path = None
         self.goal_state = None
@@ -94,7 +107,7 @@ class MPPI:
         if self.ctx.maze_owner is not self:
             self.ctx.upload_maze(self.maze, owner=self)
         self._state.copy_(torch.as_tensor(np.asarray(state, dtype=np.float64)))
-        self.launch(7, noise=noise)
+        self.controller_step(noise=noise)
         res = self._result.cpu().numpy()
         self.counter += 1
         status = int(res[2])
@@ -109,11 +122,33 @@ class MPPI:
             self.env.done = True
         return nxt, action, status == 1
 
-    # ------------------------------------------------------------------ one C-ABI call (stages: 1 rollouts, 2 update, 4 execute)
+    def controller_step(self, noise=None, weights=None):
+        """One controller step on the device state / controls.  One rank: a single C-ABI call.  Sharded: rollouts + local
+        minimum, all-reduce(MIN) of beta, weighted sums, all-reduce(SUM) of 3 + 2T doubles, then the (replicated) update and
+        executed step -- every rank ends with the same state and controls."""
+        if self.world <= 1:
+            return self.launch(_lib.MPPI_ALL, noise=noise, weights=weights)
+        import torch.distributed as dist
+        gloo = dist.get_backend(self.pg) == "gloo"
+
+        def allreduce(t, op):
+            if gloo:
+                h = t.cpu()
+                dist.all_reduce(h, op=op, group=self.pg)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=op, group=self.pg)
+        self.launch(_lib.MPPI_ROLLOUTS | _lib.MPPI_MIN, noise=noise)
+        allreduce(self._result[3:4], dist.ReduceOp.MIN)
+        self.launch(_lib.MPPI_SUMS, noise=noise, weights=weights)
+        allreduce(self._sums, dist.ReduceOp.SUM)
+        self.launch(_lib.MPPI_APPLY | _lib.MPPI_EXECUTE, noise=noise, weights=weights)
+
+    # ------------------------------------------------------------------ one C-ABI call (stages: _lib.MPPI_*)
     def launch(self, stages, noise=None, weights=None):
         goal = (C.c_double * 2)(float(self.env.goal[0]), float(self.env.goal[1]))
         _lib.check(self.ctx._h, _lib.lib().ditree_mppi_step(
             self.ctx._h, C.byref(self.params), self._state.data_ptr(), self._U.data_ptr(), self._path.data_ptr(),
             int(self._path.shape[0]), goal, None if noise is None else noise.data_ptr(), self.counter, int(stages),
             self._costs.data_ptr(), None if weights is None else weights.data_ptr(), self._flags.data_ptr(),
-            self._result.data_ptr(), self.ctx.stream), "mppi_step")
+            self._sums.data_ptr(), self._result.data_ptr(), self.ctx.stream), "mppi_step")

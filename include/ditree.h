@@ -259,13 +259,24 @@ int32_t ditree_follow_plan(ditree_ctx* ctx, double* state_io, const float* actio
  *   beta = min_k S_k;  w_k = exp(-(S_k - beta) / lambda);  U[t] += sum_k w_k eps[k, t] / sum_k w_k.
  *   execute: a = clip(U[0]) -> one env step; collision: state unchanged, U <- 0, status 2; else state <- x', U shifted by
  *   one step (last control held), status 1 inside the goal radius, else 0.
- * stages (bit mask): 1 = rollouts (fills costs [, flags]), 2 = weights + control update, 4 = execute + shift; 7 = one
- * controller step.  noise [dev] (K, T, 2) f64 or NULL = generated on the device, a pure function of (seed, counter, k, t)
- * (splitmix64 -> Box-Muller) that never touches HBM.
+ * stages (bit mask, DITREE_MPPI_*): ROLLOUTS (fills costs [, flags]), MIN (beta = min_k S_k -> result[3]), SUMS (w_k from
+ * result[3]; sums [dev] (3 + 2T) = {eta = sum w, sum w^2, collided rollouts, sum_k w_k eps[k, t, d]}), APPLY (U += sums[3..] /
+ * sums[0], weights normalised, result[4], [6], [7]), EXECUTE (env step + shift).  DITREE_MPPI_ALL = one controller step.
+ * SHARDED over ranks (BASELINE config 5: 65 536 rollouts over 8 GPUs; one process per GPU): every rank runs ROLLOUTS | MIN
+ * on its K rollouts with k_offset = its first GLOBAL rollout index, the ranks all-reduce result[3] (MIN), run SUMS,
+ * all-reduce `sums` (SUM), then APPLY | EXECUTE -- two collectives of 1 and 3 + 2T doubles per controller step; state and
+ * controls stay replicated.  noise [dev] (K, T, 2) f64 or NULL = generated on the device, a pure function of (seed,
+ * counter, GLOBAL k, t) (splitmix64 -> Box-Muller) that never touches HBM.
  *   state_io [dev] 6 f64; U_io [dev] (T, 2) f64 nominal controls; path_xy [dev] (P, 2) f64, P <= 4096; goal_xy [host] 2;
  *   costs [dev] (K) f64; weights [dev] (K) f64 or NULL (normalised w_k); flags [dev] (K) i32 or NULL (0, 1 goal, 2 collided);
  *   result [dev] 8 f64: executed action (2), status, beta, eta = sum_k w_k, nearest path index of the input state, number of
  *   collided rollouts (needs flags), effective sample size eta^2 / sum w^2. */
+#define DITREE_MPPI_ROLLOUTS 1
+#define DITREE_MPPI_MIN 2
+#define DITREE_MPPI_SUMS 4
+#define DITREE_MPPI_APPLY 8
+#define DITREE_MPPI_EXECUTE 16
+#define DITREE_MPPI_ALL 31
 typedef struct {
   int32_t T, K;                      /* horizon (<= 64), rollouts */
   double lambda;                     /* temperature */
@@ -276,10 +287,11 @@ typedef struct {
   int32_t lanes;                     /* lanes of a wavefront that share one rollout: 0 (default) or 4 = a quad (one ball and a
                                         quarter of the path window per lane: four waves per SIMD at K = 65 536), 1 = one lane.
                                         Same results either way. */
+  int64_t k_offset;                  /* global index of this rank's first rollout (0 for a single rank) */
 } ditree_mppi_params;
 int32_t ditree_mppi_step(ditree_ctx* ctx, const ditree_mppi_params* p, double* state_io, double* U_io, const double* path_xy,
                          int32_t P, const double* goal_xy, const double* noise, uint64_t counter, int32_t stages,
-                         double* costs, double* weights, int32_t* flags, double* result, void* stream);
+                         double* costs, double* weights, int32_t* flags, double* sums, double* result, void* stream);
 
 /* ------------------------------------------------------------------ denoiser */
 

@@ -14,6 +14,7 @@ from oracle import mppi as OM
 from tests.util import load_maze
 
 pytestmark = pytest.mark.gpu
+ROLL, UPD = 1, 1 | 2 | 4 | 8                 # include/ditree.h DITREE_MPPI_*: rollouts; rollouts + min + sums + apply
 
 
 @pytest.fixture(scope="module")
@@ -75,7 +76,7 @@ def test_rollout_costs_match_the_numpy_restatement(ctx, lanes, case):
     noise = tape(K, T, kw_of(m)["sigma"], 11)
     m._state.copy_(torch.as_tensor(state))
     m._U.copy_(torch.as_tensor(U))
-    m.launch(1, noise=noise.to(ctx.device))
+    m.launch(ROLL, noise=noise.to(ctx.device))
     costs = m._costs.cpu().numpy()
     flags = m._flags.cpu().numpy()
     i0 = int(m._result[5].item())
@@ -97,7 +98,7 @@ def test_quad_and_single_lane_kernels_agree_bit_for_bit(ctx):
         m._state.copy_(torch.as_tensor(np.array([path[500, 0], path[500, 1] - 0.2, -0.3, 2.5, 0.5, 0.1])))
         m._U.copy_(torch.as_tensor(np.tile(np.array([1.0, 0.2]), (T, 1))))
         m.counter = 9
-        m.launch(3)                                                  # rollouts + update with device noise
+        m.launch(UPD)                                                 # rollouts + update with device noise
         out.append((m._costs.cpu().numpy(), m._flags.cpu().numpy(), m._U.cpu().numpy(), m._result.cpu().numpy()))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3][3:], out[1][3][3:])
@@ -113,7 +114,7 @@ def test_update_matches_the_restatement_and_weights_sum_to_one(ctx):
     m._state.copy_(torch.as_tensor(state))
     m._U.copy_(torch.as_tensor(U))
     w = torch.zeros(K, dtype=torch.float64, device=ctx.device)
-    m.launch(3, noise=noise.to(ctx.device), weights=w)
+    m.launch(UPD, noise=noise.to(ctx.device), weights=w)
     rc, rf, _ = OM.rollout_costs(maze, state, U, path, m.env.goal, noise.numpy(), **kw_of(m))
     Un, wn, beta, eta, ess = OM.update(U, rc, noise.numpy(), kw_of(m)["lam"])
     res = m._result.cpu().numpy()
@@ -125,11 +126,11 @@ def test_update_matches_the_restatement_and_weights_sum_to_one(ctx):
     assert np.abs(m._U.cpu().numpy() - Un).max() < 1e-9
     # a second launch of the same call reproduces the update bit for bit (fixed summation order)
     m._U.copy_(torch.as_tensor(U))
-    m.launch(3, noise=noise.to(ctx.device))
+    m.launch(UPD, noise=noise.to(ctx.device))
     assert np.abs(m._U.cpu().numpy() - Un).max() < 1e-9
     U1 = m._U.cpu().numpy().copy()
     m._U.copy_(torch.as_tensor(U))
-    m.launch(3, noise=noise.to(ctx.device))
+    m.launch(UPD, noise=noise.to(ctx.device))
     assert np.array_equal(m._U.cpu().numpy(), U1)
 
 
@@ -143,7 +144,7 @@ def test_one_rollout_reduces_to_the_nominal_sequence(ctx):
     m._U.copy_(torch.as_tensor(U))
     w = torch.zeros(1, dtype=torch.float64, device=ctx.device)
     m._state.copy_(torch.as_tensor(state))
-    m.launch(3, weights=w)
+    m.launch(UPD, weights=w)
     assert w.item() == 1.0 and np.array_equal(m._U.cpu().numpy(), U)
     nxt, action, done = m.step(state)
     x_ref, a_ref, status, U_ref = OM.execute(maze, state, U, m.env.goal)
@@ -166,7 +167,7 @@ def test_device_noise_is_the_documented_counter_hash(ctx):
         m.counter = counter
         m._state.copy_(torch.as_tensor(state))
         m._U.copy_(torch.as_tensor(U))
-        m.launch(1)
+        m.launch(ROLL)
         got.append(m._costs.cpu().numpy().copy())
         eps = OM.device_noise(1234, counter, K, T, kw_of(m)["sigma"])
         assert abs(eps[1:, :, 0].std() - 3.0) < 0.1 and abs(eps[1:, :, 1].std() - 0.6) < 0.02

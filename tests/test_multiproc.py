@@ -219,3 +219,42 @@ def test_sharded_rrt_planner_returns_the_single_rank_path(tmp_path):
         assert np.array_equal(a["parents"], b["parents"]) and np.array_equal(a["states"], b["states"])
         assert np.array_equal(a["path"], b["path"]) and np.array_equal(a["actions"], b["actions"])      # bit for bit
         assert int(a["cc"]) == int(b["cc"]) and int(a["iters"]) == int(b["iters"])
+
+
+def _gpu_mppi_worker(rank, world, port, out_path):
+    """The MPPI controller sharded over ranks: every rank rolls out its block of the K rollouts (global rollout indices in
+    the noise hash), two tiny all-reduces per step (MIN of beta, SUM of 3 + 2T doubles), replicated update and env step."""
+    sys.path.insert(0, REPO)
+    _init(rank, world, port)
+    from ditreeonlineplanner_amd.mppi import MPPI
+    from tests.test_gpu_mppi import l_path
+    maze = load_maze("boxes")
+    path, goal_xy = l_path(maze)
+    m = MPPI(maze_data=maze, T=16, K=2048, nx=6, nu=2, seed=7)
+    assert (m.rank, m.world) == (rank, world) and m.K_local == 2048 // world
+    state = np.array([path[0, 0], path[0, 1], 0.0, 0.0, 0.0, 0.0])
+    m.reset(start_state=state, goal_state=np.array([goal_xy[0], goal_xy[1], 0, 0, 0, 0.0]))
+    m.set_ref_path(path)
+    traj, acts = [], []
+    for _ in range(60):
+        state, a, done = m.step(state)
+        assert done is False
+        traj.append(state.copy()); acts.append(a.copy())
+    np.savez(out_path.format(rank=rank), traj=np.array(traj), acts=np.array(acts), U=m._U.cpu().numpy(), ess=m.last["effective_samples"],
+             coll=m.last["collided_rollouts"])
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_mppi_controller_follows_the_single_rank_trajectory(tmp_path):
+    out = str(tmp_path / "m{w}_r{rank}.npz")
+    mp.spawn(_gpu_mppi_worker, args=(1, 29641, out.replace("{w}", "1")), nprocs=1, join=True)
+    mp.spawn(_gpu_mppi_worker, args=(2, 29642, out.replace("{w}", "2")), nprocs=2, join=True)
+    a = np.load(out.replace("{w}", "1").format(rank=0))
+    b0, b1 = [np.load(out.replace("{w}", "2").format(rank=r)) for r in range(2)]
+    # the ranks of a sharded run agree bit for bit (same all-reduced numbers, replicated update)
+    assert np.array_equal(b0["traj"], b1["traj"]) and np.array_equal(b0["U"], b1["U"])
+    # and follow the single-rank controller up to the order of the weighted sums (two partial sums added vs one pass)
+    assert np.abs(a["traj"] - b0["traj"]).max() < 1e-9 and np.abs(a["acts"] - b0["acts"]).max() < 1e-9
+    assert int(a["coll"]) == int(b0["coll"]) and abs(float(a["ess"]) - float(b0["ess"])) < 1e-6 * float(a["ess"])
+    assert a["traj"][-1, 0] > a["traj"][0, 0] + 0.2                     # it moves along the corridor
