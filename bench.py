@@ -106,19 +106,25 @@ def cpu_baseline(maze, nodes, goal, samples, cond, noise, state_dict, n_cand=512
 
 
 def pmc_traffic(kernel, precision="bf16"):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 +
-    WRITE_SIZE; profiles/run_profiles.sh + profiles/summarize.py).  Counters cannot be read inside a timed run, so
-    this is the recorded figure for the same command (same precision), or null when the summary is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02_{precision}_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            ks = json.load(f)["kernels"]
-        k = ks.get(kernel.replace("halo16_", "halo16x3_")) if precision in ("f16x3", "bf16x3") else None
-        k = k or ks[kernel]
-        return {"traffic": k["hbm_bytes_per_launch"], "traffic_unit": "bytes per launch (L2-miss side: FETCH_SIZE*2 + WRITE_SIZE)",
-                "traffic_source": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))}
-    except (OSError, KeyError, ValueError):
-        return {"traffic": None}
+    """HBM-side bytes per launch of `kernel` (its rocprofv3 name) from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 on
+    gfx950 + WRITE_SIZE; profiles/run_profiles.sh + profiles/summarize.py).  Counters cannot be read inside a timed run, so
+    this is the RECORDED figure of the same command (same precision), marked as such, or null when no summary is committed."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for rnd in ("r03", "r02"):
+        path = os.path.join(here, "profiles", f"{rnd}_{precision}_pmc_traffic.json")
+        try:
+            with open(path) as f:
+                ks = json.load(f)["kernels"]
+        except (OSError, KeyError, ValueError):
+            continue
+        base = kernel.split("<")[0]
+        k = ks.get(kernel) or ks.get(base) or next((v for n, v in ks.items() if n.split("<")[0] == base), None)
+        if k is None:
+            continue
+        return {"traffic": k["hbm_bytes_per_launch"], "traffic_kind": "recorded",
+                "traffic_unit": "bytes per launch (L2-miss side: FETCH_SIZE*2 + WRITE_SIZE)",
+                "traffic_source": os.path.relpath(path, here)}
+    return {"traffic": None}
 
 
 def launch_ranks(argv, n):
@@ -346,7 +352,7 @@ def run_rollout(args):
                                       "rollout kernel alone (the reference has no MPPI module and no ant MPPI script)",
                           "rollouts_per_gpu": K, "horizon": T, "parallelism": f"rollouts sharded x{world}, no collective"},
                "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                            "traffic": None, "kernel": "car_rollout_kernel", "avg_launch_ms": avg_ms,
+                            **recorded_traffic("rollout", kernel="car_rollout_kernel"), "kernel": "car_rollout_kernel", "avg_launch_ms": avg_ms,
                             "algorithmic_bytes_per_launch": alg,
                             "note": "FP64 transcendental-bound in practice (3 sincos + tanh + 9 sqrt/hypot per step): see DESIGN.md"},
                "outcome": {"ok": int((st == 0).sum()), "goal": int((st == 1).sum()), "collided": int((st == 2).sum())}, **comm}
@@ -379,10 +385,11 @@ def run_mppi(args):
     seg1 = a_ + (b_ - a_) * np.linspace(0, 1, 850)[:, None]
     seg2 = b_ + (c_ - b_) * np.linspace(0, 1, 850)[1:, None]
     path = np.concatenate([seg1, seg2])
-    m = MPPI(maze_data=maze, T=T, K=K, nx=6, nu=2, seed=20260104, ctx=ctx, rank=rank, world_size=world)
+    m = MPPI(maze_data=maze, T=T, K=K, nx=6, nu=2, seed=20260104, ctx=ctx, rank=rank, world_size=world, lanes=args.mppi_lanes)
     start = np.array([path[0, 0], path[0, 1], 0.0, 0.0, 0.0, 0.0])
     m.reset(start_state=start, goal_state=np.array([c_[0], c_[1], 0, 0, 0, 0.0]))
     m.set_ref_path(path)
+    m._state.copy_(torch.as_tensor(start))              # the state then stays on the device (the step writes it back)
     state = [start]
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     it = [0]
@@ -398,7 +405,6 @@ def run_mppi(args):
     def step():
         # the driver's loop: step() returns the next state to the host (one 64-byte D2H + sync per controller step)
         timed = it[0] >= args.warmup
-        m._state.copy_(torch.as_tensor(state[0]))
         if timed:
             ev[it[0] - args.warmup][0].record()
         m.launch(_lib.MPPI_ROLLOUTS)                       # the dominant kernel, bracketed on its own
@@ -413,9 +419,8 @@ def run_mppi(args):
         else:
             m.launch(_lib.MPPI_MIN | _lib.MPPI_SUMS | _lib.MPPI_APPLY | _lib.MPPI_EXECUTE)
         m.counter += 1
-        res = m._result.cpu().numpy()
-        if int(res[2]) != 2:
-            state[0] = m._state.cpu().numpy().copy()
+        res = m._result.cpu().numpy()              # one D2H + sync per step: action, status, statistics, the new state
+        state[0] = res[8:14].copy()
         it[0] += 1
 
     elapsed = _timed(step, args, dist, world, dev, rehearse)
@@ -437,7 +442,7 @@ def run_mppi(args):
                           "rollouts_global": K, "rollouts_per_gpu": Kloc, "horizon": T,
                           "parallelism": f"rollouts sharded x{world}; all-reduce MIN (1 double) + SUM ({3 + 2 * T} doubles) per step"},
                "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                            **recorded_traffic("mppi", kernel="mppi_rollout_kernel"), "kernel": "mppi_rollout_kernel<4>",
+                            **recorded_traffic("mppi", kernel="mppi_rollout_kernel"), "kernel": f"mppi_rollout_kernel<{args.mppi_lanes or 4}>",
                             "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": alg, "kernel_time_share": k_ms * 1e-3 * args.steps / elapsed,
                             "fp64": {"achieved_tflops": flop / (k_ms * 1e-3) / 1e12, "peak_tflops": 78.6,
                                      "frac": flop / (k_ms * 1e-3) / 1e12 / 78.6, "flop_per_rollout_step": 900,
@@ -526,7 +531,7 @@ def run_geometry(args):
                "config": {"workload": f"geometry kernels alone: {B} candidates, {N}-node tree, boxes.csv; includes per-call tensor "
                                       "allocation of the Python front end (event-timed around the front-end call)"},
                "roofline": {"bound": "hbm", "achieved": ro["achieved_GBps"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": ro["frac_of_hbm_peak"], "traffic": None, "kernel": "car_rollout_kernel (A = 8)",
+                            "frac": ro["frac_of_hbm_peak"], **recorded_traffic("geometry", kernel="car_rollout_kernel"), "kernel": "car_rollout_kernel (A = 8)",
                             "avg_launch_ms": ro["avg_launch_ms"], "algorithmic_bytes_per_launch": ro["algorithmic_bytes_per_launch"]},
                "kernels": res_k, **comm}
         print(json.dumps(res), flush=True)
@@ -612,7 +617,7 @@ def run_lidar_round(args):
                                       f"candidate end pose, boxes.csv, {N0}-node snapshot, seeded random weights",
                           "global_batch": Bglob, "batch_per_gpu": Bper, "parallelism": f"candidates sharded x{world}"},
                "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                            "traffic": None, "kernel": "lidar_scan_kernel", "avg_launch_ms": avg_ms,
+                            **recorded_traffic("lidar_round", kernel="lidar_scan_kernel"), "kernel": "lidar_scan_kernel", "avg_launch_ms": avg_ms,
                             "algorithmic_bytes_per_launch": alg, "kernel_time_share": avg_ms * 1e-3 * args.steps / elapsed,
                             "note": "the round itself is MFMA-bound (see the default workload); this is the lidar kernel's line"},
                **comm}
@@ -673,7 +678,7 @@ def run_ant_denoise(args):
         step()
     ctx.profile(1)
     elapsed = _timed(step, dataclass_replace(args, warmup=0), dist, world, dev, rehearse)
-    prof = ctx.profile_read()
+    prof = ctx.profile_read(prec)
     ctx.profile(0)
     ctx.check_range()                                     # f16 range guard, once for the whole loop
     comm = comm_info(dist, rehearse, dev)
@@ -716,6 +721,7 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0,
                     help="fixed GLOBAL round size split over the GPUs (strong scaling); default: --batch per GPU (weak)")
     ap.add_argument("--horizon", type=int, default=0, help="rollout workload: steps per rollout (default 16)")
+    ap.add_argument("--mppi-lanes", type=int, default=0, choices=[0, 1, 2, 4], help="mppi workload: lanes per rollout (0 = library default)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -809,14 +815,14 @@ def main():
     eng.exchange_events = None
     prof = prof_all = None
     if not args.no_profile:
-        prof = ctx.profile_read()
+        prof = ctx.profile_read(args.precision)
         # second, untimed pass of the same rounds with events around every MFMA launch (bracketing all ~120 launches
         # of a denoiser call costs ~6 %, so it stays out of the timed region): per-kernel times of all three kernels
         ctx.profile(1)
         for _ in range(min(args.steps, 5)):
             step()
         torch.cuda.synchronize()
-        prof_all = ctx.profile_read()
+        prof_all = ctx.profile_read(args.precision)
         prof_all_steps = min(args.steps, 5)
         ctx.profile(0)
 
@@ -842,11 +848,15 @@ def main():
         tp = {"dtype": "bf16", "value": Btot * args.steps / e3, "ms_per_step": 1e3 * e3 / args.steps,
               "note": "plain bf16 MFMA inputs: throughput mode, NOT within the north-star tolerance"}
         try:
-            with open(os.path.join(REPO, "profiles", "r02_round_precision.json")) as f:
+            # NOT measured in this run: the round-level deviation tests/test_gpu_round_precision.py recorded on MI355X
+            with open(os.path.join(REPO, "profiles", "r03_round_precision.json")) as f:
                 dv = json.load(f)
-            tp["round_deviation_vs_fp32_oracle"] = {k: dv["bf16"][k] for k in ("max_abs_trajectory_state", "status_flips", "candidates")}
-            tp["headline_round_deviation"] = {k: dv[args.precision][k] for k in ("max_abs_trajectory_state", "status_flips", "candidates")}
-        except (OSError, KeyError, ValueError):
+            keys = ("max_abs_trajectory_state", "p99_abs_trajectory_state", "flips", "n_agree", "candidates")
+            tp["round_deviation_vs_fp32_oracle"] = {"kind": "recorded", "source": "profiles/r03_round_precision.json (config2 round)",
+                                                    **{k: dv["bf16"]["config2"][0][k] for k in keys}}
+            tp["headline_round_deviation"] = {"kind": "recorded", "source": "profiles/r03_round_precision.json (config2 round)",
+                                              **{k: dv[args.precision]["config2"][0][k] for k in keys}}
+        except (OSError, KeyError, ValueError, IndexError):
             pass
 
     if rank == 0:

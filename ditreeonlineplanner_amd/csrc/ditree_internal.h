@@ -84,6 +84,8 @@ void launch_cond_vector_ant(const double* obs, int n_hist, const double* prev_ac
 void launch_cond_vector(const double* state, const double* prev_action, const uint8_t* has_prev,
                         const double* cond_goal, const int32_t* idx, int B, const NormArg& nm, double lm_size,
                         float* out, hipStream_t s);
+void launch_path_after_obstacle(const float* path, int stride, int P, float cx, float cy, const unsigned char* maze, int rows,
+                                int cols, int32_t* out, hipStream_t s);
 void launch_ant_advance(const double* hist_in, int n_in, const double* tape, int64_t tape_stride, int A, const double* act64, int P,
                         double* hist_out, double* prev_action, uint8_t* has_prev, double* actions_out, int64_t actout_stride,
                         int B, hipStream_t s);

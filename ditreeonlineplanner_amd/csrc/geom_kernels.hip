@@ -234,6 +234,70 @@ void launch_cond_vector_ant(const double* obs, int n_hist, const double* prev_ac
                      cond_goal, B, nm, lm_size, out);
 }
 
+// ------------------------------------------------------------------------- reference path behind the obstacle
+// planners/RRT.py:83-111 extract_path_after_obstacle in the path's float32 arithmetic: c = argmin_i ||cur - path_i|| (first
+// occurrence, np.linalg.norm along axis 1 = sqrt(dx*dx + dy*dy) in f32); over rest = path[c:], cells by cell_xy_to_rowcol
+// (f32, floor); i_b = first rest index in an occupied cell (none: -1, the reference then indexes the LAST point); then the
+// reference's while loop walks to the first free point j >= i_b and returns rest[j + 1:] (k = j + 1; the blocked run reaching
+// the end gives k = len(rest); no crossing gives k = -1, i.e. the last point alone when that one is free).
+// out[0] = c, out[1] = k.  One work-group; the path is a few hundred to a few thousand points.
+__global__ void __launch_bounds__(256)
+path_after_obstacle_kernel(const float* __restrict__ path, int stride, int P, float cx, float cy,
+                           const unsigned char* __restrict__ maze, int rows, int cols, int32_t* __restrict__ out) {
+  __shared__ float s_d[256];
+  __shared__ int s_i[256];
+  __shared__ int s_c, s_ib, s_j;
+  const int tid = threadIdx.x;
+  float best = __builtin_huge_valf();
+  int bi = 0x7fffffff;
+  for (int i = tid; i < P; i += 256) {
+    const float dx = cx - path[(size_t)i * stride], dy = cy - path[(size_t)i * stride + 1];
+    const float d = sqrtf(dx * dx + dy * dy);
+    if (d < best) { best = d; bi = i; }
+  }
+  s_d[tid] = best; s_i[tid] = bi;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) {
+      const float od = s_d[tid + o];
+      const int oi = s_i[tid + o];
+      if (od < s_d[tid] || (od == s_d[tid] && oi < s_i[tid])) { s_d[tid] = od; s_i[tid] = oi; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { s_c = s_i[0]; s_ib = 0x7fffffff; s_j = 0x7fffffff; }
+  __syncthreads();
+  const int c = s_c, n = P - c;
+  const float yc = (float)rows / 2.0f, xc = (float)cols / 2.0f;
+  auto blocked = [&](int r) {                               // rest index r -> occupied cell?
+    const float x = path[(size_t)(c + r) * stride], y = path[(size_t)(c + r) * stride + 1];
+    const int i = (int)floorf((yc - y) / 1.0f), j = (int)floorf((x + xc) / 1.0f);
+    // numpy would wrap a negative index and raise beyond the map: paths of a planner stay inside; clamp instead of faulting
+    const int ii = min(max(i, 0), rows - 1), jj = min(max(j, 0), cols - 1);
+    return maze[ii * cols + jj] == 1;
+  };
+  int mine = 0x7fffffff;
+  for (int r = tid; r < n; r += 256)
+    if (blocked(r)) { mine = r; break; }
+  if (mine != 0x7fffffff) atomicMin(&s_ib, mine);
+  __syncthreads();
+  const int ib = s_ib;
+  if (ib == 0x7fffffff) {                                   // no crossing: the reference looks at the last point
+    if (tid == 0) { out[0] = c; out[1] = blocked(n - 1) ? n : -1; }
+    return;
+  }
+  mine = 0x7fffffff;
+  for (int r = ib + tid; r < n; r += 256)
+    if (!blocked(r)) { mine = r; break; }
+  if (mine != 0x7fffffff) atomicMin(&s_j, mine);
+  __syncthreads();
+  if (tid == 0) { out[0] = c; out[1] = s_j == 0x7fffffff ? n : s_j + 1; }
+}
+void launch_path_after_obstacle(const float* path, int stride, int P, float cx, float cy, const unsigned char* maze, int rows,
+                                int cols, int32_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(path_after_obstacle_kernel, dim3(1), dim3(256), 0, s, path, stride, P, cx, cy, maze, rows, cols, out);
+}
+
 // ------------------------------------------------------------------------- ant round: advance one chunk
 // The part of planners/RRT.py:176-188 an ant chunk has besides the MuJoCo step, which has no oracle here and is not built:
 // `prev_states = curr_states_seq` (the chunk's A + 1 states; the sampler keeps the last three, fm_policy.py:96-102),

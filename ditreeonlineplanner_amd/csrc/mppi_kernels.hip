@@ -27,6 +27,7 @@ namespace {
 constexpr int MPPI_MAX_T = 64;
 constexpr int MPPI_MAX_P = 4096;         // reference path points staged in LDS (64 KB of f64 pairs)
 constexpr int MPPI_SLICES = 256;         // partial-sum slices of the update
+constexpr int MPPI_DEFAULT_LANES = 4;    // lanes per rollout when the caller does not choose (measured: DESIGN.md "MPPI")
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -61,24 +62,20 @@ struct MppiArgs {
 };
 
 template <int G> __device__ __forceinline__ double quad_min(double v) {
-  if constexpr (G == 4) {
-    v = fmin(v, __shfl_xor(v, 1));
-    v = fmin(v, __shfl_xor(v, 2));
-  }
+  if constexpr (G >= 2) v = fmin(v, __shfl_xor(v, 1));
+  if constexpr (G == 4) v = fmin(v, __shfl_xor(v, 2));
   return v;
 }
 template <int G> __device__ __forceinline__ int quad_min_i(int v) {
-  if constexpr (G == 4) {
-    v = min(v, __shfl_xor(v, 1));
-    v = min(v, __shfl_xor(v, 2));
-  }
+  if constexpr (G >= 2) v = min(v, __shfl_xor(v, 1));
+  if constexpr (G == 4) v = min(v, __shfl_xor(v, 2));
   return v;
 }
 template <int G> __device__ __forceinline__ bool quad_or(bool v) {
-  if constexpr (G == 4) {
+  if constexpr (G >= 2) {
     int x = v ? 1 : 0;
     x |= __shfl_xor(x, 1);
-    x |= __shfl_xor(x, 2);
+    if constexpr (G == 4) x |= __shfl_xor(x, 2);
     return x != 0;
   }
   return v;
@@ -163,7 +160,7 @@ mppi_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, 
     car_euler_step(s, u0 + e0, u1 + e1);
     // collision: lane g tests ball g & 1 (front / back), the quad ORs
     bool coll;
-    if constexpr (G == 4) {
+    if constexpr (G >= 2) {
       const double off = 0.15 * 0.5;
       const double sgn = (g & 1) ? -1.0 : 1.0;
       const double ox = off * cos(s[2]), oy = off * sin(s[2]);
@@ -296,9 +293,11 @@ mppi_finish_kernel(const unsigned char* __restrict__ maze, int rows, int cols, c
     if (coll) {
       result[2] = 2.0;                                   // the state stays; the nominal sequence restarts from rest
       for (int j = 0; j < 2 * a.T; ++j) U[j] = 0.0;
+      for (int j = 0; j < 6; ++j) result[8 + j] = state_io[j];
     } else {
       result[2] = reached ? 1.0 : 0.0;
       for (int j = 0; j < 6; ++j) state_io[j] = s[j];
+      for (int j = 0; j < 6; ++j) result[8 + j] = s[j];
       for (int t = 0; t + 1 < a.T; ++t) { U[2 * t] = U[2 * t + 2]; U[2 * t + 1] = U[2 * t + 3]; }   // last control held
     }
   }
@@ -316,7 +315,8 @@ extern "C" int32_t ditree_mppi_step(ditree_ctx* ctx, const ditree_mppi_params* p
       p->K < 1 || P < 1 || P > MPPI_MAX_P || !(p->lambda > 0.0) || !(p->sigma[0] > 0.0) || !(p->sigma[1] > 0.0) ||
       p->window_back < 0 || p->window_fwd < 0 || (stages & ~DITREE_MPPI_ALL) != 0 || stages == 0 || p->k_offset < 0)
     return set_err(ctx, DITREE_E_ARG, "mppi_step: bad argument (1 <= T <= 64, 1 <= P <= 4096, lambda, sigma > 0, stages 1..31)");
-  if (p->lanes != 0 && p->lanes != 1 && p->lanes != 4) return set_err(ctx, DITREE_E_ARG, "mppi_step: lanes must be 0, 1 or 4");
+  if (p->lanes != 0 && p->lanes != 1 && p->lanes != 2 && p->lanes != 4)
+    return set_err(ctx, DITREE_E_ARG, "mppi_step: lanes must be 0, 1, 2 or 4");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   MppiArgs a;
@@ -333,21 +333,22 @@ extern "C" int32_t ditree_mppi_step(ditree_ctx* ctx, const ditree_mppi_params* p
   if (stages & DITREE_MPPI_ROLLOUTS) {
     const size_t lds = (size_t)P * 16 + (size_t)a.T * 16 + 128 + (((size_t)ctx->rows * ctx->cols + 15) & ~(size_t)15);
     if (lds > 160 * 1024) return set_err(ctx, DITREE_E_ARG, "mppi_step: path + maze exceed the LDS");
-    const int G = p->lanes == 1 ? 1 : 4;
+    const int G = p->lanes == 0 ? MPPI_DEFAULT_LANES : p->lanes;
     const long long threads = (long long)a.K * G;
     const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
-    static bool attr_done[64][2] = {};
-    if (lds > 64 * 1024 && ctx->device < 64 && !attr_done[ctx->device][G == 4]) {
-      const void* fn = G == 4 ? (const void*)mppi_rollout_kernel<4> : (const void*)mppi_rollout_kernel<1>;
+    const void* fn = G == 4 ? (const void*)mppi_rollout_kernel<4> : (G == 2 ? (const void*)mppi_rollout_kernel<2> : (const void*)mppi_rollout_kernel<1>);
+    static bool attr_done[64][3] = {};
+    if (lds > 64 * 1024 && ctx->device < 64 && !attr_done[ctx->device][G >> 1]) {
       HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_done[ctx->device][G == 4] = true;
+      attr_done[ctx->device][G >> 1] = true;
     }
-    if (G == 4)
-      hipLaunchKernelGGL(mppi_rollout_kernel<4>, grid, block, lds, s, ctx->maze, ctx->rows, ctx->cols, state_io, U_io,
-                         (const double2*)path_xy, noise, a, costs, flags, result);
-    else
-      hipLaunchKernelGGL(mppi_rollout_kernel<1>, grid, block, lds, s, ctx->maze, ctx->rows, ctx->cols, state_io, U_io,
-                         (const double2*)path_xy, noise, a, costs, flags, result);
+#define MPPI_LAUNCH(GG)                                                                                                     \
+  hipLaunchKernelGGL(mppi_rollout_kernel<GG>, grid, block, lds, s, ctx->maze, ctx->rows, ctx->cols, state_io, U_io,          \
+                     (const double2*)path_xy, noise, a, costs, flags, result)
+    if (G == 4) MPPI_LAUNCH(4);
+    else if (G == 2) MPPI_LAUNCH(2);
+    else MPPI_LAUNCH(1);
+#undef MPPI_LAUNCH
   }
   if (stages & DITREE_MPPI_MIN) hipLaunchKernelGGL(mppi_min_kernel, dim3(1), dim3(256), 0, s, costs, a.K, result);
   if (stages & DITREE_MPPI_SUMS)

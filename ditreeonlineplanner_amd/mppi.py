@@ -60,7 +60,8 @@ class MPPI:
         self._U = torch.zeros(self.T, 2, dtype=f64, device=dev)
         self._costs = torch.zeros(self.K_local, dtype=f64, device=dev)
         self._flags = torch.zeros(self.K_local, dtype=torch.int32, device=dev)
-        self._result = torch.zeros(8, dtype=f64, device=dev)
+        self._result = torch.zeros(16, dtype=f64, device=dev)
+        self._state_host = None            # the state the device holds (skip the upload when the driver hands it back)
         self._sums = torch.zeros(3 + 2 * self.T, dtype=f64, device=dev)
         self._path = None
         self.reference_path = None
@@ -106,14 +107,17 @@ class MPPI:
             raise _lib.DitreeError("MPPI.step: set_ref_path(path) first")
         if self.ctx.maze_owner is not self:
             self.ctx.upload_maze(self.maze, owner=self)
-        self._state.copy_(torch.as_tensor(np.asarray(state, dtype=np.float64)))
+        state = np.asarray(state, dtype=np.float64)
+        if self._state_host is None or not np.array_equal(state, self._state_host):
+            self._state.copy_(torch.as_tensor(state))
         self.controller_step(noise=noise)
-        res = self._result.cpu().numpy()
+        res = self._result.cpu().numpy()            # the one D2H (and sync) of a step: action, status, statistics, new state
         self.counter += 1
         status = int(res[2])
         self.last = {"beta": float(res[3]), "eta": float(res[4]), "nearest_path_index": int(res[5]),
                      "collided_rollouts": int(res[6]), "effective_samples": float(res[7])}
-        nxt = self._state.cpu().numpy().copy()
+        nxt = res[8:14].copy()
+        self._state_host = nxt.copy()
         action = res[:2].copy()
         if status == 2:
             return nxt, action, None

@@ -409,14 +409,28 @@ def _ctx_profile(self, enable=True):
     check(self._h, lib().ditree_profile(self._h, int(enable)), "profile")
 
 
-PROFILE_KINDS = ("conv3_halo16_kernel", "gemm16_kernel + conv_gemm_kernel", "conv2d_small_kernel")      # split: conv3_halo16x3_kernel
+def profile_kind_names(precision=None):
+    """Names of the three MFMA kernel kinds as rocprofv3 prints them (profiles/*_kernel_stats.csv) for a denoiser
+    instantiation ("bf16", "f32", "f16x3", "bf16x3", "f16", or a PREC_* value): kind 0 the k = 3 conv kernel, 1 the other
+    dense layers, 2 the encoder's implicit Conv2d."""
+    name = {v: k for k, v in _lib.PREC_NAMES.items()}.get(precision, precision)
+    et = 1 if name in ("f16", "f16x3") else 0
+    if name == "f32":
+        return ("(none: f32 runs every layer on conv_gemm_kernel)", "conv_gemm_kernel<1, false>", "conv_gemm_kernel<1, true>")
+    if name in ("f16x3", "bf16x3"):
+        return (f"conv3_halo16x3_kernel<{et}>", f"gemm16_kernel<{et}, true>", f"conv2d_small_kernel<{et}, true>")
+    if name in ("f16", "bf16"):
+        return (f"conv3_halo16_kernel<{et}, false>", f"gemm16_kernel<{et}, false> + conv_gemm_kernel<{2 if et else 0}, false>",
+                f"conv2d_small_kernel<{et}, false>")
+    return ("conv3_halo16*_kernel", "gemm16_kernel + conv_gemm_kernel", "conv2d_small_kernel")
 
 
-def _ctx_profile_read(self):
-    """-> {kernel name: dict(ms, launches, flops)} for the MFMA kernels since profile(True)."""
+def _ctx_profile_read(self, precision=None):
+    """-> {rocprof kernel name: dict(ms, launches, flops)} for the MFMA kernels since profile(True)."""
     ms, n, fl = (C.c_double * 3)(), (C.c_int64 * 3)(), (C.c_double * 3)()
     check(self._h, lib().ditree_profile_read(self._h, ms, n, fl), "profile_read")
-    return {PROFILE_KINDS[k]: dict(ms=ms[k], launches=n[k], flops=fl[k]) for k in range(3)}
+    names = profile_kind_names(precision)
+    return {names[k]: dict(ms=ms[k], launches=n[k], flops=fl[k]) for k in range(3)}
 
 
 Context.profile = _ctx_profile

@@ -140,21 +140,21 @@ class RRT_Planner(BasePlanner):
         return bool(self.ctx.obstacle_ahead(st)[0].item())
 
     def extract_path_after_obstacle(self):
-        """RRT.py:83-111: xy of ``init_main_path`` from the point nearest to the env state onwards, cut to what
-        lies behind the first blocked stretch (host side: once per plan over a few hundred points)."""
-        xy = self.init_main_path[:, :2].copy()
-        here = self.env.state[:2]
-        first = int(np.argmin(np.linalg.norm(here - self.init_main_path[:, :2], axis=1)))
-        xy = xy[first:, :]
-        cells = np.array([self.env.cell_xy_to_rowcol(q).astype("int") for q in xy])
-        blocked = self.maze[cells[:, 0], cells[:, 1]] == 1
-        hits = np.flatnonzero(blocked)
-        k = int(hits[0]) if hits.size else -1          # no crossing: the reference starts from the last point
-        cell = cells[k]
-        while self.maze[cell[0], cell[1]] == 1 and k < len(cells):
-            cell = cells[k]
-            k += 1
-        return xy[k:]
+        """RRT.py:83-111: xy of ``init_main_path`` from the point nearest to the env state onwards, cut to what lies behind
+        the first blocked stretch.  On the device (ditree_path_after_obstacle: nearest point, cell lookup and the two
+        searches in one launch on the known maze), in the path's float32 arithmetic as the reference's arrays."""
+        import ctypes as C
+        from .._lib import check, lib
+        eng = self._engine
+        eng.ensure_maze()
+        path = np.ascontiguousarray(self.init_main_path, dtype=np.float32)
+        p_dev = torch.as_tensor(path, device=self.ctx.device)
+        out = torch.zeros(2, dtype=torch.int32, device=self.ctx.device)
+        cur = (C.c_float * 2)(*np.asarray(self.env.state[:2], dtype=np.float32))
+        check(self.ctx._h, lib().ditree_path_after_obstacle(self.ctx._h, p_dev.data_ptr(), int(path.shape[1]), int(path.shape[0]),
+                                                            cur, out.data_ptr(), self.ctx.stream), "path_after_obstacle")
+        c, k = (int(v) for v in out.cpu().numpy())
+        return self.init_main_path[c:, :2].copy()[k:]
 
     def draw_round(self, B, remain_init_path=None):
         """B x [sample -> conditioning goal] in the reference's RNG call order (base_planner.py:162-207,

@@ -212,6 +212,14 @@ int32_t ditree_accept(ditree_ctx* ctx, const ditree_tree* tree, const ditree_rou
 int32_t ditree_obstacle_ahead(ditree_ctx* ctx, const double* state, int32_t stride, int32_t B,
                               uint8_t* out, void* stream);
 
+/* planners/RRT.py:83-111 extract_path_after_obstacle on the uploaded (known) maze, in the path's float32 arithmetic: out2[0] =
+ * index c of the path point nearest to cur_xy (first occurrence), out2[1] = k such that the remaining reference path is
+ * path[c:][k:] -- the points behind the first blocked stretch (k = -1: the path crosses no obstacle, the reference then
+ * keeps its last point only; k = P - c: nothing remains).  path [dev] (P, stride >= 2) f32 rows x, y, ...; cur_xy [host] 2 f32
+ * (env.state[:2]); out2 [dev] 2 x i32. */
+int32_t ditree_path_after_obstacle(ditree_ctx* ctx, const float* path, int32_t stride, int32_t P, const float* cur_xy /*[host] 2*/,
+                                   int32_t* out2, void* stream);
+
 /* planners/RRT.py:233-254 fallback node when the budget ends without reaching the goal, over nodes
  * 1..n-1 of the tree: path == NULL: argmin ||xy - goal|| + 1e4 * obstacle_ahead; path != NULL
  * ([host] (P, 2) f64 = init_main_path xy): argmax of the nearest path index (-1 when an obstacle is
@@ -269,8 +277,8 @@ int32_t ditree_follow_plan(ditree_ctx* ctx, double* state_io, const float* actio
  * counter, GLOBAL k, t) (splitmix64 -> Box-Muller) that never touches HBM.
  *   state_io [dev] 6 f64; U_io [dev] (T, 2) f64 nominal controls; path_xy [dev] (P, 2) f64, P <= 4096; goal_xy [host] 2;
  *   costs [dev] (K) f64; weights [dev] (K) f64 or NULL (normalised w_k); flags [dev] (K) i32 or NULL (0, 1 goal, 2 collided);
- *   result [dev] 8 f64: executed action (2), status, beta, eta = sum_k w_k, nearest path index of the input state, number of
- *   collided rollouts (needs flags), effective sample size eta^2 / sum w^2. */
+ *   result [dev] 16 f64: executed action (2), status, beta, eta = sum_k w_k, nearest path index of the input state, number of
+ *   collided rollouts (needs flags), effective sample size eta^2 / sum w^2, [8..13] the state after EXECUTE (one D2H per step). */
 #define DITREE_MPPI_ROLLOUTS 1
 #define DITREE_MPPI_MIN 2
 #define DITREE_MPPI_SUMS 4
@@ -284,9 +292,9 @@ typedef struct {
   double w_track, w_progress, w_collision, w_goal;
   uint64_t seed;
   int32_t window_back, window_fwd;   /* nearest-path-index search window per step */
-  int32_t lanes;                     /* lanes of a wavefront that share one rollout: 0 (default) or 4 = a quad (one ball and a
-                                        quarter of the path window per lane: four waves per SIMD at K = 65 536), 1 = one lane.
-                                        Same results either way. */
+  int32_t lanes;                     /* lanes of a wavefront that share one rollout: 1, 2 or 4 (one ball and a share of the path
+                                        window per lane: that many waves per SIMD at K = 65 536), 0 = the measured default.
+                                        Same results whatever the value. */
   int64_t k_offset;                  /* global index of this rank's first rollout (0 for a single rank) */
 } ditree_mppi_params;
 int32_t ditree_mppi_step(ditree_ctx* ctx, const ditree_mppi_params* p, double* state_io, double* U_io, const double* path_xy,
