@@ -348,6 +348,10 @@ void launch_ant_advance(const double* hist_in, int n_in, const double* tape, int
 //   contiguous run; 100 us: each of its 12 barriers exposes a full memory latency to the only wave of the SIMD and the
 //   index arithmetic of the wave-wide copies adds a third to the instruction count) and register prefetch of the next four
 //   steps' actions (74 us).  What would help is a second wave per SIMD (two lanes per candidate, one ball each) -- DESIGN.md.
+// G lanes per candidate (1 or 2).  G = 2: both lanes of a pair integrate the (identical) dynamics, lane g tests ball g and the
+// pair ORs by one lane exchange, lane 0 stores the state rows and lane 1 the action rows -- twice the waves for the same batch
+// (two per SIMD at 65 536 candidates), each with a shorter chain per step.  Same arithmetic, same results.
+template <int G>
 __global__ void __launch_bounds__(256)
 car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, double* __restrict__ state_io,
                    const double* __restrict__ actions, int64_t act_stride, int32_t* __restrict__ status_io, int B,
@@ -358,7 +362,7 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
                    const int32_t* __restrict__ budget, int chunk_j) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   stage_maze(lds, maze, rows * cols);
-  const int ob = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ob = (blockIdx.x * blockDim.x + threadIdx.x) / G, g = threadIdx.x & (G - 1);
   if (ob >= B) return;
   const int b = idx ? idx[ob] : ob;                 // compacted rounds: actions are dense (row ob), the rest per candidate
   if (status_io[b] != DITREE_ST_OK) return;
@@ -367,8 +371,9 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
 #pragma unroll
   for (int k = 0; k < 6; ++k) s[k] = state_io[(size_t)b * 6 + k];
   const double* act = actions + (size_t)(act_dense ? ob : b) * act_stride;
-  double* so = states_out ? states_out + (size_t)b * states_stride : nullptr;
-  double* ao = actions_out ? actions_out + (size_t)b * actout_stride : nullptr;
+  // G = 2: lane 0 owns the state rows, lane 1 the action rows
+  double* so = (states_out && (G == 1 || g == 0)) ? states_out + (size_t)b * states_stride : nullptr;
+  double* ao = (actions_out && (G == 1 || g == 1)) ? actions_out + (size_t)b * actout_stride : nullptr;
   if (so) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) so[k] = s[k];                                   // states_sequence[0] = state
@@ -389,7 +394,15 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
     la0 = a0r; la1 = a1r;
     double ex = s[0] - gx, ey = s[1] - gy;
     bool done = sqrt(fma(ey, ey, ex * ex)) < 0.5;   // np.linalg.norm (ddot rounds as one fma), car_env.py:346-351
-    bool coll = car_collides(s[0], s[1], s[2], lds, rows, cols);                 // base_planner.py:306
+    bool coll;                                                                   // base_planner.py:306
+    if constexpr (G == 2) {
+      const double off = 0.15 * 0.5, sgn = g ? -1.0 : 1.0;                       // common/map_utils.py:103-115: lane g, ball g
+      const double ox = off * cos(s[2]), oy = off * sin(s[2]);
+      const int mine = ball_collides(s[0] + sgn * ox, s[1] + sgn * oy, lds, rows, cols) ? 1 : 0;
+      coll = (mine | __shfl_xor(mine, 1)) != 0;
+    } else {
+      coll = car_collides(s[0], s[1], s[2], lds, rows, cols);
+    }
     if (coll) {
       status = DITREE_ST_COLLIDED | (done ? DITREE_ST_FLAG_GOAL_AT_COLLISION : 0);
       ++i;
@@ -415,6 +428,7 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
       ao[2 * r + 1] = z ? 0.0 : act[2 * r + 1];
     }
   }
+  if (G == 2 && g != 0) return;                       // per-candidate results: lane 0
 #pragma unroll
   for (int k = 0; k < 6; ++k) state_io[(size_t)b * 6 + k] = s[k];
   status_io[b] = status;
@@ -436,10 +450,20 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
   // work-group size: one wave per group spreads a small batch over many CUs (1 024 candidates: 16 CUs instead of 4); once
   // every SIMD has a wave anyway, four waves per group share one staged maze
   const int blk = B >= 16384 ? 256 : 64;
-  hipLaunchKernelGGL(car_rollout_kernel, dim3((B + blk - 1) / blk), dim3(blk), lds, s, maze, rows, cols, state_io,
-                     actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out,
-                     actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense,
-                     budget, chunk_j);
+  // lanes per candidate: 2 once the batch leaves at most ~2 waves per SIMD anyway (DITREE_ROLLOUT_LANES = 1 | 2 overrides)
+  static int lanes_env = -1;
+  if (lanes_env < 0) { const char* e = getenv("DITREE_ROLLOUT_LANES"); lanes_env = e ? atoi(e) : 0; }
+  const int G = lanes_env == 1 ? 1 : (lanes_env == 2 ? 2 : 2);
+  if (G == 2)
+    hipLaunchKernelGGL(car_rollout_kernel<2>, dim3((2 * B + blk - 1) / blk), dim3(blk), lds, s, maze, rows, cols, state_io,
+                       actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out,
+                       actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense,
+                       budget, chunk_j);
+  else
+    hipLaunchKernelGGL(car_rollout_kernel<1>, dim3((B + blk - 1) / blk), dim3(blk), lds, s, maze, rows, cols, state_io,
+                       actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out,
+                       actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense,
+                       budget, chunk_j);
 }
 void launch_car_rollout(const unsigned char* maze, int rows, int cols, double* state_io, const double* actions,
                         int64_t act_stride, int32_t* status_io, int B, int A, double gx, double gy,

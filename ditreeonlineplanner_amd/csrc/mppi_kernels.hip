@@ -27,7 +27,7 @@ namespace {
 constexpr int MPPI_MAX_T = 64;
 constexpr int MPPI_MAX_P = 4096;         // reference path points staged in LDS (64 KB of f64 pairs)
 constexpr int MPPI_SLICES = 256;         // partial-sum slices of the update
-constexpr int MPPI_DEFAULT_LANES = 4;    // lanes per rollout when the caller does not choose (measured: DESIGN.md "MPPI")
+constexpr int MPPI_DEFAULT_LANES = 2;    // lanes per rollout when the caller does not choose (measured: DESIGN.md "MPPI")
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -50,6 +50,16 @@ __device__ __forceinline__ void mppi_noise(unsigned long long seed, unsigned lon
   const double a = 6.283185307179586 * u2;
   e0 = s0 * (r * cos(a));
   e1 = s1 * (r * sin(a));
+}
+
+// order-preserving map double -> unsigned 64-bit (and back): negative values flip all bits, the others the sign bit
+__device__ __forceinline__ unsigned long long mppi_key(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double mppi_unkey(unsigned long long k) {
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)b);
 }
 
 struct MppiArgs {
@@ -103,7 +113,8 @@ template <int G>
 __global__ void __launch_bounds__(256)
 mppi_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, const double* __restrict__ state,
                     const double* __restrict__ U, const double2* __restrict__ path, const double* __restrict__ noise,
-                    MppiArgs a, double* __restrict__ costs, int32_t* __restrict__ flags, double* __restrict__ result) {
+                    MppiArgs a, double* __restrict__ costs, int32_t* __restrict__ flags, double* __restrict__ result,
+                    unsigned long long* __restrict__ minkey) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   double2* s_path = (double2*)lds_raw;                                   // P points
   double* s_U = (double*)(s_path + a.P);                                 // T x 2
@@ -143,14 +154,14 @@ mppi_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, 
   }
   const int k = (blockIdx.x * blockDim.x + tid) / G, g = tid & (G - 1);
   if (blockIdx.x == 0 && tid == 0 && result != nullptr) result[5] = (double)i0;
-  if (k >= a.K) return;
+  const bool live = k < a.K;                           // quad-uniform (G lanes share k)
   double s[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) s[j] = x0[j];
   double cost = 0.0;
   int ip = i0;
   int flag = 0;                                        // 1 = reached the goal, 2 = collided
-  for (int t = 0; t < a.T; ++t) {
+  for (int t = 0; live && t < a.T; ++t) {
     double e0 = 0.0, e1 = 0.0;
     if (a.k0 + k > 0) {                                // GLOBAL rollout 0 is the noise-free nominal sequence
       if (noise != nullptr) { e0 = noise[((size_t)k * a.T + t) * 2]; e1 = noise[((size_t)k * a.T + t) * 2 + 1]; }
@@ -180,22 +191,21 @@ mppi_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, 
     if (reached) { cost = cost - a.w_goal; flag = 1; break; }
   }
   cost = cost + a.w_progress * (double)(a.P - 1 - ip);
-  if (g == 0) {
+  if (live && g == 0) {
     costs[k] = cost;
     if (flags != nullptr) flags[k] = flag;
   }
+  // beta = min_k S_k without a second pass over the costs: wave minimum, one atomicMin per wave on an order-preserving
+  // integer image of the double (min is order-independent: reproducible)
+  double m = (live && g == 0) ? cost : __builtin_huge_val();
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmin(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) atomicMin(minkey, mppi_key(m));
 }
 
 // ---- update: beta = min S, w_k = exp(-(S_k - beta) / lambda), eta = sum w, dU[t] = sum_k w_k eps[k, t] / eta
-__global__ void __launch_bounds__(256) mppi_min_kernel(const double* __restrict__ costs, int K, double* __restrict__ result) {
-  __shared__ double red[4];
-  double m = __builtin_huge_val();
-  for (int i = threadIdx.x; i < K; i += 256) m = fmin(m, costs[i]);
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = fmin(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) result[3] = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+__global__ void mppi_min_kernel(const unsigned long long* __restrict__ minkey, double* __restrict__ result) {
+  result[3] = mppi_unkey(*minkey);                    // the rollout kernel's atomicMin, decoded
 }
 
 // slice s owns rollouts [s * per, (s + 1) * per).  A thread takes rollout lo + tid (+ 256, ...): per rollout and step the
@@ -254,10 +264,16 @@ mppi_finish_kernel(const unsigned char* __restrict__ maze, int rows, int cols, c
   if (do_sums) {
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
-    for (int j = threadIdx.x; j < nacc; j += 256) {
-      double v = 0.0;
-      for (int s = 0; s < slices; ++s) v += partial[(size_t)s * nacc + j];     // slice order
-      sums[j < 2 ? j : j + 1] = v;
+    // thread t takes slice t (<= 256 slices); per value a fixed butterfly + a fixed order over the four waves
+    __shared__ double wsum[4];
+    for (int j = 0; j < nacc; ++j) {
+      double v = (int)threadIdx.x < slices ? partial[(size_t)threadIdx.x * nacc + j] : 0.0;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+      if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) sums[j < 2 ? j : j + 1] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+      __syncthreads();
     }
     int c = 0;
     if (flags != nullptr)
@@ -328,8 +344,11 @@ extern "C" int32_t ditree_mppi_step(ditree_ctx* ctx, const ditree_mppi_params* p
   a.gx = goal_xy[0]; a.gy = goal_xy[1];
   a.k0 = p->k_offset;
   const int slices = std::min(MPPI_SLICES, (a.K + 255) / 256);      // 256 rollouts per slice up to 65 536, more beyond
-  if ((stages & (DITREE_MPPI_SUMS)) && !ctx->mppi_partial)
+  if (!ctx->mppi_partial) {
     HIP_TRY(ctx, hipMalloc((void**)&ctx->mppi_partial, (size_t)MPPI_SLICES * (2 + 2 * MPPI_MAX_T) * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->mppi_minkey, sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->mppi_minkey, 0xFF, sizeof(unsigned long long), s));
+  }
   if (stages & DITREE_MPPI_ROLLOUTS) {
     const size_t lds = (size_t)P * 16 + (size_t)a.T * 16 + 128 + (((size_t)ctx->rows * ctx->cols + 15) & ~(size_t)15);
     if (lds > 160 * 1024) return set_err(ctx, DITREE_E_ARG, "mppi_step: path + maze exceed the LDS");
@@ -344,13 +363,14 @@ extern "C" int32_t ditree_mppi_step(ditree_ctx* ctx, const ditree_mppi_params* p
     }
 #define MPPI_LAUNCH(GG)                                                                                                     \
   hipLaunchKernelGGL(mppi_rollout_kernel<GG>, grid, block, lds, s, ctx->maze, ctx->rows, ctx->cols, state_io, U_io,          \
-                     (const double2*)path_xy, noise, a, costs, flags, result)
+                     (const double2*)path_xy, noise, a, costs, flags, result, ctx->mppi_minkey)
+    HIP_TRY(ctx, hipMemsetAsync(ctx->mppi_minkey, 0xFF, sizeof(unsigned long long), s));
     if (G == 4) MPPI_LAUNCH(4);
     else if (G == 2) MPPI_LAUNCH(2);
     else MPPI_LAUNCH(1);
 #undef MPPI_LAUNCH
   }
-  if (stages & DITREE_MPPI_MIN) hipLaunchKernelGGL(mppi_min_kernel, dim3(1), dim3(256), 0, s, costs, a.K, result);
+  if (stages & DITREE_MPPI_MIN) hipLaunchKernelGGL(mppi_min_kernel, dim3(1), dim3(1), 0, s, ctx->mppi_minkey, result);
   if (stages & DITREE_MPPI_SUMS)
     hipLaunchKernelGGL(mppi_partial_kernel, dim3(slices), dim3(256), 0, s, costs, noise, a, result, ctx->mppi_partial, weights);
   if (stages & (DITREE_MPPI_SUMS | DITREE_MPPI_APPLY | DITREE_MPPI_EXECUTE))

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DITREE_VERSION 200          /* 0.1.0 */
+#define DITREE_VERSION 300          /* 0.3.0: + denoise_status, build_id, mppi_step, expand_round_ant, path_after_obstacle */
 
 #define DITREE_OK 0
 #define DITREE_E_ARG (-1)           /* bad argument (null pointer, size out of range) */
