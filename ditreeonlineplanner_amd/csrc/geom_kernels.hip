@@ -450,10 +450,13 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
   // work-group size: one wave per group spreads a small batch over many CUs (1 024 candidates: 16 CUs instead of 4); once
   // every SIMD has a wave anyway, four waves per group share one staged maze
   const int blk = B >= 16384 ? 256 : 64;
-  // lanes per candidate: 2 once the batch leaves at most ~2 waves per SIMD anyway (DITREE_ROLLOUT_LANES = 1 | 2 overrides)
+  // lanes per candidate, measured on MI355X (profiles/r03_rollout_lanes.json): 8 192 candidates x 8 steps 31.6 -> 26.2 us with
+  // two lanes (the batch fills a quarter of the SIMDs: the second lane's wave is free), 65 536 x 16 steps 73.2 -> 80.0 us
+  // (every SIMD already has a wave; the duplicated dynamics cost more than the shorter chain saves).  DITREE_ROLLOUT_LANES
+  // = 1 | 2 overrides.
   static int lanes_env = -1;
   if (lanes_env < 0) { const char* e = getenv("DITREE_ROLLOUT_LANES"); lanes_env = e ? atoi(e) : 0; }
-  const int G = lanes_env == 1 ? 1 : (lanes_env == 2 ? 2 : 2);
+  const int G = lanes_env == 1 ? 1 : (lanes_env == 2 ? 2 : (B <= 32768 ? 2 : 1));
   if (G == 2)
     hipLaunchKernelGGL(car_rollout_kernel<2>, dim3((2 * B + blk - 1) / blk), dim3(blk), lds, s, maze, rows, cols, state_io,
                        actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out,
