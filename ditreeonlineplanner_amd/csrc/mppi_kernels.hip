@@ -214,15 +214,16 @@ __global__ void mppi_min_kernel(const unsigned long long* __restrict__ minkey, d
 // by t would live in scratch: T is a run-time value.)
 __global__ void __launch_bounds__(256)
 mppi_partial_kernel(const double* __restrict__ costs, const double* __restrict__ noise, MppiArgs a, const double* __restrict__ result,
-                    double* __restrict__ partial /*[slices][2 + 2T]*/, double* __restrict__ weights) {
-  __shared__ double red[4][2 + 2 * MPPI_MAX_T];
+                    double* __restrict__ partial /*[slices][3 + 2T]: eta, sum w^2, collided, sum w eps*/, double* __restrict__ weights,
+                    const int32_t* __restrict__ flags) {
+  __shared__ double red[4][3 + 2 * MPPI_MAX_T];
   const int per = (a.K + gridDim.x - 1) / gridDim.x;
   const int lo = blockIdx.x * per, hi = min(lo + per, a.K);
   const double beta = result[3];
-  const int nacc = 2 + 2 * a.T;
+  const int nacc = 3 + 2 * a.T;
   const int wv = threadIdx.x >> 6;
   const bool lane0 = (threadIdx.x & 63) == 0;
-  for (int j = threadIdx.x; j < 4 * (2 + 2 * MPPI_MAX_T); j += 256) (&red[0][0])[j] = 0.0;
+  for (int j = threadIdx.x; j < 4 * (3 + 2 * MPPI_MAX_T); j += 256) (&red[0][0])[j] = 0.0;
   __syncthreads();
   auto wave_sum = [](double v) {
 #pragma unroll
@@ -235,7 +236,8 @@ mppi_partial_kernel(const double* __restrict__ costs, const double* __restrict__
     const double w = valid ? exp(-(costs[k] - beta) / a.lambda) : 0.0;
     if (valid && weights != nullptr) weights[k] = w;            // un-normalised; the finish kernel divides by eta
     const double sw = wave_sum(w), sw2 = wave_sum(w * w);
-    if (lane0) { red[wv][0] += sw; red[wv][1] += sw2; }
+    const double sc = wave_sum((valid && flags != nullptr && flags[k] == 2) ? 1.0 : 0.0);      // collided rollouts (exact: integers)
+    if (lane0) { red[wv][0] += sw; red[wv][1] += sw2; red[wv][2] += sc; }
     for (int t = 0; t < a.T; ++t) {
       double e0 = 0.0, e1 = 0.0;
       if (valid && a.k0 + k > 0) {
@@ -243,7 +245,7 @@ mppi_partial_kernel(const double* __restrict__ costs, const double* __restrict__
         else mppi_noise(a.seed, a.counter, a.k0 + k, t, a.s0, a.s1, e0, e1);
       }
       const double v0 = wave_sum(w * e0), v1 = wave_sum(w * e1);
-      if (lane0) { red[wv][2 + 2 * t] += v0; red[wv][3 + 2 * t] += v1; }
+      if (lane0) { red[wv][3 + 2 * t] += v0; red[wv][4 + 2 * t] += v1; }
     }
   }
   __syncthreads();
@@ -257,13 +259,9 @@ mppi_partial_kernel(const double* __restrict__ costs, const double* __restrict__
 __global__ void __launch_bounds__(256)
 mppi_finish_kernel(const unsigned char* __restrict__ maze, int rows, int cols, const double* __restrict__ partial, int slices,
                    MppiArgs a, double* __restrict__ state_io, double* __restrict__ U, double* __restrict__ weights,
-                   const int32_t* __restrict__ flags, double* __restrict__ sums, double* __restrict__ result, int do_sums,
-                   int do_apply, int do_execute) {
-  __shared__ int cnt;
-  const int nacc = 2 + 2 * a.T;
+                   double* __restrict__ sums, double* __restrict__ result, int do_sums, int do_apply, int do_execute) {
+  const int nacc = 3 + 2 * a.T;
   if (do_sums) {
-    if (threadIdx.x == 0) cnt = 0;
-    __syncthreads();
     // thread t takes slice t (<= 256 slices); per value a fixed butterfly + a fixed order over the four waves
     __shared__ double wsum[4];
     for (int j = 0; j < nacc; ++j) {
@@ -272,16 +270,9 @@ mppi_finish_kernel(const unsigned char* __restrict__ maze, int rows, int cols, c
       for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
       if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
       __syncthreads();
-      if (threadIdx.x == 0) sums[j < 2 ? j : j + 1] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+      if (threadIdx.x == 0) sums[j] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
       __syncthreads();
     }
-    int c = 0;
-    if (flags != nullptr)
-      for (int k = threadIdx.x; k < a.K; k += 256) c += flags[k] == 2;
-    atomicAdd(&cnt, c);
-    __syncthreads();
-    if (threadIdx.x == 0) sums[2] = (double)cnt;
-    __syncthreads();
   }
   if (do_apply) {
     const double eta = sums[0];
@@ -345,7 +336,7 @@ extern "C" int32_t ditree_mppi_step(ditree_ctx* ctx, const ditree_mppi_params* p
   a.k0 = p->k_offset;
   const int slices = std::min(MPPI_SLICES, (a.K + 255) / 256);      // 256 rollouts per slice up to 65 536, more beyond
   if (!ctx->mppi_partial) {
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->mppi_partial, (size_t)MPPI_SLICES * (2 + 2 * MPPI_MAX_T) * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->mppi_partial, (size_t)MPPI_SLICES * (3 + 2 * MPPI_MAX_T) * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->mppi_minkey, sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->mppi_minkey, 0xFF, sizeof(unsigned long long), s));
   }
@@ -372,10 +363,10 @@ extern "C" int32_t ditree_mppi_step(ditree_ctx* ctx, const ditree_mppi_params* p
   }
   if (stages & DITREE_MPPI_MIN) hipLaunchKernelGGL(mppi_min_kernel, dim3(1), dim3(1), 0, s, ctx->mppi_minkey, result);
   if (stages & DITREE_MPPI_SUMS)
-    hipLaunchKernelGGL(mppi_partial_kernel, dim3(slices), dim3(256), 0, s, costs, noise, a, result, ctx->mppi_partial, weights);
+    hipLaunchKernelGGL(mppi_partial_kernel, dim3(slices), dim3(256), 0, s, costs, noise, a, result, ctx->mppi_partial, weights, flags);
   if (stages & (DITREE_MPPI_SUMS | DITREE_MPPI_APPLY | DITREE_MPPI_EXECUTE))
     hipLaunchKernelGGL(mppi_finish_kernel, dim3(1), dim3(256), 0, s, ctx->maze, ctx->rows, ctx->cols, ctx->mppi_partial, slices,
-                       a, state_io, U_io, weights, flags, sums, result, (stages & DITREE_MPPI_SUMS) ? 1 : 0,
+                       a, state_io, U_io, weights, sums, result, (stages & DITREE_MPPI_SUMS) ? 1 : 0,
                        (stages & DITREE_MPPI_APPLY) ? 1 : 0, (stages & DITREE_MPPI_EXECUTE) ? 1 : 0);
   HIP_TRY(ctx, hipGetLastError());
   return DITREE_OK;
