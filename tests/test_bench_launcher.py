@@ -65,3 +65,14 @@ def test_bench_lidar_round_two_ranks_rehearsed_on_one_gpu():
     out = json.loads(lines[-1])
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["batch_per_gpu"] == 4096
     assert out["scaling"] == "strong" and out["exchange"]["ms_per_round"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_mppi_two_ranks_rehearsed_on_one_gpu():
+    """BASELINE config 5 sharded: the K global rollouts split over 2 ranks, two all-reduces per controller step."""
+    rc, lines, err = _run(["--workload", "mppi", "--global-batch", "8192", "--gpus", "2", "--steps", "20", "--warmup", "3"],
+                          {"DITREE_REHEARSE_ONE_GPU": "1"}, timeout=600)
+    assert rc == 0, err[-3000:]
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["rollouts_per_gpu"] == 4096
+    assert out["scaling"] == "strong" and out["value"] > 0 and out["roofline"]["fp64"]["achieved_tflops"] > 0

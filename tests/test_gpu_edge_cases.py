@@ -190,3 +190,60 @@ def test_shared_context_keeps_each_planners_maze_and_each_nets_weights(ctx):
         n1.get_parameter("unet.final_conv.1.bias").add_(0.5)        # (a scale on a conv in front of a GroupNorm would cancel)
     assert not n1.is_current(ctx)
     assert not torch.equal(n1(x, lm, torch.zeros(4), cd).cpu(), y1)
+
+
+def test_round3_entry_points_argument_and_call_order_errors(ctx):
+    """ditree_mppi_step / ditree_expand_round_ant / ditree_path_after_obstacle / ditree_denoise_status: bad arguments and
+    call order give error codes with a message -- never a fault, never a silent no-op."""
+    from ditreeonlineplanner_amd import _lib
+    from ditreeonlineplanner_amd._lib import DitreeError, check, lib
+    from ditreeonlineplanner_amd.mppi import MPPI
+    maze = load_maze("boxes")
+    f64 = torch.float64
+    # status before any weights: nothing can have saturated
+    assert ctx.denoise_status() == []
+    # path_after_obstacle before a maze
+    out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    path = torch.zeros(8, 6, dtype=torch.float32, device="cuda")
+    cur = (C.c_float * 2)(0.0, 0.0)
+    with pytest.raises(DitreeError, match="no maze"):
+        check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, path.data_ptr(), 6, 8, cur, out.data_ptr(), ctx.stream), "path_after_obstacle")
+    ctx.upload_maze(maze)
+    with pytest.raises(DitreeError, match="bad argument"):
+        check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, path.data_ptr(), 1, 8, cur, out.data_ptr(), ctx.stream), "path_after_obstacle")
+    # a path that crosses nothing: k = -1 (the reference keeps its last point); a path that ends inside an obstacle: k = len
+    free_row = np.stack([np.linspace(-8.5, 8.5, 40), np.full(40, -8.5)], axis=1).astype(np.float32)           # bottom corridor
+    p_dev = dev(free_row)
+    check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, p_dev.data_ptr(), 2, 40, (C.c_float * 2)(-8.5, -8.5), out.data_ptr(), ctx.stream), "x")
+    assert out.cpu().tolist() == [0, -1]
+    into_wall = np.stack([np.linspace(-8.5, 9.5, 40), np.full(40, -8.5)], axis=1).astype(np.float32)         # ends in the border wall
+    check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, dev(into_wall).data_ptr(), 2, 40, (C.c_float * 2)(-8.5, -8.5), out.data_ptr(), ctx.stream), "x")
+    c, k = out.cpu().tolist()
+    assert c == 0 and k == 40
+    # MPPI: construction limits, step before a reference path, bad stage mask / lanes through the C-ABI
+    with pytest.raises(ValueError):
+        MPPI(maze_data=maze, T=65, K=8, ctx=ctx)
+    with pytest.raises(NotImplementedError):
+        MPPI(maze_data=maze, T=8, K=8, nx=29, nu=8, ctx=ctx)
+    m = MPPI(maze_data=maze, T=8, K=16, ctx=ctx)
+    with pytest.raises(DitreeError, match="set_ref_path"):
+        m.step(np.zeros(6))
+    m.set_ref_path(free_row.astype(np.float64))
+    m.reset(start_state=np.array([-8.5, -8.5, 0, 0, 0, 0.0]), goal_state=np.array([8.5, -8.5, 0, 0, 0, 0.0]))
+    for stages in (0, 32, 64):
+        with pytest.raises(DitreeError, match="stages"):
+            m.launch(stages)
+    m.params.lanes = 3
+    with pytest.raises(DitreeError, match="lanes"):
+        m.launch(_lib.MPPI_ALL)
+    m.params.lanes = 0
+    m.params.lam = 0.0
+    with pytest.raises(DitreeError, match="lambda"):
+        m.launch(_lib.MPPI_ALL)
+    m.params.lam = 1.0
+    nxt, a, done = m.step(np.array([-8.5, -8.5, 0, 0, 0, 0.0]))
+    assert done is False and np.isfinite(nxt).all()
+    # the ant round without the ant network / with malformed inputs
+    z = lambda *shape, dt=f64: torch.zeros(*shape, dtype=dt, device="cuda")      # noqa: E731
+    with pytest.raises(DitreeError, match="not loaded"):
+        ctx.expand_round_ant(z(4, 3, 29), z(4, 8), z(4, dt=torch.uint8), z(4, 2), z(4, 2, 16, 8, dt=torch.float32), z(4, 2, 2, 29), np.ones(70))
