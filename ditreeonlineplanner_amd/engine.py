@@ -199,7 +199,10 @@ class ExpansionEngine:
         self.run_type = int(run_type)
         self.init_main_path = None          # (P, >=2) reference path of an earlier plan (run_type > 0)
         self.tree = DeviceTree(ctx, capacity, self.n_chunks, self.A, track_obstacle_ahead=self.run_type > 0)
-        self.rb = RoundBuffers(ctx, batch, self.n_chunks, self.A)
+        # sharded rounds exchange ceil(batch / world) fixed slots per rank: size the round buffers for whole slots, so a batch
+        # that does not divide by the rank count is fine (the last rank's tail slots stay unused)
+        per = (batch + world_size - 1) // world_size
+        self.rb = RoundBuffers(ctx, per * world_size, self.n_chunks, self.A)
         self._budget = self._budget_parent = None
         if len(self.schedule) > 1:
             self._budget = torch.zeros(batch, dtype=torch.int32, device=ctx.device)
@@ -267,8 +270,8 @@ class ExpansionEngine:
         """samples (B,6) f64, cond_goal (B,2) f64 [device tensors, all candidates of the round];
         noise (B, n_chunks, P, 2) f32 or inject_actions (B, n_chunks, P, 2) f64 for this round."""
         B = samples.shape[0]
-        if B > self.rb.B:
-            raise ValueError(f"round of {B} candidates exceeds engine batch {self.rb.B}")
+        if B > self.batch:
+            raise ValueError(f"round of {B} candidates exceeds engine batch {self.batch}")
         lo, hi, per = self.shard(B)
         n = hi - lo
         self.ensure_maze()

@@ -76,3 +76,14 @@ def test_bench_mppi_two_ranks_rehearsed_on_one_gpu():
     out = json.loads(lines[-1])
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["rollouts_per_gpu"] == 4096
     assert out["scaling"] == "strong" and out["value"] > 0 and out["roofline"]["fp64"]["achieved_tflops"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_on_one_gpu():
+    """DITREE_FORCE_DIST=1: the record exchange through the nccl backend (RCCL) with a one-rank group -- the collective, its
+    event timing and `ranks_seen` run on the real backend, which the gloo rehearsals cannot show."""
+    rc, lines, err = _run(["--steps", "2", "--warmup", "1", "--batch", "256", "--no-cpu-baseline", "--no-throughput-line",
+                           "--no-early-exit-line"], {"DITREE_FORCE_DIST": "1"}, timeout=600)
+    assert rc == 0, err[-3000:]
+    out = json.loads(lines[-1])
+    assert out["ranks_seen"] == 1 and out["backend"].startswith("nccl") and out["exchange"]["ms_per_round"] > 0

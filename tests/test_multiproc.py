@@ -55,7 +55,7 @@ def test_shard_partition():
             assert got == list(range(B))
 
 
-def _gpu_worker(rank, world, port, out_path):
+def _gpu_worker(rank, world, port, out_path, B=96):
     sys.path.insert(0, REPO)
     _init(rank, world, port)
     from ditreeonlineplanner_amd.engine import ExpansionEngine
@@ -67,7 +67,6 @@ def _gpu_worker(rank, world, port, out_path):
     start = np.array([*G.cell_rowcol_to_xy([17, 2], maze), np.deg2rad(45.0), 0, 0, 0])
     goal = np.array([*G.cell_rowcol_to_xy([2, 17], maze), 0, 0, 0, 0])
     ctx = Context(0)
-    B = 96
     eng = ExpansionEngine(ctx, maze, start, goal, batch=B, capacity=4096, rank=rank, world_size=world)
     rt, at = ORRT.RandomTape(42), ActionTape(7)
     done = 0
@@ -101,6 +100,23 @@ def test_sharded_round_builds_identical_tree(tmp_path):
         assert np.array_equal(a["path"], b["path"]) and np.array_equal(a["actions"], b["actions"])
         assert set(np.unique(b["owner"][1:]).tolist()) <= {0, 1} and len(np.unique(b["owner"][1:])) == 2
     assert len(a["parents"]) > 50 and len(a["path"]) > 10
+
+
+@pytest.mark.gpu
+def test_sharded_round_four_ranks_ragged_batch(tmp_path):
+    """Four ranks (the most one GPU box may host) and a round size that does not divide by the rank count (97 = 25 + 25 + 25
+    + 22): fixed slots per rank, the last rank's tail slots unused -- the same tree, path and owners as one rank."""
+    out = str(tmp_path / "q{w}_r{rank}.npz")
+    mp.spawn(_gpu_worker, args=(1, 29651, out.replace("{w}", "1"), 97), nprocs=1, join=True)
+    mp.spawn(_gpu_worker, args=(4, 29652, out.replace("{w}", "4"), 97), nprocs=4, join=True)
+    a = np.load(out.replace("{w}", "1").format(rank=0))
+    for r in range(4):
+        b = np.load(out.replace("{w}", "4").format(rank=r))
+        assert np.array_equal(a["parents"], b["parents"]) and np.array_equal(a["states"], b["states"])
+        assert np.array_equal(a["counters"][:5], b["counters"][:5]) and np.array_equal(a["last_action"], b["last_action"])
+        assert np.array_equal(a["path"], b["path"]) and np.array_equal(a["actions"], b["actions"])
+        assert set(np.unique(b["owner"][1:]).tolist()) <= {0, 1, 2, 3} and len(np.unique(b["owner"][1:])) >= 3
+    assert len(a["parents"]) > 50
 
 
 def _gpu_denoiser_worker(rank, world, port, out_path):
