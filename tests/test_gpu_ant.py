@@ -246,9 +246,9 @@ def _oracle_ant_round(net, maze, hist, tape, prev, has_prev, goal, noise, act_me
 
 @pytest.mark.parametrize("n_hist", [1, 3])
 def test_ant_round_sequencing_against_oracle(ctx, ant_net, n_hist):
-    """32 candidates x 24 chunks of A = 2 (cfgs/antmaze.yaml): history carry-over, previous action, stride-29 local maps,
+    """20 candidates x 24 chunks of A = 2 (cfgs/antmaze.yaml): history carry-over, previous action, stride-29 local maps,
     8-d un-normalisation with non-trivial statistics -- against the oracle driven by the same next-observation tape."""
-    B, nC, A = 32, 24, 2
+    B, nC, A = 20, 24, 2
     maze, hist, tape, prev, has_prev, goal, noise = _ant_round_inputs(B, nC, A, n_hist)
     rng = np.random.default_rng(9)
     act_mean, act_std = rng.normal(0, 0.3, 8), rng.uniform(0.6, 1.5, 8)
