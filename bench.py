@@ -195,8 +195,9 @@ def recorded_traffic(tag, precision=None, kernel=None):
     try:
         with open(path) as f:
             ks = json.load(f)["kernels"]
-        k = ks[kernel] if kernel else max(ks.values(), key=lambda v: v.get("hbm_bytes_per_launch", 0) * v.get("launches", 1))
-        return {"traffic": k["hbm_bytes_per_launch"], "traffic_kind": "recorded", "traffic_source": "profiles/" + name,
+        kname = kernel if kernel else max(ks, key=lambda n: ks[n].get("hbm_bytes_per_launch", 0) * ks[n].get("launches", 1))
+        k = ks[kname]
+        return {"traffic": k["hbm_bytes_per_launch"], "traffic_kind": "recorded", "traffic_kernel": kname, "traffic_source": "profiles/" + name,
                 "traffic_unit": "bytes per launch (L2-miss side: FETCH_SIZE*2 + WRITE_SIZE)"}
     except (OSError, KeyError, ValueError):
         return {"traffic": None}
@@ -442,7 +443,7 @@ def run_mppi(args):
                           "rollouts_global": K, "rollouts_per_gpu": Kloc, "horizon": T,
                           "parallelism": f"rollouts sharded x{world}; all-reduce MIN (1 double) + SUM ({3 + 2 * T} doubles) per step"},
                "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                            **recorded_traffic("mppi", kernel="mppi_rollout_kernel"), "kernel": f"mppi_rollout_kernel<{args.mppi_lanes or 4}>",
+                            **recorded_traffic("mppi", kernel="mppi_rollout_kernel"), "kernel": f"mppi_rollout_kernel<{args.mppi_lanes or 2}>",
                             "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": alg, "kernel_time_share": k_ms * 1e-3 * args.steps / elapsed,
                             "fp64": {"achieved_tflops": flop / (k_ms * 1e-3) / 1e12, "peak_tflops": 78.6,
                                      "frac": flop / (k_ms * 1e-3) / 1e12 / 78.6, "flop_per_rollout_step": 900,

@@ -61,6 +61,7 @@ struct ConvGemmParams {
   int* sat;
 };
 
+void denoise_set_dry_run(bool on);   // launchers check their contracts but enqueue nothing (plan validation at reserve time)
 void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s);
 bool conv2d_small_eligible(int fmt);                    // implicit Conv2d layers run on the 64 x 64-tile kernel
 int conv_gemm_kind(const ConvGemmParams& p, int fmt);   // 0 halo kernel, 1 gemm16 / generic, 2 implicit Conv2d

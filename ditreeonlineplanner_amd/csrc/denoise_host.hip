@@ -902,19 +902,24 @@ void DenoiserState::build(int prec_, int Bmax_) {
     }
   }
   if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("sync after build failed");
-  // Validation pass: every op of the plan once, on the zeroed workspace, for the smallest batch unit.  Any layer whose shape
-  // fits no kernel (a future kernel_size / n_groups / embedding width) throws HERE, i.e. ditree_denoise_reserve returns an
-  // error -- not the first denoise call, and never an abort of the host process.
+  // Validation pass: every op of the plan once in DRY-RUN mode (the launchers run their dispatch and shape contracts, nothing is
+  // enqueued).  Any layer whose shape fits no kernel (a future kernel_size / n_groups / embedding width) throws HERE, i.e.
+  // ditree_denoise_reserve returns an error -- not the first denoise call, and never an abort of the host process.
   {
-    std::vector<float> zeros((size_t)bgran * lm * lm, 0.0f);
-    float* lm_dev = (float*)dalloc(zeros.size() * 4);
+    float* lm_dev = (float*)dalloc((size_t)bgran * lm * lm * 4);
     lm_ptr = lm_dev;
-    for (auto& op : enc_ops) op(0, bgran, 0, nullptr);
-    film_op(bgran, bgran, nullptr);
-    for (auto& op : unet_ops) op(bgran, bgran, nullptr);
+    denoise_set_dry_run(true);
+    try {
+      for (auto& op : enc_ops) op(0, bgran, 0, nullptr);
+      film_op(bgran, bgran, nullptr);
+      for (auto& op : unet_ops) op(bgran, bgran, nullptr);
+    } catch (...) {
+      denoise_set_dry_run(false);
+      lm_ptr = nullptr;
+      throw;
+    }
+    denoise_set_dry_run(false);
     lm_ptr = nullptr;
-    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) throw std::runtime_error("validation pass of the denoiser plan failed");
-    if (hipMemset(sat_flags, 0, SAT_SLOTS * sizeof(int)) != hipSuccess) throw std::runtime_error("hipMemset failed");
   }
 }
 

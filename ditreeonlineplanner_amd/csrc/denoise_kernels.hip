@@ -30,6 +30,12 @@
 
 #include "denoise.h"
 
+// Plan validation (DenoiserState::build): every launcher runs its dispatch and shape contracts, but enqueues nothing while the
+// dry-run flag is set -- an unsupported layer shape fails at reserve time, and the validation leaves no launches in a profile.
+static thread_local bool g_dn_dry_run = false;
+void denoise_set_dry_run(bool on) { g_dn_dry_run = on; }
+#define DN_LAUNCH(...) do { if (!g_dn_dry_run) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
 typedef __attribute__((ext_vector_type(8))) short short8_t;
@@ -1914,46 +1920,46 @@ void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
   const dim3 grid(ntm * ntn), block(512);
   if (halo_eligible(p, fmt)) {
     if (split) {
-      if (f16) hipLaunchKernelGGL(conv3_halo16x3_kernel<1>, grid, block, 147456, s, p);
-      else hipLaunchKernelGGL(conv3_halo16x3_kernel<0>, grid, block, 147456, s, p);
+      if (f16) DN_LAUNCH(conv3_halo16x3_kernel<1>, grid, block, 147456, s, p);
+      else DN_LAUNCH(conv3_halo16x3_kernel<0>, grid, block, 147456, s, p);
     } else {
-      if (f16) hipLaunchKernelGGL((conv3_halo16_kernel<1, false>), grid, block, 147456, s, p);
-      else hipLaunchKernelGGL((conv3_halo16_kernel<0, false>), grid, block, 147456, s, p);
+      if (f16) DN_LAUNCH((conv3_halo16_kernel<1, false>), grid, block, 147456, s, p);
+      else DN_LAUNCH((conv3_halo16_kernel<0, false>), grid, block, 147456, s, p);
     }
     return;
   }
   if (gemm16_eligible(p, fmt)) {
     if (split) {
-      if (f16) hipLaunchKernelGGL((gemm16_kernel<1, true>), grid, block, 131072, s, p);
-      else hipLaunchKernelGGL((gemm16_kernel<0, true>), grid, block, 131072, s, p);
+      if (f16) DN_LAUNCH((gemm16_kernel<1, true>), grid, block, 131072, s, p);
+      else DN_LAUNCH((gemm16_kernel<0, true>), grid, block, 131072, s, p);
     } else {
-      if (f16) hipLaunchKernelGGL((gemm16_kernel<1, false>), grid, block, 131072, s, p);
-      else hipLaunchKernelGGL((gemm16_kernel<0, false>), grid, block, 131072, s, p);
+      if (f16) DN_LAUNCH((gemm16_kernel<1, false>), grid, block, 131072, s, p);
+      else DN_LAUNCH((gemm16_kernel<0, false>), grid, block, 131072, s, p);
     }
     return;
   }
   if (p.c2d && conv2d_small_eligible(fmt) && (p.N & 63) == 0 && (p.Cin & 63) == 0 && p.out_f32 && p.mode == MODE_BIAS) {
     const dim3 g2(((p.M + 63) >> 6) * (p.N >> 6), p.splitk > 1 ? p.splitk : 1);
     if (split) {
-      if (f16) hipLaunchKernelGGL((conv2d_small_kernel<1, true>), g2, dim3(256), 3 * 16384, s, p);
-      else hipLaunchKernelGGL((conv2d_small_kernel<0, true>), g2, dim3(256), 3 * 16384, s, p);
+      if (f16) DN_LAUNCH((conv2d_small_kernel<1, true>), g2, dim3(256), 3 * 16384, s, p);
+      else DN_LAUNCH((conv2d_small_kernel<0, true>), g2, dim3(256), 3 * 16384, s, p);
     } else {
-      if (f16) hipLaunchKernelGGL((conv2d_small_kernel<1, false>), g2, dim3(256), 3 * 16384, s, p);
-      else hipLaunchKernelGGL((conv2d_small_kernel<0, false>), g2, dim3(256), 3 * 16384, s, p);
+      if (f16) DN_LAUNCH((conv2d_small_kernel<1, false>), g2, dim3(256), 3 * 16384, s, p);
+      else DN_LAUNCH((conv2d_small_kernel<0, false>), g2, dim3(256), 3 * 16384, s, p);
     }
     return;
   }
   if (split) throw std::runtime_error("conv_gemm: a split GEMM of this shape fits no tile (conv_gemm_supported is the contract)");
   if (p.c2d) {
     const dim3 grid2(ntm * ntn, p.splitk > 1 ? p.splitk : 1);
-    if (st == ST_F32) hipLaunchKernelGGL((conv_gemm_kernel<1, true>), grid2, block, 131072, s, p);
-    else if (f16) hipLaunchKernelGGL((conv_gemm_kernel<2, true>), grid2, block, 131072, s, p);
-    else hipLaunchKernelGGL((conv_gemm_kernel<0, true>), grid2, block, 131072, s, p);
+    if (st == ST_F32) DN_LAUNCH((conv_gemm_kernel<1, true>), grid2, block, 131072, s, p);
+    else if (f16) DN_LAUNCH((conv_gemm_kernel<2, true>), grid2, block, 131072, s, p);
+    else DN_LAUNCH((conv_gemm_kernel<0, true>), grid2, block, 131072, s, p);
     return;
   }
-  if (st == ST_F32) hipLaunchKernelGGL((conv_gemm_kernel<1, false>), grid, block, 131072, s, p);
-  else if (f16) hipLaunchKernelGGL((conv_gemm_kernel<2, false>), grid, block, 131072, s, p);
-  else hipLaunchKernelGGL((conv_gemm_kernel<0, false>), grid, block, 131072, s, p);
+  if (st == ST_F32) DN_LAUNCH((conv_gemm_kernel<1, false>), grid, block, 131072, s, p);
+  else if (f16) DN_LAUNCH((conv_gemm_kernel<2, false>), grid, block, 131072, s, p);
+  else DN_LAUNCH((conv_gemm_kernel<0, false>), grid, block, 131072, s, p);
 }
 
 // ============================================================================= small kernels
@@ -2182,7 +2188,7 @@ void launch_gn1d(void* x, int ld, int Lp, int row_off, int coff, int L, int C, c
   if (fmt_st(fmt) != ST_F32 && L * (C >> 6) <= 256 && (C & 63) == 0 && (ld & 7) == 0 && (coff & 7) == 0 &&
       (mode != MODE_GN_MISH_RES || (ldres & 7) == 0) && (mode != MODE_GN_MISH_FILM || ((film_ld | film_off) & 3) == 0)) {
     const int n_sg = B * 8;
-#define CALLS(F) hipLaunchKernelGGL(gn1d_short_kernel<F>, dim3((n_sg + 3) / 4), dim3(256), 0, s, x, ld, Lp, row_off, coff, L, C, gamma, \
+#define CALLS(F) DN_LAUNCH(gn1d_short_kernel<F>, dim3((n_sg + 3) / 4), dim3(256), 0, s, x, ld, Lp, row_off, coff, L, C, gamma, \
                                     beta, eps, mode, film, film_ld, film_off, res, ldres, res_Lp, res_off, x_plane, res_plane, n_sg, sat)
     switch (fmt) {
       case 0: CALLS(0); break;
@@ -2194,7 +2200,7 @@ void launch_gn1d(void* x, int ld, int Lp, int row_off, int coff, int L, int C, c
 #undef CALLS
     return;
   }
-#define CALL(F) hipLaunchKernelGGL(gn1d_kernel<F>, dim3(B * 8), dim3(256), 0, s, x, ld, Lp, row_off, coff, L, C, gamma, beta, eps, \
+#define CALL(F) DN_LAUNCH(gn1d_kernel<F>, dim3(B * 8), dim3(256), 0, s, x, ld, Lp, row_off, coff, L, C, gamma, beta, eps, \
                                    mode, film, film_ld, film_off, res, ldres, res_Lp, res_off, x_plane, res_plane, sat)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
@@ -2286,8 +2292,8 @@ void launch_encoder_stem(const float* lm, int n, const float* W, const float* ga
   if (n != 20 && n != 16) throw std::runtime_error("encoder stem: local map must be 20 x 20 or 16 x 16");
 #define CALL(F)                                                                                                                    \
   do {                                                                                                                             \
-    if (n == 20) hipLaunchKernelGGL((encoder_stem_kernel<F, 20>), dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps, plane, sat);  \
-    else hipLaunchKernelGGL((encoder_stem_kernel<F, 16>), dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps, plane, sat);          \
+    if (n == 20) DN_LAUNCH((encoder_stem_kernel<F, 20>), dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps, plane, sat);  \
+    else DN_LAUNCH((encoder_stem_kernel<F, 16>), dim3(B), dim3(256), 0, s, lm, W, gamma, beta, out, eps, plane, sat);          \
   } while (0)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
@@ -2313,7 +2319,7 @@ __global__ void prep_sample_kernel(const float* __restrict__ x, void* __restrict
 void launch_prep_sample(const float* x, void* A0, int B, int P, int D, int fmt, long long plane, hipStream_t s, int* sat) {
   long long rows = (long long)B * P;
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define CALL(F) hipLaunchKernelGGL(prep_sample_kernel<F>, grid, block, 0, s, x, A0, B, P, D, plane, sat)
+#define CALL(F) DN_LAUNCH(prep_sample_kernel<F>, grid, block, 0, s, x, A0, B, P, D, plane, sat)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
 }
@@ -2351,7 +2357,7 @@ __global__ void __launch_bounds__(1024) time_embed_kernel(float t, const float* 
 }
 void launch_time_embed(float t, const float* W1, const float* b1, const float* W2, const float* b2, float* out,
                        hipStream_t s) {
-  hipLaunchKernelGGL(time_embed_kernel, dim3(1), dim3(1024), 0, s, t, W1, b1, W2, b2, out);
+  DN_LAUNCH(time_embed_kernel, dim3(1), dim3(1024), 0, s, t, W1, b1, W2, b2, out);
 }
 
 // FiLM input: Mish(cat(time_emb 256, map_emb E, obs_cond G)) zero-padded to Kpad columns
@@ -2375,7 +2381,7 @@ __global__ void prep_cond_kernel(const float* __restrict__ temb, const float* __
 }
 void launch_prep_cond(const float* temb, const float* map_emb, int E, int E_ld, const float* cond, int G, void* out, int B,
                       int Kpad, int fmt, long long plane, hipStream_t s, int* sat) {
-#define CALL(F) hipLaunchKernelGGL(prep_cond_kernel<F>, dim3(B), dim3(256), 0, s, temb, map_emb, E, E_ld, cond, G, out, B, Kpad, plane, sat)
+#define CALL(F) DN_LAUNCH(prep_cond_kernel<F>, dim3(B), dim3(256), 0, s, temb, map_emb, E, E_ld, cond, G, out, B, Kpad, plane, sat)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
 }
@@ -2449,7 +2455,7 @@ void launch_final_proj_flow(const void* Y, int C, int Lp, long long plane, const
   dim3 grid((unsigned)((pos + 3) / 4)), block(256);
   ActNormArg nm{};
   for (int d = 0; d < D && d < 8; ++d) { nm.mu[d] = act_norm[d]; nm.sg[d] = act_norm[D + d]; }
-#define CALLD(F, DD) hipLaunchKernelGGL((final_proj_flow_kernel<F, DD>), grid, block, 0, s, Y, C, Lp, plane, W, bias, x, dt, nm, actions, B, P, raw)
+#define CALLD(F, DD) DN_LAUNCH((final_proj_flow_kernel<F, DD>), grid, block, 0, s, Y, C, Lp, plane, W, bias, x, dt, nm, actions, B, P, raw)
 #define CALL(F) do { if (D == 2) CALLD(F, 2); else if (D == 8) CALLD(F, 8); else throw std::runtime_error("final projection: action_dim must be 2 or 8"); } while (0)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
@@ -2483,8 +2489,8 @@ __global__ void im2col2d_kernel(const void* __restrict__ in, void* __restrict__ 
 void launch_im2col2d(const void* in, bool src_f32, void* out, int B, int H, int W, int C, const TapList& taps, int stride,
                      int pad, int OH, int OW, int Kpad, int fmt, hipStream_t s) {
   dim3 grid((unsigned)((long long)B * OH * OW)), block(Kpad >= 256 ? 256 : 64);
-#define CALL(F) do { if (src_f32) hipLaunchKernelGGL((im2col2d_kernel<F, true>), grid, block, 0, s, in, out, B, H, W, C, taps, stride, pad, OH, OW, Kpad); \
-                     else hipLaunchKernelGGL((im2col2d_kernel<F, false>), grid, block, 0, s, in, out, B, H, W, C, taps, stride, pad, OH, OW, Kpad); } while (0)
+#define CALL(F) do { if (src_f32) DN_LAUNCH((im2col2d_kernel<F, true>), grid, block, 0, s, in, out, B, H, W, C, taps, stride, pad, OH, OW, Kpad); \
+                     else DN_LAUNCH((im2col2d_kernel<F, false>), grid, block, 0, s, in, out, B, H, W, C, taps, stride, pad, OH, OW, Kpad); } while (0)
   DISPATCH_ST(fmt, CALL)
 #undef CALL
 }
@@ -2604,7 +2610,7 @@ void launch_gn2d(const float* in, int nslab, long long slab_stride, const float*
   if (C < 64 || C > 1024 || (C & (C - 1)) != 0 || (HW + 256 / (C >> 2) - 1) / (256 / (C >> 2)) > GN2D_MAXP)
     throw std::runtime_error("encoder GroupNorm: unsupported map shape");
   dim3 grid((unsigned)B), block(256);
-#define CALL(F) hipLaunchKernelGGL(gn2d_kernel<F>, grid, block, 0, s, in, nslab, slab_stride, gamma, beta, res, relu, out, HW, C, eps, \
+#define CALL(F) DN_LAUNCH(gn2d_kernel<F>, grid, block, 0, s, in, nslab, slab_stride, gamma, beta, res, relu, out, HW, C, eps, \
                                    res_plane, out_plane, sat)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
@@ -2633,7 +2639,7 @@ __global__ void maxpool2d_kernel(const void* __restrict__ in, void* __restrict__
 void launch_maxpool2d(const void* in, void* out, int B, int H, int W, int C, int OH, int OW, int fmt, hipStream_t s) {
   long long total = (long long)B * OH * OW * C;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
-#define CALL(F) hipLaunchKernelGGL(maxpool2d_kernel<F>, grid, block, 0, s, in, out, B, H, W, C, OH, OW)
+#define CALL(F) DN_LAUNCH(maxpool2d_kernel<F>, grid, block, 0, s, in, out, B, H, W, C, OH, OW)
   DISPATCH_ST(fmt, CALL)
 #undef CALL
 }
@@ -2653,7 +2659,7 @@ void launch_avgpool2d(const void* in, void* out, int B, int HW, int C, int fmt, 
                       hipStream_t s) {
   long long total = (long long)B * C;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
-#define CALL(F) hipLaunchKernelGGL(avgpool2d_kernel<F>, grid, block, 0, s, in, out, B, HW, C, in_plane, out_plane)
+#define CALL(F) DN_LAUNCH(avgpool2d_kernel<F>, grid, block, 0, s, in, out, B, HW, C, in_plane, out_plane)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
 }
@@ -2672,7 +2678,7 @@ void launch_unpack_act(const void* in, int ld, int coff, int Lp, int roff, float
                        long long plane, hipStream_t s) {
   long long total = (long long)B * L * C;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
-#define CALL(F) hipLaunchKernelGGL(unpack_act_kernel<F>, grid, block, 0, s, in, ld, coff, Lp, roff, out, B, L, C, plane)
+#define CALL(F) DN_LAUNCH(unpack_act_kernel<F>, grid, block, 0, s, in, ld, coff, Lp, roff, out, B, L, C, plane)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL
 }
