@@ -67,7 +67,8 @@ struct DenoiserState {
   int dims[3] = {512, 1024, 2048};
   bool loaded = false;
   // workspace
-  int prec = -1, Bmax = 0;     // prec: the DITREE_PREC_* the workspace was built for
+  int prec = -1, Bmax = 0;     // prec: the DITREE_PREC_* the workspace was built for; Bmax: samples the WORKSPACE holds
+  int Buser = 0;               // samples the caller reserved for: calls up to this size are served in sub-batches of <= Bmax
   int bgran = 16;              // batch rows are padded to a multiple of this
   int ufmt = 0, efmt = 0;      // formats (denoise.h) of the U-Net activations / GEMMs and of the encoder
   std::vector<void*> allocs;
@@ -225,6 +226,7 @@ struct DenoiserState {
     sat_names.clear();
     prec = -1;
     Bmax = 0;
+    Buser = 0;
     temb_t = -1.0f;
   }
 
@@ -488,7 +490,19 @@ void DenoiserState::build(int prec_, int Bmax_) {
   // rows of a batch are padded to whole work units: 16 samples, or -- the split formats exist on the 256-row halo / gemm16
   // tiles only -- as many as fill a tile at the shortest level (P / 4 rows per sample: 64 samples at P = 16)
   bgran = fmt_split(ufmt) ? std::max(16, 1024 / P) : 16;
+  Buser = Bmax_;
   Bmax = (Bmax_ + bgran - 1) / bgran * bgran;
+  {
+    // The split kernels reach the lo plane through a 32-bit buffer offset, so an activation plane must stay below 2 GiB; and
+    // nothing is gained by a workspace beyond a few thousand samples (every layer already launches >> 256 tiles).  Larger
+    // calls run as sub-batches of `Bmax` samples (denoise_core): the reserved batch is a capacity, not a workspace size.
+    const long long per_sample = std::max({(long long)(L2 + 2) * 2 * C2, (long long)(L1 + 2) * 2 * C1, (long long)(L0 + 2) * C0,
+                                           (long long)L0 * 64}) * fmt_es(ufmt);
+    long long cap = std::min<long long>(8192, 0x7f000000LL / per_sample);
+    cap = cap / 256 * 256;
+    if (cap < 256) throw std::runtime_error("denoiser too large for one 256-sample work unit");
+    if (Bmax > cap) Bmax = (int)cap;
+  }
   if (fmt_split(ufmt) && ((C0 | C1 | C2) & 255) != 0)
     throw std::runtime_error("the split precisions need down_dims that are multiples of 256 (halo / gemm16 tiles)");
   x_cur = (float*)dalloc((size_t)Bmax * P * D * 4);
@@ -976,6 +990,11 @@ static int denoise_core(ditree_ctx* ctx, const float* noise, int64_t noise_strid
                         const double* act_norm, double* actions, float* x_out, hipStream_t s, float t_scale, int raw,
                         int reuse_encoder);
 
+static int denoise_core_one(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const int32_t* noise_idx,
+                            const float* local_map, const float* cond, int B, int K, const float* t0, const float* dt,
+                            const double* act_norm, double* actions, float* x_out, hipStream_t s, float t_scale, int raw,
+                            int reuse_encoder);
+
 int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const int32_t* noise_idx, const float* local_map,
                 const float* cond, int B, int K, const float* t0, const float* dt, const double* act_norm, double* actions,
                 float* x_out, hipStream_t s) {
@@ -983,9 +1002,8 @@ int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const
                       20.0f /* pos_emb_scale, fm_policy.py:187 */, 0, 0);
 }
 
-// t_scale: factor on t0[k] before the sinusoidal embedding (20 for the flow sampler, 1 for a raw evaluation);
-// raw: the last projection writes the network output instead of the Euler update; reuse_encoder: keep the map
-// embedding of the previous call (same local maps: the steps of a DDPM loop).
+// A call of up to the reserved batch: rows are independent, so it runs as sub-batches of at most the workspace size (every
+// pointer advances by the rows done; a compacted round's noise index list advances with them).
 static int denoise_core(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const int32_t* noise_idx,
                         const float* local_map, const float* cond, int B, int K, const float* t0, const float* dt,
                         const double* act_norm, double* actions, float* x_out, hipStream_t s, float t_scale, int raw,
@@ -993,7 +1011,33 @@ static int denoise_core(ditree_ctx* ctx, const float* noise, int64_t noise_strid
   DenoiserState* st = ctx->dn;
   if (!st || !st->loaded) return set_err(ctx, DITREE_E_STATE, "denoise: weights not loaded");
   if (st->prec < 0) return set_err(ctx, DITREE_E_STATE, "denoise: call ditree_denoise_reserve first");
-  if (B <= 0 || B > st->Bmax) return set_err(ctx, DITREE_E_ARG, "denoise: batch exceeds the reserved workspace");
+  if (B <= 0 || B > st->Buser) return set_err(ctx, DITREE_E_ARG, "denoise: batch exceeds the reserved workspace");
+  if (B <= st->Bmax)
+    return denoise_core_one(ctx, noise, noise_stride, noise_idx, local_map, cond, B, K, t0, dt, act_norm, actions, x_out, s,
+                            t_scale, raw, reuse_encoder);
+  if (!noise || !local_map || !cond) return set_err(ctx, DITREE_E_ARG, "denoise: bad argument");
+  const size_t PD = (size_t)st->P * st->D, LM = (size_t)st->lm * st->lm;
+  for (int b0 = 0; b0 < B; b0 += st->Bmax) {
+    const int bn = std::min(st->Bmax, B - b0);
+    // (the map embedding of a previous call covers one sub-batch only: larger calls recompute it)
+    const int rc = denoise_core_one(ctx, noise_idx ? noise : noise + (size_t)b0 * noise_stride, noise_stride,
+                                    noise_idx ? noise_idx + b0 : nullptr, local_map + (size_t)b0 * LM, cond + (size_t)b0 * st->G, bn,
+                                    K, t0, dt, act_norm, actions ? actions + (size_t)b0 * PD : nullptr,
+                                    x_out ? x_out + (size_t)b0 * PD : nullptr, s, t_scale, raw, 0);
+    if (rc) return rc;
+  }
+  return DITREE_OK;
+}
+
+// t_scale: factor on t0[k] before the sinusoidal embedding (20 for the flow sampler, 1 for a raw evaluation);
+// raw: the last projection writes the network output instead of the Euler update; reuse_encoder: keep the map
+// embedding of the previous call (same local maps: the steps of a DDPM loop).
+static int denoise_core_one(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const int32_t* noise_idx,
+                            const float* local_map, const float* cond, int B, int K, const float* t0, const float* dt,
+                            const double* act_norm, double* actions, float* x_out, hipStream_t s, float t_scale, int raw,
+                            int reuse_encoder) {
+  DenoiserState* st = ctx->dn;
+  if (B <= 0 || B > st->Bmax) return set_err(ctx, DITREE_E_ARG, "denoise: batch exceeds the workspace");
   if (!noise || !local_map || !cond || !t0 || !dt || !act_norm || K <= 0 || (!actions && !x_out))
     return set_err(ctx, DITREE_E_ARG, "denoise: bad argument");
   const int Bp = (B + st->bgran - 1) / st->bgran * st->bgran;
@@ -1127,7 +1171,7 @@ int32_t ditree_denoise_reserve(ditree_ctx* ctx, int32_t max_batch, int32_t preci
   if (max_batch <= 0 || precision < DITREE_PREC_BF16 || precision > DITREE_PREC_F16)
     return set_err(ctx, DITREE_E_ARG, "denoise_reserve: bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (st->prec == precision && st->Bmax >= max_batch) return DITREE_OK;
+  if (st->prec == precision && st->Buser >= max_batch) return DITREE_OK;
   try {
     HIP_TRY(ctx, hipDeviceSynchronize());
     st->build(precision, max_batch);

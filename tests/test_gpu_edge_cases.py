@@ -247,3 +247,28 @@ def test_round3_entry_points_argument_and_call_order_errors(ctx):
     z = lambda *shape, dt=f64: torch.zeros(*shape, dtype=dt, device="cuda")      # noqa: E731
     with pytest.raises(DitreeError, match="not loaded"):
         ctx.expand_round_ant(z(4, 3, 29), z(4, 8), z(4, dt=torch.uint8), z(4, 2), z(4, 2, 16, 8, dt=torch.float32), z(4, 2, 2, 29), np.ones(70))
+
+
+def test_rounds_on_a_side_stream_equal_rounds_on_the_default_stream(ctx):
+    """Every entry point enqueues on the stream it is handed (torch's CURRENT stream through the front end): an expansion on a
+    non-default stream gives the same tree, and is ordered with respect to that stream only."""
+    from ditreeonlineplanner_amd.engine import ExpansionEngine
+    maze = load_maze("boxes")
+    start = np.array([*G.cell_rowcol_to_xy([17, 2], maze), np.deg2rad(45.0), 0, 0, 0])
+    goal = np.array([*G.cell_rowcol_to_xy([2, 17], maze), 0, 0, 0, 0])
+    trees = []
+    for side in (False, True):
+        eng = ExpansionEngine(ctx, maze, start, goal, batch=64, capacity=2048)
+        rt, at = ORRT.RandomTape(42), ActionTape(5)
+        stream = torch.cuda.Stream() if side else torch.cuda.current_stream()
+        with torch.cuda.stream(stream):
+            done = 0
+            for _ in range(4):
+                s, c = rt.draw_round(64, maze.shape[1], maze.shape[0], goal)
+                acts = np.stack([at.actions(np.arange(done, done + 64), j) for j in range(eng.n_chunks)], axis=1)
+                eng.expand_round(dev(s), dev(c), inject_actions=dev(acts))
+                done += 64
+            stream.synchronize()
+            trees.append(eng.tree_snapshot())
+    assert np.array_equal(trees[0]["parents"], trees[1]["parents"]) and np.array_equal(trees[0]["states"], trees[1]["states"])
+    assert len(trees[0]["parents"]) > 20

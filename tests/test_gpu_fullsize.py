@@ -153,6 +153,32 @@ def test_denoiser_batch_1024_rows_independent(ctx):
         assert torch.equal(part, full[lo:lo + 16])
 
 
+def test_denoiser_call_larger_than_the_workspace_runs_as_sub_batches(ctx):
+    """The reserved batch is a capacity: the activation workspace is capped at 8192 samples (split formats: an activation plane
+    must stay below 2 GiB, 14 k samples for the large network), larger calls run as sub-batches.  9000 rows (8192 + a ragged
+    808): rows on both sides of the sub-batch boundary equal the same rows computed alone, and a call beyond the reserved
+    batch is still refused."""
+    from ditreeonlineplanner_amd._lib import DitreeError
+    from ditreeonlineplanner_amd.model import NoisePredNet
+    net = NoisePredNet(seed=3)
+    B = 9000
+    for prec in (0, 2):
+        net.bind(ctx, precision=prec, max_batch=B)
+        g = torch.Generator().manual_seed(9)
+        noise = torch.randn(B, 64, 2, generator=g).cuda()
+        lm = (torch.rand(B, 20, 20, generator=g) > 0.7).float().cuda() * 2 - 1
+        cond = (torch.randn(B, 7, generator=g) * 0.5).cuda()
+        full = ctx.denoise(noise, lm, cond, want_actions=False)
+        acts = ctx.denoise(noise, lm, cond, want_actions=True)
+        assert torch.isfinite(full).all() and acts.shape == (B, 64, 2)
+        for lo in (0, 8184, 8192, 8984):
+            part = ctx.denoise(noise[lo:lo + 16].contiguous(), lm[lo:lo + 16].contiguous(), cond[lo:lo + 16].contiguous(),
+                               want_actions=False)
+            assert torch.equal(part, full[lo:lo + 16]), (prec, lo)
+        with pytest.raises(DitreeError, match="exceeds"):
+            ctx.denoise(torch.cat([noise, noise[:8]]), torch.cat([lm, lm[:8]]), torch.cat([cond, cond[:8]]), want_actions=False)
+
+
 @pytest.mark.parametrize("B", [1000, 513, 100, 31])
 def test_denoiser_ragged_batches_equal_full_batch_rows(ctx, B):
     """Partially filled GEMM tiles, ragged encoder tiles and padded sample rows: the first B rows of a ragged batch are

@@ -229,3 +229,32 @@ def test_driver_surface(ctx):
     assert m._path.shape[0] == 4096 and len(m.reference_path) == len(long_path)
     nxt, action, done = m.step(start)
     assert done is False and nxt.shape == (6,)
+
+
+def test_known_obstacle_bends_the_controls_away_from_the_reference_path(ctx):
+    """update_maze: a cell on the reference path becomes occupied in the KNOWN maze (the lidar's finding).  The planning
+    rollouts collide there, so the controller stops following the path into it: with the obstacle known it never collides
+    (the executed step is checked against the same maze) and keeps its distance, where the controller that does not know it
+    drives straight through the cell."""
+    maze = load_maze("boxes")
+    blocked = maze.copy()
+    blocked[18, 9] = 1                                             # on the bottom corridor, 8 cells ahead of the start
+    cell_xy = G.cell_rowcol_to_xy([18, 9], maze)
+    out = {}
+    for name, known in (("unknown", maze), ("known", blocked)):
+        m, _, path, start = make(ctx, 2048, 16, seed=11)
+        m.update_maze(known)
+        state = start.copy()
+        closest = np.inf
+        for step in range(1500):
+            nxt, action, done = m.step(state)
+            if done is None:
+                break
+            state = nxt
+            closest = min(closest, float(np.hypot(state[0] - cell_xy[0], state[1] - cell_xy[1])))
+            if closest < 0.3 or state[0] > cell_xy[0] + 1.0:
+                break
+        out[name] = (closest, done, state.copy())
+    assert out["unknown"][0] < 0.3                                 # drives through the cell it does not know about
+    assert out["known"][1] is not None or out["known"][0] > 0.55   # never inside the occupied cell (half-width 0.5 + ball)
+    assert out["known"][0] > 0.55, out["known"]
