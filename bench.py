@@ -144,6 +144,10 @@ def launch_ranks(argv, n):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    import signal
+    # a terminated launcher must not leave its ranks behind: turn SIGTERM / SIGHUP into an exit that runs the cleanup below
+    for sig in (signal.SIGTERM, signal.SIGHUP):
+        signal.signal(sig, lambda signum, frame: sys.exit(128 + signum))
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
@@ -266,6 +270,7 @@ def run_dry(args):
         dist.destroy_process_group()
     if os.environ.get("DITREE_BENCH_DRYRUN_FAIL_RANK", "") == str(rank):
         raise SystemExit(7)
+    time.sleep(float(os.environ.get("DITREE_BENCH_DRYRUN_SLEEP", "0")))       # tests of the launcher's cleanup
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": seen, "workload": args.workload,
                           "note": "launcher rehearsal on CPU: not a measurement"}), flush=True)

@@ -87,3 +87,26 @@ def test_bench_rccl_path_on_one_gpu():
     assert rc == 0, err[-3000:]
     out = json.loads(lines[-1])
     assert out["ranks_seen"] == 1 and out["backend"].startswith("nccl") and out["exchange"]["ms_per_round"] > 0
+
+
+def test_launcher_takes_its_ranks_down_when_it_is_terminated(tmp_path):
+    """SIGTERM to the launcher (a driver's timeout) must end the rank processes it started, not orphan them."""
+    import signal
+    import time
+    env = dict(os.environ, DITREE_BENCH_DRYRUN="1", DITREE_BENCH_DRYRUN_SLEEP="60")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--steps", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    kids = []
+    for _ in range(100):                                   # wait until both ranks exist
+        out = subprocess.run(["ps", "-o", "pid=", "--ppid", str(p.pid)], stdout=subprocess.PIPE).stdout.split()
+        kids = [int(x) for x in out]
+        if len(kids) >= 2:
+            break
+        time.sleep(0.1)
+    assert len(kids) >= 2
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    time.sleep(0.5)
+    for k in kids:
+        assert not os.path.exists(f"/proc/{k}") or open(f"/proc/{k}/stat").read().split()[2] == "Z", k
