@@ -2,7 +2,8 @@
 
 Constructor kwargs, ``plan() -> (path f32 (P,6)|None, actions f32 (A,2)|None)``, ``reset``,
 ``update_maze``, ``results`` and ``node_list`` follow the reference.  Extra kwargs:
-  ``batch``            candidates per round (default 256; 1 = the reference's sequential order),
+  ``batch``            candidates per round (default 512 = one full wave of 256-row tiles on the 256 CUs for the `large`
+                       denoiser: rounds of 128 and 256 take the same time as each other; 1 = the reference's sequential order),
   ``max_candidates``   deterministic budget instead of / in addition to the wall-clock budget,
   ``early_exit``       (default True) later chunks of collided / finished candidates are skipped, as the
                        reference abandons a collided edge; results are identical either way,
@@ -47,7 +48,7 @@ class RRT_Planner(BasePlanner):
         self.init_main_path = None
         self.run_type = kwargs.get("run_type", 0)
         self.env.run_type = self.run_type
-        self.batch = int(kwargs.get("batch", 256))
+        self.batch = int(kwargs.get("batch", 512))
         self.max_candidates = kwargs.get("max_candidates", None)
         self.capacity = int(kwargs.get("capacity", 65536))
         lm = self.local_map_size if isinstance(self.local_map_size, (int, float)) else self.local_map_size[0]
