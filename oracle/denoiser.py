@@ -19,7 +19,10 @@ the reference's constructor order, so ``torch.manual_seed(s)`` followed by
 construction yields bit-identical weights to the reference class (verified by
 tests/golden/make_golden.py when the goldens are generated).  torchvision is absent
 from the build container, so the ResNet-18 half follows the published torchvision
-0.22 topology and is **parity unpinned** against the reference.
+0.22 topology and is **parity unpinned** against the reference.  It is cross-checked
+against an independent implementation of the same architecture (transformers'
+ResNetModel with the BatchNorm -> GroupNorm(C/16) rule applied):
+tests/test_oracle_encoder_crosscheck.py.
 """
 from __future__ import annotations
 
