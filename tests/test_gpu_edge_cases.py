@@ -272,3 +272,44 @@ def test_rounds_on_a_side_stream_equal_rounds_on_the_default_stream(ctx):
             trees.append(eng.tree_snapshot())
     assert np.array_equal(trees[0]["parents"], trees[1]["parents"]) and np.array_equal(trees[0]["states"], trees[1]["states"])
     assert len(trees[0]["parents"]) > 20
+
+
+def test_round3_kernels_at_their_smallest_and_odd_sizes(ctx):
+    """Degenerate sizes of the new kernels: one rollout / one step / a one-point path, odd rollout counts across the lane
+    groups and slices, a one-candidate ant round, a one-point reference path -- results finite and consistent, no fault."""
+    from ditreeonlineplanner_amd import _lib
+    from ditreeonlineplanner_amd._lib import check, lib
+    from ditreeonlineplanner_amd.mppi import MPPI
+    from oracle import mppi as OM
+    maze = load_maze("boxes")
+    start = np.array([-8.5, -8.5, 0.0, 1.0, 0.2, 0.0])
+    goal = np.array([8.5, -8.5, 0, 0, 0, 0.0])
+    for K, T, P, lanes in ((1, 1, 1, 1), (3, 5, 2, 2), (127, 7, 33, 4), (257, 16, 100, 2), (1000, 64, 4096, 4)):
+        m = MPPI(maze_data=maze, T=T, K=K, lanes=lanes, seed=K, ctx=ctx)
+        m.reset(start_state=start, goal_state=goal)
+        path = np.stack([np.linspace(-8.5, 8.5, P), np.full(P, -8.5)], axis=1)
+        m.set_ref_path(path)
+        nxt, a, done = m.step(start)
+        assert done is False and np.isfinite(nxt).all() and np.isfinite(a).all(), (K, T, P)
+        assert 0 < m.last["effective_samples"] <= K + 1e-9 and m.last["eta"] >= 1.0 - 1e-12
+        # the same call on the numpy restatement (device noise mirrored on the host)
+        kw = dict(lam=1.0, sigma=(3.0, 0.6), w_track=20.0, w_progress=0.5, w_collision=1e3, w_goal=50.0, window_back=8, window_fwd=56)
+        eps = OM.device_noise(K, 0, K, T, kw["sigma"])
+        rc, rf, _ = OM.rollout_costs(maze, start, np.zeros((T, 2)), path, m.env.goal, eps, **kw)
+        assert np.abs(m._costs.cpu().numpy() - rc).max() < 1e-9 * max(1.0, np.abs(rc).max()), (K, T, P)
+    # one-point reference path for extract_path_after_obstacle
+    out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ctx.upload_maze(maze)
+    one = dev(np.array([[-8.5, -8.5]], dtype=np.float32))
+    check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, one.data_ptr(), 2, 1, (C.c_float * 2)(0.0, 0.0), out.data_ptr(), ctx.stream), "x")
+    assert out.cpu().tolist() == [0, -1]
+    # a one-candidate, one-chunk ant round
+    from ditreeonlineplanner_amd.model import NoisePredNet
+    net = NoisePredNet(input_dim=8, additional_global_cond_dim=97, pred_horizon=16, local_map_size=16, seed=0)
+    net.bind(ctx, precision=_lib.PREC_F16X3, max_batch=1)
+    rng = np.random.default_rng(0)
+    hist = rng.normal(size=(1, 1, 29))
+    hist[..., 3:7] = np.array([0.0, 0.0, 0.0, 1.0])
+    a, end = ctx.expand_round_ant(dev(hist), dev(np.zeros((1, 8))), dev(np.zeros(1, dtype=np.uint8)), dev(np.zeros((1, 2))),
+                                  torch.randn(1, 1, 16, 8, device="cuda"), dev(rng.normal(size=(1, 1, 2, 29))), np.concatenate([np.zeros(27), np.ones(27), np.zeros(8), np.ones(8)]))
+    assert a.shape == (1, 1, 2, 8) and torch.isfinite(a).all() and end.shape == (1, 29)
