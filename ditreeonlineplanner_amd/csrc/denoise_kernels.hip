@@ -79,6 +79,9 @@ __device__ __forceinline__ void sat_flush(int* flag, float m) {
 // and so did carrying the wave's compare mask): there the maximum of a ROW is formed in a transient register, compared once,
 // and the flag is written right away behind a wave-uniform branch that is never taken in a healthy network.
 __device__ __forceinline__ void sat_check_row(int* flag, const float (&v)[8]) {
+#ifdef DITREE_NO_RANGE_GUARD      // measurement build only: what the guard costs in the MFMA epilogues
+  return;
+#endif
   float t = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fabsf(v[2]));
   t = __builtin_fmaxf(__builtin_fmaxf(t, __builtin_fabsf(v[3])), __builtin_fabsf(v[4]));
   t = __builtin_fmaxf(__builtin_fmaxf(t, __builtin_fabsf(v[5])), __builtin_fabsf(v[6]));
