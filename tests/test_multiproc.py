@@ -41,6 +41,11 @@ def test_allgather_fields_gloo_cpu(B):
     mp.spawn(_cpu_worker, args=(2, 29531 + B, B), nprocs=2, join=True)
 
 
+def test_allgather_fields_gloo_cpu_eight_ranks():
+    """The rank count of the target node (8): fixed slots per rank, a ragged round (8190 = 7 x 1024 + 1022)."""
+    mp.spawn(_cpu_worker, args=(8, 29571, 8190), nprocs=8, join=True)
+
+
 def test_shard_partition():
     from ditreeonlineplanner_amd.engine import ExpansionEngine
     for world in (1, 2, 4, 8):
