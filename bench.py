@@ -452,7 +452,7 @@ def run_mppi(args):
                             "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": alg, "kernel_time_share": k_ms * 1e-3 * args.steps / elapsed,
                             "fp64": {"achieved_tflops": flop / (k_ms * 1e-3) / 1e12, "peak_tflops": 78.6,
                                      "frac": flop / (k_ms * 1e-3) / 1e12 / 78.6, "flop_per_rollout_step": 900,
-                                     "note": "the governing unit: a sequential FP64 chain per rollout (4 lanes share one rollout); flop count from the source, fma = 2"},
+                                     "note": "the governing unit: a sequential FP64 chain per rollout (2 lanes share one rollout by default); flop count from the source, fma = 2"},
                             "note": "noise is generated on the device: the kernel writes 12 B per rollout and reads ~30 KB of shared inputs per work-group out of L2"},
                "controller": {"state_xy": [float(state[0][0]), float(state[0][1])], **m.last}, **comm}
         res["controller"].update({"collided_rollouts_last_step": int(m._result[6].item()), "effective_samples_last_step": float(m._result[7].item())})
