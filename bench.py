@@ -380,7 +380,11 @@ def run_mppi(args):
     from ditreeonlineplanner_amd import _lib
     from ditreeonlineplanner_amd.mppi import MPPI
     from ditreeonlineplanner_amd.ops import Context
-    K = args.global_batch or (args.batch if args.batch_set else 65536)
+    # --global-batch K: K rollouts split over the ranks (strong scaling; default 65 536 = BASELINE config 5);
+    # --batch K: K rollouts PER GPU (weak scaling: the step is latency-bound at 8 192 rollouts per GPU, so this is the mode
+    # in which more GPUs buy more samples per controller step)
+    weak = args.batch_set and not args.global_batch
+    K = args.batch * world if weak else (args.global_batch or 65536)
     T = args.horizon or 16
     maze = load_maze("boxes")
     ctx = Context(local)
@@ -441,7 +445,7 @@ def run_mppi(args):
         flop = Kloc * T * 900.0
         res = {"metric": "MPPI rollouts/sec (controller step: K x T=16 car rollouts with collision / goal / path-tracking cost, soft-min update, one executed step)",
                "value": K * args.steps / elapsed, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
                "dtype": "f64", "data": _data(rehearse),
                "config": {"workload": f"BASELINE config 5: {K} MPPI rollouts (global) x T={T}, car model on boxes.csv, L-shaped reference path of "
                                       f"{len(path)} points, on-device noise; the build's own controller (the reference ships no MPPI module: parity unpinned)",
