@@ -3,7 +3,8 @@
 Constructor kwargs, ``plan() -> (path f32 (P,6)|None, actions f32 (A,2)|None)``, ``reset``,
 ``update_maze``, ``results`` and ``node_list`` follow the reference.  Extra kwargs:
   ``batch``            candidates per round (default 512 = one full wave of 256-row tiles on the 256 CUs for the `large`
-                       denoiser: rounds of 128 and 256 take the same time as each other; 1 = the reference's sequential order),
+                       denoiser: rounds of 128 and 256 take the same time as each other, multiples of 512 fill whole waves; 1 = the
+                       reference's sequential order),
   ``max_candidates``   deterministic budget instead of / in addition to the wall-clock budget,
   ``early_exit``       (default True) later chunks of collided / finished candidates are skipped, as the
                        reference abandons a collided edge; results are identical either way,
