@@ -87,6 +87,16 @@ def test_bench_rccl_path_on_one_gpu():
     assert rc == 0, err[-3000:]
     out = json.loads(lines[-1])
     assert out["ranks_seen"] == 1 and out["backend"].startswith("nccl") and out["exchange"]["ms_per_round"] > 0
+    # the driver's contract for the line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert out["metric"].startswith("candidate tree-expansions/sec (carmaze, H=32)") and out["vs_baseline"] is None
+    assert out["dtype"] == "f16x3" and "workload" in out["config"] and out["higher_is_better"] is True
+    r = out["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel"].startswith("conv3_halo16x3_kernel")
 
 
 def test_launcher_takes_its_ranks_down_when_it_is_terminated(tmp_path):
