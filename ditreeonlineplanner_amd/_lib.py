@@ -28,11 +28,12 @@ class DitreeError(RuntimeError):
 
 class Tree(C.Structure):
     _fields_ = [("capacity", C.c_int32), ("n_chunks", C.c_int32), ("A", C.c_int32),
+                ("state_dim", C.c_int32), ("action_dim", C.c_int32),
                 ("state", C.c_void_p), ("xy", C.c_void_p), ("parent", C.c_void_p),
                 ("last_action", C.c_void_p), ("has_prev", C.c_void_p), ("num_visit", C.c_void_p),
                 ("edge_states", C.c_void_p), ("edge_actions", C.c_void_p),
                 ("edge_nstates", C.c_void_p), ("edge_nactions", C.c_void_p), ("obstacle_ahead", C.c_void_p),
-                ("edge_owner", C.c_void_p), ("counters", C.c_void_p)]
+                ("edge_owner", C.c_void_p), ("hist", C.c_void_p), ("hist_n", C.c_void_p), ("counters", C.c_void_p)]
 
 
 class Round(C.Structure):
@@ -40,10 +41,31 @@ class Round(C.Structure):
                 ("chunks_run", C.c_void_p), ("end_state", C.c_void_p), ("states", C.c_void_p),
                 ("actions", C.c_void_p), ("chunk_steps", C.c_void_p), ("node_id", C.c_void_p),
                 ("last_action", C.c_void_p), ("first_action", C.c_void_p),
-                ("own_lo", C.c_int32), ("own_n", C.c_int32), ("shard", C.c_int32)]
+                ("own_lo", C.c_int32), ("own_n", C.c_int32), ("shard", C.c_int32),
+                ("hist", C.c_void_p), ("hist_n", C.c_void_p)]
 
 
-RECORD_DOUBLES = 12          # include/ditree.h DITREE_RECORD_DOUBLES
+RECORD_DOUBLES = 12          # include/ditree.h DITREE_RECORD_DOUBLES (the car's record; ditree_record_doubles for any tree)
+
+
+class Strides(C.Structure):
+    """include/ditree.h ditree_strides: element (candidate b, row i, component k) at b * cand + i * row + k * comp doubles."""
+    _fields_ = [("cand", C.c_int64), ("row", C.c_int64), ("comp", C.c_int64)]
+
+
+class AntModel(C.Structure):
+    """include/ditree.h ditree_ant_model -- the build's stand-in for the ant's MuJoCo step (NOT MuJoCo, parity unpinned)."""
+    _fields_ = [(n, C.c_double) for n in ("h", "frame_skip", "k_act", "k_spr", "k_dmp", "k_lim", "hip_lim", "ank_lo", "ank_hi",
+                                          "ank_rest", "contact_gain", "leg_r", "k_push", "c_lin", "z0", "z_gain", "k_z", "c_z",
+                                          "k_lift", "c_ang", "k_up", "k_yaw", "cphi", "sphi")]
+
+    @classmethod
+    def default(cls):
+        return cls(0.01, 5.0, 60.0, 20.0, 6.0, 400.0, 0.5236, 0.5236, 1.2217, 0.87, 6.0, 0.4, 16.0, 3.0, 0.55, 0.3, 120.0, 12.0,
+                   4.0, 5.0, 25.0, 10.0, 0.5 ** 0.5, 0.5 ** 0.5)
+
+
+ANT_DYN_TAPE, ANT_DYN_MODEL = 0, 1
 
 
 class RoundParams(C.Structure):
@@ -56,11 +78,12 @@ class RoundParams(C.Structure):
 
 
 class AntRoundParams(C.Structure):
-    _fields_ = [("obs_hist", C.c_void_p), ("n_hist", C.c_int32), ("prev_action", C.c_void_p), ("has_prev", C.c_void_p),
-                ("cond_goal", C.c_void_p), ("noise", C.c_void_p), ("next_obs_tape", C.c_void_p), ("n_chunks", C.c_int32),
-                ("A", C.c_int32), ("K", C.c_int32), ("t0", C.POINTER(C.c_float)), ("dt", C.POINTER(C.c_float)),
-                ("norm", C.POINTER(C.c_double)), ("act_norm", C.POINTER(C.c_double)), ("axis", C.POINTER(C.c_double)),
-                ("lm_n", C.c_int32), ("lm_size", C.c_double), ("s_global", C.c_double)]
+    _fields_ = [("n_nodes", C.c_int32), ("samples", C.c_void_p), ("cond_goal", C.c_void_p), ("noise", C.c_void_p),
+                ("inject_actions", C.c_void_p), ("P", C.c_int32), ("K", C.c_int32), ("t0", C.POINTER(C.c_float)),
+                ("dt", C.POINTER(C.c_float)), ("norm", C.POINTER(C.c_double)), ("desired_goal", C.POINTER(C.c_double)),
+                ("goal_radius", C.c_double), ("ball_radius", C.c_double), ("axis", C.POINTER(C.c_double)), ("lm_n", C.c_int32),
+                ("lm_size", C.c_double), ("s_global", C.c_double), ("dynamics", C.c_int32), ("next_obs_tape", C.c_void_p),
+                ("model", C.POINTER(AntModel)), ("early_exit", C.c_int32), ("cond_out", C.c_void_p)]
 
 
 class MppiParams(C.Structure):
@@ -90,6 +113,11 @@ SIGNATURES = {
     "ditree_cond_vector": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _pd, _f64, _vp, _vp]),
     "ditree_car_rollout": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _pd, _vp, _i64, _vp, _i64, _vp, _vp,
                                   _vp, _vp]),
+    "ditree_car_rollout_ld": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _pd, _vp, C.POINTER(Strides), _vp, C.POINTER(Strides),
+                                     _vp, _vp, _vp, _vp]),
+    "ditree_ant_collision": (_i32, [_vp, _vp, _i32, _i32, _f64, _f64, _vp, _vp]),
+    "ditree_ant_rollout": (_i32, [_vp, C.POINTER(AntModel), _vp, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _pd, _f64, _f64, _f64,
+                                  _vp, C.POINTER(Strides), _vp, C.POINTER(Strides), _vp, _vp]),
     "ditree_lidar_scan": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ditree_obstacle_ahead": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "ditree_path_after_obstacle": (_i32, [_vp, _vp, _i32, _i32, _pf, _vp, _vp]),
@@ -97,7 +125,8 @@ SIGNATURES = {
     "ditree_follow_plan": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _pd, _f64, _f64, _vp, _vp, _vp]),
     "ditree_accept": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), _i32, _vp]),
     "ditree_round_pack": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), _vp, _vp]),
-    "ditree_round_unpack": (_i32, [_vp, C.POINTER(Round), _vp, _vp]),
+    "ditree_round_unpack": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), _vp, _vp]),
+    "ditree_record_doubles": (_i32, [C.POINTER(Tree)]),
     "ditree_comm_unique_id": (_i32, [_vp, _vp]),
     "ditree_comm_init": (_i32, [_vp, _i32, _i32, _vp]),
     "ditree_allgather_nodes": (_i32, [_vp, _vp, _vp, _i64, _vp]),
@@ -112,7 +141,10 @@ SIGNATURES = {
     "ditree_profile": (_i32, [_vp, _i32]),
     "ditree_profile_read": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ditree_denoise_debug_read": (_i32, [_vp, C.c_char_p, _i32, _vp, _i64, C.POINTER(_i32), _vp]),
-    "ditree_expand_round_ant": (_i32, [_vp, C.POINTER(AntRoundParams), _i32, _vp, _vp, _vp, _vp]),
+    "ditree_expand_round_ant": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), C.POINTER(AntRoundParams), _vp]),
+    "ditree_ant_round_begin": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), C.POINTER(AntRoundParams), _vp]),
+    "ditree_ant_chunk_sample": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), C.POINTER(AntRoundParams), _i32, _vp]),
+    "ditree_ant_chunk_step": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), C.POINTER(AntRoundParams), _i32, _vp, _vp]),
     "ditree_expand_round": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), C.POINTER(RoundParams), _vp]),
 }
 
@@ -132,11 +164,21 @@ def lib():
             f"{LIB_PATH} is missing: build it with `python -m ditreeonlineplanner_amd.build` "
             "(hipcc, gfx950).  There is no CPU fallback for the expansion path.")
     # a library built from other sources than the ones next to it (a stale .so that travelled with a snapshot) is refused
-    from . import build as _build
-    have, want = _build.library_id(LIB_PATH), _build.source_id()
-    if have != want and os.environ.get("DITREE_ALLOW_STALE_LIB", "0") != "1":
-        raise DitreeLibraryError(f"{LIB_PATH} is stale: built from sources {have}, the sources here are {want}; "
-                                 "run `python -m ditreeonlineplanner_amd.build`")
+    # (DITREE_ALLOW_STALE_LIB=1 skips the check; a deployment that ships the package and the .so WITHOUT csrc/ and
+    # include/ditree.h has nothing to compare against: the check is skipped with a warning, the library's own id is what
+    # `build_id()` reports)
+    if os.environ.get("DITREE_ALLOW_STALE_LIB", "0") != "1":
+        from . import build as _build
+        try:
+            want = _build.source_id()
+        except OSError as e:
+            import warnings
+            warnings.warn(f"libditree_hip.so: sources not found next to the package ({e.filename}); stale-library check skipped")
+            want = None
+        have = _build.library_id(LIB_PATH)
+        if want is not None and have != want:
+            raise DitreeLibraryError(f"{LIB_PATH} is stale: built from sources {have}, the sources here are {want}; "
+                                     "run `python -m ditreeonlineplanner_amd.build`")
     try:
         h = C.CDLL(LIB_PATH)
     except OSError as e:

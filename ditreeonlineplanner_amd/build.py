@@ -28,6 +28,7 @@ ARCH = "gfx950"
 UNITS = [
     ("geom_kernels.hip", ["-ffp-contract=off"]),
     ("mppi_kernels.hip", ["-ffp-contract=off"]),
+    ("ant_kernels.hip", ["-ffp-contract=off"]),
     ("ditree_api.hip", []),
     ("denoise_kernels.hip", []),
     ("denoise_host.hip", []),

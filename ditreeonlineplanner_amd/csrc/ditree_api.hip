@@ -7,11 +7,12 @@
 #include <cstdio>
 #include <cstring>
 
+#include "ant_device.h"
 #include "ditree_internal.h"
 
 void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double* state_io, const double* actions,
                            int64_t act_stride, int32_t* status_io, int B, int A, double gx, double gy,
-                           double* states_out, int64_t states_stride, double* actions_out, int64_t actout_stride,
+                           double* states_out, ditree_strides states_stride, double* actions_out, ditree_strides actout_stride,
                            int32_t* steps_out, int64_t steps_stride, int32_t* chunks_run, double* prev_action_io,
                            uint8_t* has_prev_io, const int32_t* idx, int act_dense, hipStream_t s, const int32_t* budget,
                            int chunk_j);
@@ -67,7 +68,7 @@ void ditree_ctx_destroy(ditree_ctx* ctx) {
   if (ctx->path_dev) hipFree(ctx->path_dev);
   if (ctx->mppi_partial) hipFree(ctx->mppi_partial);
   if (ctx->mppi_minkey) hipFree(ctx->mppi_minkey);
-  void* ant[] = {ctx->ant_hist[0], ctx->ant_hist[1], ctx->ant_prev, ctx->ant_hasprev, ctx->ant_cond, ctx->ant_lmap, ctx->ant_act};
+  void* ant[] = {ctx->ant_hist, ctx->ant_hist_n, ctx->ant_idx, ctx->ant_prev, ctx->ant_hasprev, ctx->ant_cond, ctx->ant_lmap, ctx->ant_act};
   for (void* q : ant) if (q) hipFree(q);
   delete ctx;
 }
@@ -151,7 +152,7 @@ int32_t ditree_cond_vector_ant(ditree_ctx* ctx, const double* obs, int32_t n_his
   AntNormArg nm;
   for (int i = 0; i < 27; ++i) { nm.obs_mean[i] = norm[i]; nm.obs_std[i] = norm[27 + i]; }
   for (int i = 0; i < 8; ++i) { nm.act_mean[i] = norm[54 + i]; nm.act_std[i] = norm[62 + i]; }
-  launch_cond_vector_ant(obs, n_hist, prev_action, has_prev, cond_goal, B, nm, local_map_size, out, (hipStream_t)stream);
+  launch_cond_vector_ant(obs, n_hist, nullptr, prev_action, has_prev, cond_goal, nullptr, B, nm, local_map_size, out, (hipStream_t)stream);
   HIP_TRY(ctx, hipGetLastError());
   return DITREE_OK;
 }
@@ -193,6 +194,77 @@ int32_t ditree_car_rollout(ditree_ctx* ctx, double* state_io, const double* acti
   launch_car_rollout(ctx->maze, ctx->rows, ctx->cols, state_io, actions, act_stride, status_io, B, A, goal_xy[0],
                      goal_xy[1], states_out, states_stride, actions_out, actout_stride, steps_out, prev_action_io,
                      has_prev_io, (hipStream_t)stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+int32_t ditree_car_rollout_ld(ditree_ctx* ctx, double* state_io, const double* actions, int64_t act_stride, int32_t* status_io,
+                              int32_t B, int32_t A, const double* goal_xy, double* states_out, const ditree_strides* states_ld,
+                              double* actions_out, const ditree_strides* actions_ld, int32_t* steps_out, double* prev_action_io,
+                              uint8_t* has_prev_io, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!ctx->maze) return set_err(ctx, DITREE_E_STATE, "car_rollout: no maze uploaded");
+  if (B == 0) return DITREE_OK;
+  if (!state_io || !actions || !status_io || !goal_xy || B < 0 || A <= 0 || act_stride < 2 * (int64_t)A)
+    return set_err(ctx, DITREE_E_ARG, "car_rollout: bad argument");
+  const ditree_strides sl = states_ld ? *states_ld : ditree_strides{6 * (int64_t)(A + 1), 6, 1};
+  const ditree_strides al = actions_ld ? *actions_ld : ditree_strides{2 * (int64_t)A, 2, 1};
+  if (sl.cand < 1 || sl.row < 1 || sl.comp < 1 || al.cand < 1 || al.row < 1 || al.comp < 1)
+    return set_err(ctx, DITREE_E_ARG, "car_rollout: strides must be positive");
+  launch_car_rollout_ex(ctx->maze, ctx->rows, ctx->cols, state_io, actions, act_stride, status_io, B, A, goal_xy[0], goal_xy[1],
+                        states_out, sl, actions_out, al, steps_out, 1, nullptr, prev_action_io, has_prev_io, nullptr, 1,
+                        (hipStream_t)stream, nullptr, 0);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+int32_t ditree_ant_collision(ditree_ctx* ctx, const double* state, int32_t stride, int32_t B, double ball_radius, double s_global,
+                             uint8_t* out, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!ctx->maze) return set_err(ctx, DITREE_E_STATE, "ant_collision: no maze uploaded");
+  if (B == 0) return DITREE_OK;
+  if (!state || !out || B < 0 || stride < 7 || !(s_global > 0.0) || !(ball_radius >= 0.0))
+    return set_err(ctx, DITREE_E_ARG, "ant_collision: bad argument (stride >= 7, s_global > 0)");
+  launch_ant_collision(ctx->maze, ctx->rows, ctx->cols, state, stride, B, ball_radius, s_global, out, (hipStream_t)stream);
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+static int fill_ant_model(ditree_ctx* ctx, const ditree_ant_model* m, AntModelArg* a) {
+  if (!(m->h > 0.0) || !(m->frame_skip >= 1.0) || m->frame_skip > 64.0 || m->frame_skip != (double)(int)m->frame_skip)
+    return set_err(ctx, DITREE_E_ARG, "ant model: need h > 0 and an integral frame_skip in 1..64");
+  a->h = m->h; a->frame_skip = (int)m->frame_skip;
+  a->k_act = m->k_act; a->k_spr = m->k_spr; a->k_dmp = m->k_dmp; a->k_lim = m->k_lim; a->hip_lim = m->hip_lim;
+  a->ank_lo = m->ank_lo; a->ank_hi = m->ank_hi; a->ank_rest = m->ank_rest; a->contact_gain = m->contact_gain;
+  a->leg_r = m->leg_r; a->k_push = m->k_push; a->c_lin = m->c_lin; a->z0 = m->z0; a->z_gain = m->z_gain; a->k_z = m->k_z;
+  a->c_z = m->c_z; a->k_lift = m->k_lift; a->c_ang = m->c_ang; a->k_up = m->k_up; a->k_yaw = m->k_yaw; a->cphi = m->cphi;
+  a->sphi = m->sphi;
+  return DITREE_OK;
+}
+
+int32_t ditree_ant_rollout(ditree_ctx* ctx, const ditree_ant_model* model, double* state_io, const double* actions,
+                           int64_t act_stride, const double* next_obs_tape, int64_t tape_stride, int32_t* status_io, int32_t B,
+                           int32_t A, const double* desired_goal_xy, double goal_radius, double ball_radius, double s_global,
+                           double* states_out, const ditree_strides* states_ld, double* actions_out,
+                           const ditree_strides* actions_ld, int32_t* steps_out, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!ctx->maze) return set_err(ctx, DITREE_E_STATE, "ant_rollout: no maze uploaded");
+  if (B == 0) return DITREE_OK;
+  if (!state_io || !actions || !status_io || !desired_goal_xy || B < 0 || A <= 0 || act_stride < ANT_D * (int64_t)A ||
+      !(s_global > 0.0))
+    return set_err(ctx, DITREE_E_ARG, "ant_rollout: bad argument");
+  if (!model && (!next_obs_tape || tape_stride < ANT_S * (int64_t)A))
+    return set_err(ctx, DITREE_E_ARG, "ant_rollout: neither a model nor a next-observation tape of A rows");
+  const ditree_strides sl = states_ld ? *states_ld : ditree_strides{ANT_S * (int64_t)(A + 1), ANT_S, 1};
+  const ditree_strides al = actions_ld ? *actions_ld : ditree_strides{ANT_D * (int64_t)A, ANT_D, 1};
+  if (sl.cand < 1 || sl.row < 1 || sl.comp < 1 || al.cand < 1 || al.row < 1 || al.comp < 1)
+    return set_err(ctx, DITREE_E_ARG, "ant_rollout: strides must be positive");
+  AntModelArg ma;
+  if (model) { const int rc = fill_ant_model(ctx, model, &ma); if (rc) return rc; }
+  launch_ant_rollout(ctx->maze, ctx->rows, ctx->cols, model ? &ma : nullptr, state_io, actions, act_stride, next_obs_tape,
+                     tape_stride, status_io, B, A, desired_goal_xy[0], desired_goal_xy[1], goal_radius, ball_radius, s_global,
+                     states_out, sl, actions_out, al, steps_out, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1,
+                     (hipStream_t)stream);
   HIP_TRY(ctx, hipGetLastError());
   return DITREE_OK;
 }
@@ -292,6 +364,9 @@ static int check_tree(ditree_ctx* ctx, const ditree_tree* t) {
       !t->edge_states || !t->edge_actions || !t->edge_nstates || !t->edge_nactions || !t->counters ||
       t->capacity <= 0 || t->n_chunks <= 0 || t->A <= 0)
     return set_err(ctx, DITREE_E_ARG, "tree descriptor incomplete");
+  if (t->state_dim < 3 || t->state_dim > 64 || t->action_dim < 1 || t->action_dim > 32)
+    return set_err(ctx, DITREE_E_ARG, "tree: state_dim must be 3..64 and action_dim 1..32 (car 6 / 2, ant 29 / 8)");
+  if ((t->hist == nullptr) != (t->hist_n == nullptr)) return set_err(ctx, DITREE_E_ARG, "tree: hist and hist_n come together");
   return DITREE_OK;
 }
 static int check_round(ditree_ctx* ctx, const ditree_round* r) {
@@ -310,6 +385,10 @@ int32_t ditree_accept(ditree_ctx* ctx, const ditree_tree* tree, const ditree_rou
   if (rc) return rc;
   if (round->B == 0) return DITREE_OK;
   if (tree->obstacle_ahead && !ctx->maze) return set_err(ctx, DITREE_E_STATE, "accept: obstacle-ahead flags need the maze");
+  if (tree->hist && round->shard > 0 && (!round->hist || !round->hist_n))
+    return set_err(ctx, DITREE_E_ARG, "accept: a sharded round on a tree with `hist` needs the round's hist / hist_n arrays");
+  if (emulate_sticky && (tree->state_dim != 6 || tree->action_dim != 2))
+    return set_err(ctx, DITREE_E_ARG, "accept: the sticky-done emulation is the car env's (car_env.py:254,266)");
   const AheadArg ts = ahead_samples();
   launch_accept(*tree, *round, emulate_sticky, ctx->maze, ctx->rows, ctx->cols, ts, (hipStream_t)stream);
   HIP_TRY(ctx, hipGetLastError());
@@ -330,14 +409,21 @@ int32_t ditree_round_pack(ditree_ctx* ctx, const ditree_tree* tree, const ditree
   return DITREE_OK;
 }
 
-int32_t ditree_round_unpack(ditree_ctx* ctx, const ditree_round* round, const double* records, void* stream) {
+int32_t ditree_record_doubles(const ditree_tree* tree) { return tree ? record_doubles(*tree) : DITREE_E_ARG; }
+
+int32_t ditree_round_unpack(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round, const double* records,
+                            void* stream) {
   if (!ctx) return DITREE_E_ARG;
-  int rc = check_round(ctx, round);
+  int rc = check_tree(ctx, tree);
+  if (rc) return rc;
+  rc = check_round(ctx, round);
   if (rc) return rc;
   if (round->B == 0) return DITREE_OK;
   if (!records || !round->last_action || !round->first_action)
     return set_err(ctx, DITREE_E_ARG, "round_unpack: records and the round's last_action / first_action arrays are required");
-  launch_round_unpack(*round, records, (hipStream_t)stream);
+  if (tree->hist && (!round->hist || !round->hist_n))
+    return set_err(ctx, DITREE_E_ARG, "round_unpack: a tree with `hist` needs the round's hist / hist_n arrays");
+  launch_round_unpack(*tree, *round, records, (hipStream_t)stream);
   HIP_TRY(ctx, hipGetLastError());
   return DITREE_OK;
 }
@@ -426,13 +512,14 @@ static int ensure_scratch(ditree_ctx* ctx, int B, int lm_n, int P) {
   HIP_TRY(ctx, hipDeviceSynchronize());
   void** ptrs[] = {(void**)&ctx->cur_state, (void**)&ctx->prev_action, (void**)&ctx->has_prev, (void**)&ctx->lmap,
                    (void**)&ctx->cond, (void**)&ctx->act64, (void**)&ctx->alive_idx, (void**)&ctx->alive_cnt};
+  int nb = B > ctx->scratch_B ? B : ctx->scratch_B;
+  int nl = lm_n > ctx->scratch_lm ? lm_n : ctx->scratch_lm;
+  int np = P > ctx->scratch_P ? P : ctx->scratch_P;
+  ctx->scratch_B = ctx->scratch_lm = ctx->scratch_P = 0;      // a failed allocation below leaves "nothing reserved"
   for (auto p : ptrs) {
     if (*p) HIP_TRY(ctx, hipFree(*p));
     *p = nullptr;
   }
-  int nb = B > ctx->scratch_B ? B : ctx->scratch_B;
-  int nl = lm_n > ctx->scratch_lm ? lm_n : ctx->scratch_lm;
-  int np = P > ctx->scratch_P ? P : ctx->scratch_P;
   HIP_TRY(ctx, hipMalloc((void**)&ctx->cur_state, (size_t)nb * 6 * sizeof(double)));
   HIP_TRY(ctx, hipMalloc((void**)&ctx->prev_action, (size_t)nb * 2 * sizeof(double)));
   HIP_TRY(ctx, hipMalloc((void**)&ctx->has_prev, (size_t)nb));
@@ -448,72 +535,214 @@ static int ensure_scratch(ditree_ctx* ctx, int B, int lm_n, int P) {
   return DITREE_OK;
 }
 
-// BASELINE config 3's round without its physics: per chunk [local map -> ant conditioning vector -> denoiser -> A 8-d actions],
-// the observation history / previous action carried on the device between the chunks, next observations from a tape.
-int32_t ditree_expand_round_ant(ditree_ctx* ctx, const ditree_ant_round_params* p, int32_t B, double* actions_out,
-                                double* end_obs, float* cond_out, void* stream) {
-  if (!ctx) return DITREE_E_ARG;
+// ---- BASELINE config 3: the ant round (include/ditree.h "One expansion round of the ANT").
+static int check_ant_round(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round, const ditree_ant_round_params* p,
+                           int need_sampler, int* P_out) {
+  int rc = check_tree(ctx, tree);
+  if (rc) return rc;
+  rc = check_round(ctx, round);
+  if (rc) return rc;
   if (!ctx->maze) return set_err(ctx, DITREE_E_STATE, "expand_round_ant: no maze uploaded");
+  if (tree->state_dim != ANT_S || tree->action_dim != ANT_D || !tree->hist)
+    return set_err(ctx, DITREE_E_ARG, "expand_round_ant: the tree must have state_dim 29, action_dim 8 and hist / hist_n");
+  if (!p || !p->cond_goal || !p->norm || !p->desired_goal || !p->axis || !(p->s_global > 0.0) || p->P < tree->A)
+    return set_err(ctx, DITREE_E_ARG, "expand_round_ant: bad parameters");
+  if (need_sampler) {
+    if (!p->noise && !p->inject_actions) return set_err(ctx, DITREE_E_ARG, "expand_round_ant: neither noise nor inject_actions");
+    if (!p->inject_actions) {
+      if (!p->t0 || !p->dt || p->K < 1) return set_err(ctx, DITREE_E_ARG, "expand_round_ant: flow schedule missing");
+      int32_t d5[5];
+      if (ditree_denoise_dims(ctx, d5) != DITREE_OK) return DITREE_E_STATE;
+      if (d5[1] != ANT_D || d5[3] != 97 || p->lm_n != d5[2] || p->P != d5[0])
+        return set_err(ctx, DITREE_E_ARG, "expand_round_ant: the loaded denoiser is not the ant network (P " + std::to_string(d5[0]) +
+                       ", action_dim " + std::to_string(d5[1]) + ", cond " + std::to_string(d5[3]) + ", map " + std::to_string(d5[2]) +
+                       "; need P = params.P, 8, 97, map = params.lm_n)");
+    }
+  }
+  *P_out = p->P;
+  return DITREE_OK;
+}
+
+static int ensure_ant_scratch(ditree_ctx* ctx, int B, int P, int lm) {
+  if (B <= ctx->ant_B && P <= ctx->ant_P && lm <= ctx->ant_lm) return DITREE_OK;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  void** ptrs[] = {(void**)&ctx->ant_hist, (void**)&ctx->ant_hist_n, (void**)&ctx->ant_idx, (void**)&ctx->ant_prev,
+                   (void**)&ctx->ant_hasprev, (void**)&ctx->ant_cond, (void**)&ctx->ant_lmap, (void**)&ctx->ant_act};
+  const size_t nb = (size_t)std::max(B, ctx->ant_B), np = (size_t)std::max(P, ctx->ant_P), nl = (size_t)std::max(lm, ctx->ant_lm);
+  ctx->ant_B = ctx->ant_P = ctx->ant_lm = 0;            // a failed allocation below leaves "nothing reserved", not stale sizes
+  for (auto q : ptrs) { if (*q) HIP_TRY(ctx, hipFree(*q)); *q = nullptr; }
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_hist, nb * 3 * ANT_S * sizeof(double)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_hist_n, nb * sizeof(int32_t)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_idx, nb * sizeof(int32_t)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_prev, nb * ANT_D * sizeof(double)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_hasprev, nb));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_cond, nb * 97 * sizeof(float)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_lmap, nb * nl * nl * sizeof(float)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_act, nb * np * ANT_D * sizeof(double)));
+  if (!ctx->alive_cnt) HIP_TRY(ctx, hipMalloc((void**)&ctx->alive_cnt, 16));
+  if (!ctx->alive_cnt_host) HIP_TRY(ctx, hipHostMalloc((void**)&ctx->alive_cnt_host, 16, hipHostMallocDefault));
+  ctx->ant_B = (int)nb; ctx->ant_P = (int)np; ctx->ant_lm = (int)nl;
+  return DITREE_OK;
+}
+
+int32_t ditree_ant_round_begin(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
+                               const ditree_ant_round_params* p, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  int P = 0;
+  int rc = check_ant_round(ctx, tree, round, p, 0, &P);
+  if (rc) return rc;
+  if (!p->samples || p->n_nodes <= 0 || p->n_nodes > tree->capacity)
+    return set_err(ctx, DITREE_E_ARG, "ant_round_begin: samples / n_nodes");
+  const int B = round->B;
   if (B == 0) return DITREE_OK;
-  if (!p || !p->obs_hist || !p->prev_action || !p->has_prev || !p->cond_goal || !p->noise || !p->next_obs_tape || !p->t0 ||
-      !p->dt || !p->norm || !p->act_norm || !p->axis || !actions_out || B < 0 || p->n_hist < 1 || p->n_hist > 3 ||
-      p->n_chunks < 1 || p->A < 2 || p->K < 1)
-    return set_err(ctx, DITREE_E_ARG, "expand_round_ant: bad parameters (1 <= n_hist <= 3, action_horizon >= 2)");
-  int32_t d5[5];
-  if (ditree_denoise_dims(ctx, d5) != DITREE_OK) return DITREE_E_STATE;
-  const int P = d5[0], D = d5[1], lm = d5[2], G = d5[3];
-  if (D != 8 || G != 97 || p->lm_n != lm || p->A > P)
-    return set_err(ctx, DITREE_E_ARG, "expand_round_ant: the loaded denoiser is not the ant network (action_dim " + std::to_string(D) +
-                   ", cond " + std::to_string(G) + ", map " + std::to_string(lm) + "; need 8 / 97 / lm_n, action_horizon <= pred_horizon)");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (B > ctx->ant_B || P > ctx->ant_P || lm > ctx->ant_lm) {
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    void** ptrs[] = {(void**)&ctx->ant_hist[0], (void**)&ctx->ant_hist[1], (void**)&ctx->ant_prev, (void**)&ctx->ant_hasprev,
-                     (void**)&ctx->ant_cond, (void**)&ctx->ant_lmap, (void**)&ctx->ant_act};
-    for (auto q : ptrs) { if (*q) HIP_TRY(ctx, hipFree(*q)); *q = nullptr; }
-    const size_t nb = (size_t)std::max(B, ctx->ant_B), np = (size_t)std::max(P, ctx->ant_P), nl = (size_t)std::max(lm, ctx->ant_lm);
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_hist[0], nb * 87 * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_hist[1], nb * 87 * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_prev, nb * 8 * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_hasprev, nb));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_cond, nb * 97 * sizeof(float)));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_lmap, nb * nl * nl * sizeof(float)));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_act, nb * np * 8 * sizeof(double)));
-    ctx->ant_B = (int)nb; ctx->ant_P = (int)np; ctx->ant_lm = (int)nl;
+  rc = ensure_ant_scratch(ctx, B, P, p->lm_n);
+  if (rc) return rc;
+  launch_round_begin(round->status, round->chunks_run, round->chunk_steps, B, tree->n_chunks, s);
+  // RRT.py:141-147: nearest node -> curr_state (the live state of the round: round->end_state), prev_actions, prev_states
+  launch_nn_argmin(p->samples, ANT_S, B, tree->xy, p->n_nodes, round->parent, tree->state, tree->last_action, tree->has_prev,
+                   round->end_state, ctx->ant_prev, ctx->ant_hasprev, s, ANT_S, ANT_D);
+  launch_ant_gather_hist(round->parent, tree->hist, tree->hist_n, B, ctx->ant_hist, ctx->ant_hist_n, s);
+  ctx->ant_n_run = B;
+  ctx->ant_run_idx = nullptr;
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+int32_t ditree_ant_chunk_sample(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
+                                const ditree_ant_round_params* p, int32_t j, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  int P = 0;
+  int rc = check_ant_round(ctx, tree, round, p, 1, &P);
+  if (rc) return rc;
+  const int B = round->B, nC = tree->n_chunks, A = tree->A;
+  if (j < 0 || j >= nC) return set_err(ctx, DITREE_E_ARG, "ant_chunk_sample: chunk index out of range");
+  if (B == 0) return DITREE_OK;
+  if (B > ctx->ant_B) return set_err(ctx, DITREE_E_STATE, "ant_chunk_sample: call ditree_ant_round_begin first");
+  hipStream_t s = (hipStream_t)stream;
+  if (p->early_exit && j > 0) {
+    // RRT.py:179-184: a collided edge is abandoned -- the chunk runs on the candidates that are still alive
+    launch_compact_alive(round->status, B, ctx->ant_idx, ctx->alive_cnt, s);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->alive_cnt_host, ctx->alive_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    ctx->ant_n_run = *ctx->alive_cnt_host;
+    ctx->ant_run_idx = ctx->ant_idx;
+  } else if (j == 0) {
+    ctx->ant_n_run = B;
+    ctx->ant_run_idx = nullptr;
+  }
+  const int n_run = ctx->ant_n_run;
+  const int32_t* idx = ctx->ant_run_idx;
+  if (n_run == 0) return DITREE_OK;
+  const int64_t ac_stride = (int64_t)nC * A * ANT_D;
+  if (p->inject_actions)
+    launch_ant_copy_actions(p->inject_actions + (size_t)j * P * ANT_D, (int64_t)nC * P * ANT_D, 0, idx, round->status, n_run, A,
+                            round->actions + (size_t)j * A * ANT_D, ac_stride, s);
+  if (p->inject_actions && !p->cond_out) {               // action tapes need neither the map nor the conditioning
+    HIP_TRY(ctx, hipGetLastError());
+    return DITREE_OK;
   }
   AxisArg ax;
-  int rc = fill_axis(ctx, p->axis, p->lm_n, &ax);
+  rc = fill_axis(ctx, p->axis, p->lm_n, &ax);
   if (rc) return rc;
   AntNormArg nm;
   for (int i = 0; i < 27; ++i) { nm.obs_mean[i] = p->norm[i]; nm.obs_std[i] = p->norm[27 + i]; }
   for (int i = 0; i < 8; ++i) { nm.act_mean[i] = p->norm[54 + i]; nm.act_std[i] = p->norm[62 + i]; }
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->ant_prev, p->prev_action, (size_t)B * 8 * sizeof(double), hipMemcpyDeviceToDevice, s));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->ant_hasprev, p->has_prev, (size_t)B, hipMemcpyDeviceToDevice, s));
-  const int nC = p->n_chunks, A = p->A;
-  const double* hist = p->obs_hist;              // (B, n, 29) view the chunk's sampler call sees
-  int n = p->n_hist;
-  for (int j = 0; j < nC; ++j) {
-    // RRT.py:158-166: the local map is cut at the chunk's start state = last row of the history (x, y, element 2)
-    launch_local_map(ctx->maze, ctx->rows, ctx->cols, hist + (size_t)(n - 1) * 29, nullptr, nullptr, B, p->lm_n, ax, p->s_global, 1,
-                     ctx->ant_lmap, s, n * 29);
-    launch_cond_vector_ant(hist, n, ctx->ant_prev, ctx->ant_hasprev, p->cond_goal, B, nm, p->lm_size, ctx->ant_cond, s);
-    if (cond_out)
-      HIP_TRY(ctx, hipMemcpy2DAsync(cond_out + (size_t)j * 97, (size_t)nC * 97 * sizeof(float), ctx->ant_cond, 97 * sizeof(float),
-                                    97 * sizeof(float), (size_t)B, hipMemcpyDeviceToDevice, s));
-    rc = denoise_run(ctx, p->noise + (size_t)j * P * 8, (int64_t)nC * P * 8, nullptr, ctx->ant_lmap, ctx->ant_cond, B, p->K, p->t0,
-                     p->dt, p->act_norm, ctx->ant_act, nullptr, s);
-    if (rc) return rc;
-    double* nxt = ctx->ant_hist[j & 1];
-    launch_ant_advance(hist, n, p->next_obs_tape + (size_t)j * A * 29, (int64_t)nC * A * 29, A, ctx->ant_act, P, nxt, ctx->ant_prev,
-                       ctx->ant_hasprev, actions_out + (size_t)j * A * 8, (int64_t)nC * A * 8, B, s);
-    hist = nxt;
-    n = 3;
+  // RRT.py:158-166: the local map is cut at the chunk's start state (x, y, element 2)
+  launch_local_map(ctx->maze, ctx->rows, ctx->cols, round->end_state, round->status, idx, n_run, p->lm_n, ax, p->s_global, 1,
+                   ctx->ant_lmap, s, ANT_S);
+  launch_cond_vector_ant(ctx->ant_hist, 3, ctx->ant_hist_n, ctx->ant_prev, ctx->ant_hasprev, p->cond_goal, idx, n_run, nm,
+                         p->lm_size, ctx->ant_cond, s);
+  if (p->cond_out) {
+    if (idx) return set_err(ctx, DITREE_E_ARG, "expand_round_ant: cond_out is a test output of rounds without early_exit");
+    HIP_TRY(ctx, hipMemcpy2DAsync(p->cond_out + (size_t)j * 97, (size_t)nC * 97 * sizeof(float), ctx->ant_cond, 97 * sizeof(float),
+                                  97 * sizeof(float), (size_t)B, hipMemcpyDeviceToDevice, s));
   }
-  if (end_obs)
-    HIP_TRY(ctx, hipMemcpy2DAsync(end_obs, 29 * sizeof(double), hist + 2 * 29, 87 * sizeof(double), 29 * sizeof(double), (size_t)B,
-                                  hipMemcpyDeviceToDevice, s));
+  if (p->inject_actions) {
+    HIP_TRY(ctx, hipGetLastError());
+    return DITREE_OK;
+  }
+  rc = denoise_run(ctx, p->noise + (size_t)j * P * ANT_D, (int64_t)nC * P * ANT_D, idx, ctx->ant_lmap, ctx->ant_cond, n_run, p->K,
+                   p->t0, p->dt, p->norm + 54, ctx->ant_act, nullptr, s);
+  if (rc) return rc;
+  launch_ant_copy_actions(ctx->ant_act, (int64_t)P * ANT_D, 1, idx, round->status, n_run, A, round->actions + (size_t)j * A * ANT_D,
+                          ac_stride, s);
   HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+static int ant_chunk_step_impl(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round, const ditree_ant_round_params* p,
+                               int j, const double* obs, int64_t obs_stride, const AntModelArg* model, hipStream_t s) {
+  const int B = round->B, nC = tree->n_chunks, A = tree->A, P = p->P;
+  const int n_run = ctx->ant_n_run;
+  if (n_run == 0) return DITREE_OK;
+  const double* acts;
+  int64_t act_stride;
+  int act_dense;
+  if (p->inject_actions) {
+    acts = p->inject_actions + (size_t)j * P * ANT_D;
+    act_stride = (int64_t)nC * P * ANT_D;
+    act_dense = 0;
+  } else {
+    acts = ctx->ant_act;
+    act_stride = (int64_t)P * ANT_D;
+    act_dense = 1;
+  }
+  const int64_t st_stride = (int64_t)nC * (A + 1) * ANT_S, ac_stride = (int64_t)nC * A * ANT_D;
+  launch_ant_rollout(ctx->maze, ctx->rows, ctx->cols, model, round->end_state, acts, act_stride, obs, obs_stride, round->status,
+                     n_run, A, p->desired_goal[0], p->desired_goal[1], p->goal_radius, p->ball_radius, p->s_global,
+                     round->states + (size_t)j * (A + 1) * ANT_S, ditree_strides{st_stride, ANT_S, 1},
+                     round->actions + (size_t)j * A * ANT_D, ditree_strides{ac_stride, ANT_D, 1}, round->chunk_steps + j, nC,
+                     round->chunks_run, ctx->ant_prev, ctx->ant_hasprev, ctx->ant_hist, ctx->ant_hist_n, ctx->ant_run_idx, act_dense,
+                     s);
+  (void)B;
+  HIP_TRY(ctx, hipGetLastError());
+  return DITREE_OK;
+}
+
+int32_t ditree_ant_chunk_step(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
+                              const ditree_ant_round_params* p, int32_t j, const double* next_obs, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  int P = 0;
+  int rc = check_ant_round(ctx, tree, round, p, 1, &P);
+  if (rc) return rc;
+  if (j < 0 || j >= tree->n_chunks) return set_err(ctx, DITREE_E_ARG, "ant_chunk_step: chunk index out of range");
+  if (round->B == 0) return DITREE_OK;
+  if (round->B > ctx->ant_B) return set_err(ctx, DITREE_E_STATE, "ant_chunk_step: call ditree_ant_round_begin first");
+  if (!next_obs) return set_err(ctx, DITREE_E_ARG, "ant_chunk_step: next_obs (B, A, 29) is required");
+  return ant_chunk_step_impl(ctx, tree, round, p, j, next_obs, (int64_t)tree->A * ANT_S, nullptr, (hipStream_t)stream);
+}
+
+int32_t ditree_expand_round_ant(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
+                                const ditree_ant_round_params* p, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  int P = 0;
+  int rc = check_ant_round(ctx, tree, round, p, 1, &P);
+  if (rc) return rc;
+  AntModelArg ma;
+  const AntModelArg* model = nullptr;
+  if (p->dynamics == DITREE_ANT_DYN_MODEL) {
+    if (!p->model) return set_err(ctx, DITREE_E_ARG, "expand_round_ant: DITREE_ANT_DYN_MODEL without a model");
+    rc = fill_ant_model(ctx, p->model, &ma);
+    if (rc) return rc;
+    model = &ma;
+  } else if (p->dynamics == DITREE_ANT_DYN_TAPE) {
+    if (!p->next_obs_tape) return set_err(ctx, DITREE_E_ARG, "expand_round_ant: DITREE_ANT_DYN_TAPE without next_obs_tape");
+  } else {
+    return set_err(ctx, DITREE_E_ARG, "expand_round_ant: dynamics must be DITREE_ANT_DYN_TAPE or DITREE_ANT_DYN_MODEL");
+  }
+  rc = ditree_ant_round_begin(ctx, tree, round, p, stream);
+  if (rc) return rc;
+  const int nC = tree->n_chunks, A = tree->A;
+  for (int j = 0; j < nC; ++j) {
+    rc = ditree_ant_chunk_sample(ctx, tree, round, p, j, stream);
+    if (rc) return rc;
+    if (ctx->ant_n_run == 0) break;
+    const double* obs = model ? nullptr : p->next_obs_tape + (size_t)j * A * ANT_S;
+    rc = ant_chunk_step_impl(ctx, tree, round, p, j, obs, (int64_t)nC * A * ANT_S, model, (hipStream_t)stream);
+    if (rc) return rc;
+  }
   return DITREE_OK;
 }
 
@@ -531,7 +760,7 @@ int32_t ditree_chunk_budget(ditree_ctx* ctx, const ditree_tree* tree, const doub
     if (schedule_chunks[i] < 1 || schedule_chunks[i] > tree->n_chunks)
       return set_err(ctx, DITREE_E_ARG, "chunk_budget: a schedule entry exceeds the tree's edge capacity (n_chunks)");
   hipStream_t s = (hipStream_t)stream;
-  launch_nn_argmin(samples, 6, B, tree->xy, n_nodes, parent_scratch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+  launch_nn_argmin(samples, tree->state_dim, B, tree->xy, n_nodes, parent_scratch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s);
   launch_chunk_budget(parent_scratch, B, tree->num_visit, schedule_chunks, n_schedule, budget_out, s);
   HIP_TRY(ctx, hipGetLastError());
   return DITREE_OK;
@@ -550,6 +779,8 @@ int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditr
     return set_err(ctx, DITREE_E_ARG, "expand_round: bad parameters");
   if (!p->inject_actions && (!p->t0 || !p->dt || p->K <= 0))
     return set_err(ctx, DITREE_E_ARG, "expand_round: flow schedule missing");
+  if (tree->state_dim != 6 || tree->action_dim != 2)
+    return set_err(ctx, DITREE_E_ARG, "expand_round: the car round needs a tree with state_dim 6 / action_dim 2 (ant: ditree_expand_round_ant)");
   const int B = round->B, A = tree->A, nC = tree->n_chunks, P = p->P;
   if (!p->inject_actions) {
     // the scratch buffers below are sized from the caller's P / lm_n; the denoiser strides them by ITS dimensions
@@ -599,8 +830,8 @@ int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditr
       act_stride = (int64_t)P * 2;
     }
     launch_car_rollout_ex(ctx->maze, ctx->rows, ctx->cols, ctx->cur_state, acts, act_stride, round->status, n_run, A,
-                          p->goal_xy[0], p->goal_xy[1], round->states + (size_t)j * (A + 1) * 6, st_stride,
-                          round->actions + (size_t)j * A * 2, ac_stride, round->chunk_steps + j, nC,
+                          p->goal_xy[0], p->goal_xy[1], round->states + (size_t)j * (A + 1) * 6, ditree_strides{st_stride, 6, 1},
+                          round->actions + (size_t)j * A * 2, ditree_strides{ac_stride, 2, 1}, round->chunk_steps + j, nC,
                           round->chunks_run, ctx->prev_action, ctx->has_prev, idx, act_dense, s, p->chunk_budget, j);
     if (p->early_exit && j + 1 < nC) {
       launch_compact_alive(round->status, B, ctx->alive_idx, ctx->alive_cnt, s, p->chunk_budget, j + 1);

@@ -45,9 +45,13 @@ struct ditree_ctx {
   int32_t* alive_cnt_host = nullptr;  // pinned host copy
   double* path_dev = nullptr;       // reference path xy for the fallback selection
   int path_cap = 0;
-  // ant round scratch (ditree_expand_round_ant): two (B, 3, 29) history buffers, (B, 8) previous action, flags, (B, 97) cond
+  // ant round scratch (ditree_expand_round_ant): (B, 3, 29) history + valid rows, (B, 8) previous action, flags, (B, 97) cond
   int ant_B = 0;
-  double* ant_hist[2] = {nullptr, nullptr};
+  double* ant_hist = nullptr;
+  int32_t* ant_hist_n = nullptr;
+  int32_t* ant_idx = nullptr;       // alive candidates of an early-exit round
+  int ant_n_run = 0;                // rows the current chunk runs on (ditree_ant_chunk_sample -> _step)
+  const int32_t* ant_run_idx = nullptr;
   double* ant_prev = nullptr;
   uint8_t* ant_hasprev = nullptr;
   float* ant_cond = nullptr;
@@ -76,20 +80,32 @@ void launch_maze_convert(const float* src, unsigned char* dst, int n, hipStream_
 void launch_nn_argmin(const double* queries, int q_stride, int B, const double* node_xy, int N,
                       int32_t* out_idx, const double* node_state, const double* node_last_action,
                       const uint8_t* node_has_prev, double* out_state, double* out_prev_action,
-                      uint8_t* out_has_prev, hipStream_t s);
+                      uint8_t* out_has_prev, hipStream_t s, int S = 6, int D = 2);
 void launch_local_map(const unsigned char* maze, int rows, int cols, const double* state,
                       const int32_t* active, const int32_t* idx, int B, int n, const AxisArg& axis,
                       double s_global, int scaled, float* out, hipStream_t s, int state_stride = 6);
-void launch_cond_vector_ant(const double* obs, int n_hist, const double* prev_action, const uint8_t* has_prev,
-                            const double* cond_goal, int B, const AntNormArg& nm, double lm_size, float* out, hipStream_t s);
+void launch_cond_vector_ant(const double* obs, int n_rows, const int32_t* hist_n, const double* prev_action, const uint8_t* has_prev,
+                            const double* cond_goal, const int32_t* idx, int B, const AntNormArg& nm, double lm_size, float* out,
+                            hipStream_t s);
 void launch_cond_vector(const double* state, const double* prev_action, const uint8_t* has_prev,
                         const double* cond_goal, const int32_t* idx, int B, const NormArg& nm, double lm_size,
                         float* out, hipStream_t s);
 void launch_path_after_obstacle(const float* path, int stride, int P, float cx, float cy, const unsigned char* maze, int rows,
                                 int cols, int32_t* out, hipStream_t s);
-void launch_ant_advance(const double* hist_in, int n_in, const double* tape, int64_t tape_stride, int A, const double* act64, int P,
-                        double* hist_out, double* prev_action, uint8_t* has_prev, double* actions_out, int64_t actout_stride,
-                        int B, hipStream_t s);
+// ant_kernels.hip
+struct AntModelArg;
+void launch_ant_collision(const unsigned char* maze, int rows, int cols, const double* state, int stride, int B, double ball_radius,
+                          double s_global, uint8_t* out, hipStream_t s);
+void launch_ant_gather_hist(const int32_t* parent, const double* node_hist, const int32_t* node_hist_n, int B, double* hist,
+                            int32_t* hist_n, hipStream_t s);
+void launch_ant_copy_actions(const double* act, int64_t act_stride, int act_dense, const int32_t* idx, const int32_t* status,
+                             int n_run, int A, double* out, int64_t out_stride, hipStream_t s);
+void launch_ant_rollout(const unsigned char* maze, int rows, int cols, const AntModelArg* model, double* state_io,
+                        const double* actions, int64_t act_stride, const double* tape, int64_t tape_stride, int32_t* status_io, int B,
+                        int A, double gx, double gy, double goal_radius, double ball_radius, double s_global, double* states_out,
+                        ditree_strides sl, double* actions_out, ditree_strides al, int32_t* steps_out, int64_t steps_stride,
+                        int32_t* chunks_run, double* prev_action_io, uint8_t* has_prev_io, double* hist_out, int32_t* hist_n,
+                        const int32_t* idx, int act_dense, hipStream_t s);
 void launch_compact_alive(const int32_t* status, int B, int32_t* idx_out, int32_t* count, hipStream_t s,
                           const int32_t* budget = nullptr, int next_chunk = 0);
 void launch_chunk_budget(const int32_t* parent, int B, const int32_t* num_visit, const int32_t* chunks, int n,
@@ -108,7 +124,8 @@ void launch_round_begin(int32_t* status, int32_t* chunks_run, int32_t* chunk_ste
 void launch_round_chunk_end(const int32_t* chunk_status_in, int32_t* status, int32_t* chunks_run,
                             const double* cur_state, double* end_state, int B, hipStream_t s);
 void launch_round_pack(const ditree_tree& t, const ditree_round& r, double* rec, hipStream_t s);
-void launch_round_unpack(const ditree_round& r, const double* rec, hipStream_t s);
+void launch_round_unpack(const ditree_tree& t, const ditree_round& r, const double* rec, hipStream_t s);
+int record_doubles(const ditree_tree& t);
 struct AheadArg { double t[30]; };
 void launch_accept(const ditree_tree& t, const ditree_round& r, int emulate_sticky, const unsigned char* maze, int rows,
                    int cols, const AheadArg& ts, hipStream_t s);

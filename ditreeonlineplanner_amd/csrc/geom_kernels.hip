@@ -46,7 +46,7 @@ nn_argmin_kernel(const double* __restrict__ queries, int q_stride, int B, const 
                  int N, int32_t* __restrict__ out_idx, const double* __restrict__ node_state,
                  const double* __restrict__ node_last_action, const uint8_t* __restrict__ node_has_prev,
                  double* __restrict__ out_state, double* __restrict__ out_prev_action,
-                 uint8_t* __restrict__ out_has_prev) {
+                 uint8_t* __restrict__ out_has_prev, int S, int D) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int q0 = wave * NN_QPW;
@@ -86,21 +86,21 @@ nn_argmin_kernel(const double* __restrict__ queries, int q_stride, int B, const 
     if (q < B) {
       if (lane == 0) out_idx[q] = ix;
       if (node_state != nullptr) {
-        if (lane < 6) out_state[(size_t)q * 6 + lane] = node_state[(size_t)ix * 6 + lane];
-        if (lane >= 8 && lane < 10) out_prev_action[(size_t)q * 2 + (lane - 8)] = node_last_action[(size_t)ix * 2 + (lane - 8)];
-        if (lane == 16) out_has_prev[q] = node_has_prev[ix];
+        if (lane < S) out_state[(size_t)q * S + lane] = node_state[(size_t)ix * S + lane];               // S <= 64
+        if (lane >= 32 && lane < 32 + D) out_prev_action[(size_t)q * D + (lane - 32)] = node_last_action[(size_t)ix * D + (lane - 32)];
+        if (lane == 63) out_has_prev[q] = node_has_prev[ix];
       }
     }
   }
 }
 void launch_nn_argmin(const double* queries, int q_stride, int B, const double* node_xy, int N, int32_t* out_idx,
                       const double* node_state, const double* node_last_action, const uint8_t* node_has_prev,
-                      double* out_state, double* out_prev_action, uint8_t* out_has_prev, hipStream_t s) {
+                      double* out_state, double* out_prev_action, uint8_t* out_has_prev, hipStream_t s, int S, int D) {
   int waves = (B + NN_QPW - 1) / NN_QPW;
   int blocks = (waves + 3) / 4;
   hipLaunchKernelGGL(nn_argmin_kernel, dim3(blocks), dim3(256), 0, s, queries, q_stride, B,
                      (const double2*)node_xy, N, out_idx, node_state, node_last_action, node_has_prev, out_state,
-                     out_prev_action, out_has_prev);
+                     out_prev_action, out_has_prev, S, D);
 }
 
 // ------------------------------------------------------------------------- local map
@@ -186,20 +186,27 @@ void launch_cond_vector(const double* state, const double* prev_action, const ui
 // columns of its rotation matrix (common/se3_utils.py:177-189), the last `obs_history` = 3 steps are kept (zero rows in
 // front when fewer are given, :96-102), x, y dropped (:107): 3 x 29 = 87 values; then the previous action (8, normalised;
 // raw zeros when there is none, :113-123) and tanh((goal - position) / local_map_size) with yaw = 0 (:82,125-143).
-__global__ void cond_vector_ant_kernel(const double* __restrict__ obs, int n_hist, const double* __restrict__ prev_action,
-                                       const uint8_t* __restrict__ has_prev, const double* __restrict__ cond_goal, int B,
+// Two input forms: obs (B, n_rows, 29) with n_rows = n_hist given steps each (hist_n == NULL), or -- the round's buffers --
+// obs (B, 3, 29) with the hist_n[b] valid steps at the END of the three rows (n_rows = 3).  idx: compacted rounds (dense output
+// row ob <- candidate idx[ob]).
+__global__ void cond_vector_ant_kernel(const double* __restrict__ obs, int n_rows, const int32_t* __restrict__ hist_n,
+                                       const double* __restrict__ prev_action,
+                                       const uint8_t* __restrict__ has_prev, const double* __restrict__ cond_goal,
+                                       const int32_t* __restrict__ idx, int B,
                                        AntNormArg nm, double lm_size, float* __restrict__ out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  float* o = out + (size_t)b * 97;
+  const int ob = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ob >= B) return;
+  const int b = idx ? idx[ob] : ob;
+  const int n_hist = hist_n ? hist_n[b] : n_rows;
+  float* o = out + (size_t)ob * 97;
   for (int hs = 0; hs < 3; ++hs) {                        // slot hs of the 3-step history <- given step hs - (3 - n_hist)
-    const int src = hs - (3 - n_hist);
+    const int src = hs - (3 - n_hist) + (n_rows - n_hist);          // the valid steps are the LAST n_hist of the n_rows rows
     float* oh = o + hs * 29;
-    if (src < 0) {
+    if (hs < 3 - n_hist) {
       for (int k = 0; k < 29; ++k) oh[k] = 0.0f;
       continue;
     }
-    const double* st = obs + ((size_t)b * n_hist + src) * 29;
+    const double* st = obs + ((size_t)b * n_rows + src) * 29;
     double v[27];
     for (int k = 0; k < 27; ++k) v[k] = (st[2 + k] - nm.obs_mean[k]) / nm.obs_std[k];
     // obs_seq[..., 3:7] = v[1..4] = (qx, qy, qz, qw)
@@ -220,7 +227,7 @@ __global__ void cond_vector_ant_kernel(const double* __restrict__ obs, int n_his
   } else {
     for (int k = 0; k < 8; ++k) oa[k] = 0.0f;
   }
-  const double* last = obs + ((size_t)b * n_hist + (n_hist - 1)) * 29;        // position = obs_seq[:, -1, :2] (:74)
+  const double* last = obs + ((size_t)b * n_rows + (n_rows - 1)) * 29;        // position = obs_seq[:, -1, :2] (:74)
   const float gx = (float)(cond_goal[(size_t)b * 2 + 0] - last[0]);
   const float gy = (float)(cond_goal[(size_t)b * 2 + 1] - last[1]);
   const float sc = (float)lm_size;
@@ -228,10 +235,11 @@ __global__ void cond_vector_ant_kernel(const double* __restrict__ obs, int n_his
   o[95] = tanhf(gx / sc);
   o[96] = tanhf(gy / sc);
 }
-void launch_cond_vector_ant(const double* obs, int n_hist, const double* prev_action, const uint8_t* has_prev,
-                            const double* cond_goal, int B, const AntNormArg& nm, double lm_size, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(cond_vector_ant_kernel, dim3((B + 127) / 128), dim3(128), 0, s, obs, n_hist, prev_action, has_prev,
-                     cond_goal, B, nm, lm_size, out);
+void launch_cond_vector_ant(const double* obs, int n_rows, const int32_t* hist_n, const double* prev_action, const uint8_t* has_prev,
+                            const double* cond_goal, const int32_t* idx, int B, const AntNormArg& nm, double lm_size, float* out,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(cond_vector_ant_kernel, dim3((B + 127) / 128), dim3(128), 0, s, obs, n_rows, hist_n, prev_action, has_prev,
+                     cond_goal, idx, B, nm, lm_size, out);
 }
 
 // ------------------------------------------------------------------------- reference path behind the obstacle
@@ -298,42 +306,6 @@ void launch_path_after_obstacle(const float* path, int stride, int P, float cx, 
   hipLaunchKernelGGL(path_after_obstacle_kernel, dim3(1), dim3(256), 0, s, path, stride, P, cx, cy, maze, rows, cols, out);
 }
 
-// ------------------------------------------------------------------------- ant round: advance one chunk
-// The part of planners/RRT.py:176-188 an ant chunk has besides the MuJoCo step, which has no oracle here and is not built:
-// `prev_states = curr_states_seq` (the chunk's A + 1 states; the sampler keeps the last three, fm_policy.py:96-102),
-// `prev_actions = curr_action_seq` (its last row conditions the next call, :113-123), and the edge's action rows.  The next
-// observations come from a TAPE (test infrastructure, the ant analogue of inject_actions).
-//   hist_in (B, n_in, 29): history the chunk's sampler call saw, its last row is the chunk's start state;
-//   tape (B, tape_stride): A rows of 29 for this chunk;  hist_out (B, 3, 29): last three rows of [start, tape rows];
-//   n_out = min(3, A + 1) valid rows are written at the END of hist_out's 3 slots when A + 1 < 3 -- the caller passes
-//   hist_out + (3 - n_out) * 29 as the next (B, n_out, 29) view with stride 3 * 29 ... kept simple: A >= 2 is required.
-__global__ void ant_advance_kernel(const double* __restrict__ hist_in, int n_in, const double* __restrict__ tape,
-                                   int64_t tape_stride, int A, const double* __restrict__ act64, int P, double* __restrict__ hist_out,
-                                   double* __restrict__ prev_action, uint8_t* __restrict__ has_prev,
-                                   double* __restrict__ actions_out, int64_t actout_stride, int B) {
-  const int b = blockIdx.x;
-  if (b >= B) return;
-  const double* start = hist_in + ((size_t)b * n_in + (n_in - 1)) * 29;
-  const double* tp = tape + (size_t)b * tape_stride;
-  // rows of the chunk's state sequence: r = 0 start, r = 1..A tape rows; keep r = A - 2 .. A
-  for (int e = threadIdx.x; e < 3 * 29; e += blockDim.x) {
-    const int slot = e / 29, k = e - slot * 29;
-    const int r = A - 2 + slot;
-    const double v = r == 0 ? start[k] : tp[(size_t)(r - 1) * 29 + k];
-    hist_out[(size_t)b * 87 + e] = v;
-  }
-  for (int e = threadIdx.x; e < A * 8; e += blockDim.x)
-    actions_out[(size_t)b * actout_stride + e] = act64[(size_t)b * P * 8 + e];
-  if (threadIdx.x < 8) prev_action[(size_t)b * 8 + threadIdx.x] = act64[(size_t)b * P * 8 + (size_t)(A - 1) * 8 + threadIdx.x];
-  if (threadIdx.x == 0) has_prev[b] = 1;
-}
-void launch_ant_advance(const double* hist_in, int n_in, const double* tape, int64_t tape_stride, int A, const double* act64, int P,
-                        double* hist_out, double* prev_action, uint8_t* has_prev, double* actions_out, int64_t actout_stride,
-                        int B, hipStream_t s) {
-  hipLaunchKernelGGL(ant_advance_kernel, dim3(B), dim3(128), 0, s, hist_in, n_in, tape, tape_stride, A, act64, P, hist_out,
-                     prev_action, has_prev, actions_out, actout_stride, B);
-}
-
 // ------------------------------------------------------------------------- rollout
 // planners/base_planner.py:257-320 + car_env.py:240-282,341-396 + common/map_utils.py:103-115 for a batch of candidates.
 // One lane per candidate: the A Euler steps with their goal + two-ball collision tests are a sequential FP64 chain of
@@ -355,8 +327,8 @@ template <int G>
 __global__ void __launch_bounds__(256)
 car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, double* __restrict__ state_io,
                    const double* __restrict__ actions, int64_t act_stride, int32_t* __restrict__ status_io, int B,
-                   int A, double gx, double gy, double* __restrict__ states_out, int64_t states_stride,
-                   double* __restrict__ actions_out, int64_t actout_stride, int32_t* __restrict__ steps_out,
+                   int A, double gx, double gy, double* __restrict__ states_out, ditree_strides sl,
+                   double* __restrict__ actions_out, ditree_strides al, int32_t* __restrict__ steps_out,
                    int64_t steps_stride, int32_t* __restrict__ chunks_run, double* __restrict__ prev_action_io,
                    uint8_t* __restrict__ has_prev_io, const int32_t* __restrict__ idx, int act_dense,
                    const int32_t* __restrict__ budget, int chunk_j) {
@@ -372,11 +344,13 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
   for (int k = 0; k < 6; ++k) s[k] = state_io[(size_t)b * 6 + k];
   const double* act = actions + (size_t)(act_dense ? ob : b) * act_stride;
   // G = 2: lane 0 owns the state rows, lane 1 the action rows
-  double* so = (states_out && (G == 1 || g == 0)) ? states_out + (size_t)b * states_stride : nullptr;
-  double* ao = (actions_out && (G == 1 || g == 1)) ? actions_out + (size_t)b * actout_stride : nullptr;
+  // row i, component k of a candidate's block: base + i * row + k * comp (packed rows: {6, 1}; step-major SoA: {6 B, B} --
+  // then the 64 lanes of a wave store 512 contiguous bytes)
+  double* so = (states_out && (G == 1 || g == 0)) ? states_out + (size_t)b * sl.cand : nullptr;
+  double* ao = (actions_out && (G == 1 || g == 1)) ? actions_out + (size_t)b * al.cand : nullptr;
   if (so) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) so[k] = s[k];                                   // states_sequence[0] = state
+    for (int k = 0; k < 6; ++k) so[k * sl.comp] = s[k];                         // states_sequence[0] = state
   }
   int status = DITREE_ST_OK;
   int steps = 0;
@@ -388,9 +362,9 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
     steps = i + 1;
     if (so) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) so[(size_t)(i + 1) * 6 + k] = s[k];
+      for (int k = 0; k < 6; ++k) so[(size_t)(i + 1) * sl.row + k * sl.comp] = s[k];
     }
-    if (ao) { ao[2 * i] = a0r; ao[2 * i + 1] = a1r; }
+    if (ao) { ao[(size_t)i * al.row] = a0r; ao[(size_t)i * al.row + al.comp] = a1r; }
     la0 = a0r; la1 = a1r;
     double ex = s[0] - gx, ey = s[1] - gy;
     bool done = sqrt(fma(ey, ey, ex * ex)) < 0.5;   // np.linalg.norm (ddot rounds as one fma), car_env.py:346-351
@@ -418,14 +392,14 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
   for (int r = i; r < A; ++r) {
     if (so) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) so[(size_t)(r + 1) * 6 + k] = 0.0;
+      for (int k = 0; k < 6; ++k) so[(size_t)(r + 1) * sl.row + k * sl.comp] = 0.0;
     }
     if (ao) {
       // only the goal branch zeroes the remaining actions (:314-317); a collided edge is discarded
       // by the caller, its untouched tail is copied through like the reference's array
       const bool z = (status == DITREE_ST_GOAL);
-      ao[2 * r] = z ? 0.0 : act[2 * r];
-      ao[2 * r + 1] = z ? 0.0 : act[2 * r + 1];
+      ao[(size_t)r * al.row] = z ? 0.0 : act[2 * r];
+      ao[(size_t)r * al.row + al.comp] = z ? 0.0 : act[2 * r + 1];
     }
   }
   if (G == 2 && g != 0) return;                       // per-candidate results: lane 0
@@ -442,7 +416,7 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
 }
 void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double* state_io, const double* actions,
                            int64_t act_stride, int32_t* status_io, int B, int A, double gx, double gy,
-                           double* states_out, int64_t states_stride, double* actions_out, int64_t actout_stride,
+                           double* states_out, ditree_strides states_stride, double* actions_out, ditree_strides actout_stride,
                            int32_t* steps_out, int64_t steps_stride, int32_t* chunks_run, double* prev_action_io,
                            uint8_t* has_prev_io, const int32_t* idx, int act_dense, hipStream_t s, const int32_t* budget,
                            int chunk_j) {
@@ -473,8 +447,8 @@ void launch_car_rollout(const unsigned char* maze, int rows, int cols, double* s
                         double* states_out, int64_t states_stride, double* actions_out, int64_t actout_stride,
                         int32_t* steps_out, double* prev_action_io, uint8_t* has_prev_io, hipStream_t s) {
   launch_car_rollout_ex(maze, rows, cols, state_io, actions, act_stride, status_io, B, A, gx, gy, states_out,
-                        states_stride, actions_out, actout_stride, steps_out, 1, nullptr, prev_action_io,
-                        has_prev_io, nullptr, 1, s, nullptr, 0);
+                        ditree_strides{states_stride, 6, 1}, actions_out, ditree_strides{actout_stride, 2, 1}, steps_out, 1,
+                        nullptr, prev_action_io, has_prev_io, nullptr, 1, s, nullptr, 0);
 }
 
 // ------------------------------------------------------------------------- lidar
@@ -992,7 +966,8 @@ accept_scan_kernel(ditree_tree t, ditree_round r, int emulate_sticky) {
 }
 
 // Phase 2: one wave per candidate copies the accepted edge into its node slot, dropping
-// all-zero rows (RRT.py:196-199).
+// all-zero rows (RRT.py:196-199).  State / action width S / D at run time (car 6 / 2, ant 29 / 8; S, D <= 64: a lane per
+// component, the zero-row test is one ballot).
 __global__ void __launch_bounds__(64)
 accept_commit_kernel(ditree_tree t, ditree_round r, const unsigned char* __restrict__ maze, int rows, int cols,
                      AheadArg ts) {
@@ -1000,65 +975,63 @@ accept_commit_kernel(ditree_tree t, ditree_round r, const unsigned char* __restr
   const int id = r.node_id[b];
   if (id < 0) return;
   const int lane = threadIdx.x;
-  const int A = t.A, nC = t.n_chunks;
+  const int A = t.A, nC = t.n_chunks, S = t.state_dim, D = t.action_dim;
   const int phantom = t.counters[7];
   const int par = r.parent[b];
   const size_t es_cap = (size_t)nC * (A + 1), ea_cap = (size_t)nC * A;
-  double* es = t.edge_states + (size_t)id * es_cap * 6;
-  double* ea = t.edge_actions + (size_t)id * ea_cap * 2;
-  const double* cs = r.states + (size_t)b * es_cap * 6;
-  const double* ca = r.actions + (size_t)b * ea_cap * 2;
+  double* es = t.edge_states + (size_t)id * es_cap * S;
+  double* ea = t.edge_actions + (size_t)id * ea_cap * D;
+  const double* cs = r.states + (size_t)b * es_cap * S;
+  const double* ca = r.actions + (size_t)b * ea_cap * D;
   int ns = 0, na = 0;
-  double endst[6];
+  double endv = 0.0;                                   // lane k < S: component k of the node's state
   // sharded rounds: the trajectories of candidates another rank expanded are not here -- their nodes get state, parent
   // and last action from the exchanged record, the edge rows stay with the owner (edge_owner)
   const bool own = r.shard == 0 || (b >= r.own_lo && b < r.own_lo + r.own_n);
   int owner = -1;
   if (b == phantom) {
     // frozen env step (car_env.py:254): the edge is [s, s] and the first sampled action
-    for (int k = 0; k < 6; ++k) endst[k] = t.state[(size_t)par * 6 + k];
-    bool zero = true;
-    for (int k = 0; k < 6; ++k) zero &= (endst[k] == 0.0);
+    if (lane < S) endv = t.state[(size_t)par * S + lane];
+    const bool zero = __ballot(lane < S && endv != 0.0) == 0ull;
     if (!zero) {
-      if (lane < 6) { es[lane] = endst[lane]; es[6 + lane] = endst[lane]; }
+      if (lane < S) { es[lane] = endv; es[S + lane] = endv; }
       ns = 2;
     }
-    const double fa0 = r.first_action ? r.first_action[(size_t)b * 2] : ca[0];
-    const double fa1 = r.first_action ? r.first_action[(size_t)b * 2 + 1] : ca[1];
-    if (!(fa0 == 0.0 && fa1 == 0.0)) {
-      if (lane == 0) { ea[0] = fa0; ea[1] = fa1; }
+    double fa = 0.0;
+    if (lane < D) fa = r.first_action ? r.first_action[(size_t)b * D + lane] : ca[lane];
+    if (__ballot(lane < D && fa != 0.0) != 0ull) {
+      if (lane < D) ea[lane] = fa;
       na = 1;
     }
   } else if (!own) {
-    for (int k = 0; k < 6; ++k) endst[k] = r.end_state[(size_t)b * 6 + k];
+    if (lane < S) endv = r.end_state[(size_t)b * S + lane];
     owner = r.shard > 0 ? b / r.shard : 0;
     ns = -1;
     na = -1;
   } else {
-    for (int k = 0; k < 6; ++k) endst[k] = r.end_state[(size_t)b * 6 + k];
+    if (lane < S) endv = r.end_state[(size_t)b * S + lane];
     owner = r.shard > 0 ? b / r.shard : -1;
     const int run = r.chunks_run[b];
     const int rows_s = run * (A + 1), rows_a = run * A;
-    // serial compaction per wave: rows are few (<= 72) and tiny
+    // serial compaction per wave: rows are few (<= 72) and small
     for (int row = 0; row < rows_s; ++row) {
-      const double* p = cs + (size_t)row * 6;
-      bool zero = true;
-      for (int k = 0; k < 6; ++k) zero &= (p[k] == 0.0);
-      if (!zero) {
-        if (lane < 6) es[(size_t)ns * 6 + lane] = p[lane];
+      const double v = lane < S ? cs[(size_t)row * S + lane] : 0.0;
+      if (__ballot(v != 0.0) != 0ull) {
+        if (lane < S) es[(size_t)ns * S + lane] = v;
         ++ns;
       }
     }
     for (int row = 0; row < rows_a; ++row) {
-      const double* p = ca + (size_t)row * 2;
-      if (!(p[0] == 0.0 && p[1] == 0.0)) {
-        if (lane < 2) ea[(size_t)na * 2 + lane] = p[lane];
+      const double v = lane < D ? ca[(size_t)row * D + lane] : 0.0;
+      if (__ballot(v != 0.0) != 0ull) {
+        if (lane < D) ea[(size_t)na * D + lane] = v;
         ++na;
       }
     }
   }
-  if (lane < 6) t.state[(size_t)id * 6 + lane] = endst[lane];
-  if (lane < 2) t.xy[(size_t)id * 2 + lane] = endst[lane];
+  if (lane < S) t.state[(size_t)id * S + lane] = endv;
+  if (lane < 2) t.xy[(size_t)id * 2 + lane] = endv;
+  const double psi = __shfl(endv, 2), ex = __shfl(endv, 0), ey = __shfl(endv, 1);
   if (lane == 0) {
     t.parent[id] = par;
     t.has_prev[id] = 1;
@@ -1067,51 +1040,96 @@ accept_commit_kernel(ditree_tree t, ditree_round r, const unsigned char* __restr
     t.edge_nactions[id] = na;
     if (t.edge_owner != nullptr) t.edge_owner[id] = owner;
     if (t.obstacle_ahead != nullptr)                                   // RRT.py:202-205 (run_type > 0)
-      t.obstacle_ahead[id] = obstacle_ahead_dev(endst[0], endst[1], endst[2], maze, rows, cols, ts) ? 1 : 0;
+      t.obstacle_ahead[id] = obstacle_ahead_dev(ex, ey, psi, maze, rows, cols, ts) ? 1 : 0;
   }
-  __syncthreads();
-  if (lane < 2) {
+  if (lane < D) {
     double la;
-    if (r.last_action != nullptr && b != phantom) la = r.last_action[(size_t)b * 2 + lane];     // exchanged record
-    else la = (na > 0) ? ea[(size_t)(na - 1) * 2 + lane] : 0.0;
-    t.last_action[(size_t)id * 2 + lane] = la;
+    // a lane reads back what it stored itself (same address, program order)
+    if (r.last_action != nullptr && b != phantom) la = r.last_action[(size_t)b * D + lane];     // exchanged record
+    else la = (na > 0) ? ea[(size_t)(na - 1) * D + lane] : 0.0;
+    t.last_action[(size_t)id * D + lane] = la;
+  }
+  if (t.hist != nullptr) {
+    // what the first sampler call of a child will see (RRT.py:146-147: parent_states_seq, fm_policy.py:96-102: its last
+    // obs_history = 3 rows): valid rows at the END of the node's three slots
+    double* h = t.hist + (size_t)id * 3 * S;
+    int n;
+    if (ns >= 0) {
+      n = ns < 3 ? ns : 3;
+      for (int q = 0; q < n; ++q)
+        if (lane < S) h[(size_t)(3 - n + q) * S + lane] = es[(size_t)(ns - n + q) * S + lane];
+    } else {
+      n = r.hist_n[b];
+      for (int q = 3 - n; q < 3; ++q)
+        if (lane < S) h[(size_t)q * S + lane] = r.hist[((size_t)b * 3 + q) * S + lane];
+    }
+    if (lane == 0) t.hist_n[id] = n;
   }
 }
 
-// ---- candidate records of a sharded round (include/ditree.h DITREE_RECORD_DOUBLES)
-__global__ void round_pack_kernel(ditree_tree t, ditree_round r, double* __restrict__ rec) {
+// ---- candidate records of a sharded round (include/ditree.h "Candidate record"): R = S + 2 D + 2 [+ 3 S] doubles
+__device__ __forceinline__ bool row_is_zero(const double* p, int n) {
+  bool z = true;
+  for (int k = 0; k < n; ++k) z &= (p[k] == 0.0);
+  return z;
+}
+__global__ void round_pack_kernel(ditree_tree t, ditree_round r, double* __restrict__ rec, int R) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= r.B) return;
-  double* o = rec + (size_t)b * DITREE_RECORD_DOUBLES;
-  for (int k = 0; k < 6; ++k) o[k] = r.end_state[(size_t)b * 6 + k];
-  const int A = t.A, nC = t.n_chunks;
-  const double* ca = r.actions + (size_t)b * nC * A * 2;
+  const int A = t.A, nC = t.n_chunks, S = t.state_dim, D = t.action_dim;
+  double* o = rec + (size_t)b * R;
+  for (int k = 0; k < S; ++k) o[k] = r.end_state[(size_t)b * S + k];
+  const double* ca = r.actions + (size_t)b * nC * A * D;
   // last kept (non-zero) action row of the chunks that ran: what accept_commit_kernel derives from the compacted edge
-  double l0 = 0.0, l1 = 0.0;
+  double* la = o + S;
+  for (int k = 0; k < D; ++k) la[k] = 0.0;
   for (int row = r.chunks_run[b] * A - 1; row >= 0; --row) {
-    const double a0 = ca[(size_t)row * 2], a1 = ca[(size_t)row * 2 + 1];
-    if (!(a0 == 0.0 && a1 == 0.0)) { l0 = a0; l1 = a1; break; }
+    if (!row_is_zero(ca + (size_t)row * D, D)) {
+      for (int k = 0; k < D; ++k) la[k] = ca[(size_t)row * D + k];
+      break;
+    }
   }
-  o[6] = l0; o[7] = l1;
-  o[8] = ca[0]; o[9] = ca[1];
-  int32_t* oi = (int32_t*)(o + 10);
-  oi[0] = r.parent[b]; oi[1] = r.status[b]; oi[2] = r.chunks_run[b]; oi[3] = 0;
+  for (int k = 0; k < D; ++k) o[S + D + k] = ca[k];
+  int n = 0;
+  if (t.hist != nullptr) {
+    // the last <= 3 kept state rows, valid rows at the end of the three slots
+    const double* cs = r.states + (size_t)b * nC * (A + 1) * S;
+    double* h = o + S + 2 * D + 2;
+    for (int k = 0; k < 3 * S; ++k) h[k] = 0.0;
+    for (int row = r.chunks_run[b] * (A + 1) - 1; row >= 0 && n < 3; --row) {
+      if (!row_is_zero(cs + (size_t)row * S, S)) {
+        for (int k = 0; k < S; ++k) h[(size_t)(2 - n) * S + k] = cs[(size_t)row * S + k];
+        ++n;
+      }
+    }
+  }
+  int32_t* oi = (int32_t*)(o + S + 2 * D);
+  oi[0] = r.parent[b]; oi[1] = r.status[b]; oi[2] = r.chunks_run[b]; oi[3] = n;
 }
-__global__ void round_unpack_kernel(ditree_round r, const double* __restrict__ rec) {
+__global__ void round_unpack_kernel(ditree_tree t, ditree_round r, const double* __restrict__ rec, int R) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= r.B) return;
-  const double* o = rec + (size_t)b * DITREE_RECORD_DOUBLES;
-  for (int k = 0; k < 6; ++k) r.end_state[(size_t)b * 6 + k] = o[k];
-  r.last_action[(size_t)b * 2] = o[6]; r.last_action[(size_t)b * 2 + 1] = o[7];
-  r.first_action[(size_t)b * 2] = o[8]; r.first_action[(size_t)b * 2 + 1] = o[9];
-  const int32_t* oi = (const int32_t*)(o + 10);
+  const int S = t.state_dim, D = t.action_dim;
+  const double* o = rec + (size_t)b * R;
+  for (int k = 0; k < S; ++k) r.end_state[(size_t)b * S + k] = o[k];
+  for (int k = 0; k < D; ++k) {
+    r.last_action[(size_t)b * D + k] = o[S + k];
+    r.first_action[(size_t)b * D + k] = o[S + D + k];
+  }
+  const int32_t* oi = (const int32_t*)(o + S + 2 * D);
   r.parent[b] = oi[0]; r.status[b] = oi[1]; r.chunks_run[b] = oi[2];
+  if (t.hist != nullptr) {
+    r.hist_n[b] = oi[3];
+    const double* h = o + S + 2 * D + 2;
+    for (int k = 0; k < 3 * S; ++k) r.hist[(size_t)b * 3 * S + k] = h[k];
+  }
 }
+int record_doubles(const ditree_tree& t) { return t.state_dim + 2 * t.action_dim + 2 + (t.hist ? 3 * t.state_dim : 0); }
 void launch_round_pack(const ditree_tree& t, const ditree_round& r, double* rec, hipStream_t s) {
-  hipLaunchKernelGGL(round_pack_kernel, dim3((r.B + 127) / 128), dim3(128), 0, s, t, r, rec);
+  hipLaunchKernelGGL(round_pack_kernel, dim3((r.B + 127) / 128), dim3(128), 0, s, t, r, rec, record_doubles(t));
 }
-void launch_round_unpack(const ditree_round& r, const double* rec, hipStream_t s) {
-  hipLaunchKernelGGL(round_unpack_kernel, dim3((r.B + 127) / 128), dim3(128), 0, s, r, rec);
+void launch_round_unpack(const ditree_tree& t, const ditree_round& r, const double* rec, hipStream_t s) {
+  hipLaunchKernelGGL(round_unpack_kernel, dim3((r.B + 127) / 128), dim3(128), 0, s, t, r, rec, record_doubles(t));
 }
 
 void launch_accept(const ditree_tree& t, const ditree_round& r, int emulate_sticky, const unsigned char* maze, int rows,

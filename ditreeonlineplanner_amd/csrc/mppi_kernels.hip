@@ -335,9 +335,10 @@ extern "C" int32_t ditree_mppi_step(ditree_ctx* ctx, const ditree_mppi_params* p
   a.gx = goal_xy[0]; a.gy = goal_xy[1];
   a.k0 = p->k_offset;
   const int slices = std::min(MPPI_SLICES, (a.K + 255) / 256);      // 256 rollouts per slice up to 65 536, more beyond
-  if (!ctx->mppi_partial) {
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->mppi_partial, (size_t)MPPI_SLICES * (3 + 2 * MPPI_MAX_T) * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->mppi_minkey, sizeof(unsigned long long)));
+  if (!ctx->mppi_partial || !ctx->mppi_minkey) {             // both or neither: a failed second allocation is retried, never skipped
+    if (!ctx->mppi_partial)
+      HIP_TRY(ctx, hipMalloc((void**)&ctx->mppi_partial, (size_t)MPPI_SLICES * (3 + 2 * MPPI_MAX_T) * sizeof(double)));
+    if (!ctx->mppi_minkey) HIP_TRY(ctx, hipMalloc((void**)&ctx->mppi_minkey, sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->mppi_minkey, 0xFF, sizeof(unsigned long long), s));
   }
   if (stages & DITREE_MPPI_ROLLOUTS) {

@@ -25,18 +25,24 @@ CNT_NODES, CNT_GOAL, CNT_LATCH, CNT_ITERS, CNT_CANDS, CNT_STICKY, CNT_OVERFLOW, 
 
 
 class DeviceTree:
-    def __init__(self, ctx: Context, capacity: int, n_chunks: int, A: int, track_obstacle_ahead: bool = False):
+    """planners/base_planner.py:24-34 ``Node`` as a struct of arrays in HBM (include/ditree.h ditree_tree).  ``state_dim`` /
+    ``action_dim``: 6 / 2 for the car, 29 / 8 for the ant; ``hist``: keep the last three rows of every node's edge (what the
+    first sampler call of a child sees with obs_history 3 -- the ant)."""
+
+    def __init__(self, ctx: Context, capacity: int, n_chunks: int, A: int, track_obstacle_ahead: bool = False,
+                 state_dim: int = 6, action_dim: int = 2, hist: bool = False):
         dev = ctx.device
         self.capacity, self.n_chunks, self.A = capacity, n_chunks, A
+        self.S, self.D = S, D = int(state_dim), int(action_dim)
         f64, i32, u8 = torch.float64, torch.int32, torch.uint8
-        self.state = torch.zeros(capacity, 6, dtype=f64, device=dev)
+        self.state = torch.zeros(capacity, S, dtype=f64, device=dev)
         self.xy = torch.zeros(capacity, 2, dtype=f64, device=dev)
         self.parent = torch.full((capacity,), -1, dtype=i32, device=dev)
-        self.last_action = torch.zeros(capacity, 2, dtype=f64, device=dev)
+        self.last_action = torch.zeros(capacity, D, dtype=f64, device=dev)
         self.has_prev = torch.zeros(capacity, dtype=u8, device=dev)
         self.num_visit = torch.zeros(capacity, dtype=i32, device=dev)
-        self.edge_states = torch.zeros(capacity, n_chunks * (A + 1), 6, dtype=f64, device=dev)
-        self.edge_actions = torch.zeros(capacity, n_chunks * A, 2, dtype=f64, device=dev)
+        self.edge_states = torch.zeros(capacity, n_chunks * (A + 1), S, dtype=f64, device=dev)
+        self.edge_actions = torch.zeros(capacity, n_chunks * A, D, dtype=f64, device=dev)
         self.edge_nstates = torch.zeros(capacity, dtype=i32, device=dev)
         self.edge_nactions = torch.zeros(capacity, dtype=i32, device=dev)
         self.counters = torch.zeros(8, dtype=i32, device=dev)
@@ -44,10 +50,13 @@ class DeviceTree:
         self.obstacle_ahead = torch.zeros(capacity, dtype=u8, device=dev) if track_obstacle_ahead else None
         # rank holding each node's edge rows (sharded rounds keep trajectories on the producing rank); -1 = every rank
         self.edge_owner = torch.full((capacity,), -1, dtype=i32, device=dev)
-        self.desc = Tree(capacity, n_chunks, A, *[None if t is None else t.data_ptr() for t in (
+        self.hist = torch.zeros(capacity, 3, S, dtype=f64, device=dev) if hist else None
+        self.hist_n = torch.zeros(capacity, dtype=i32, device=dev) if hist else None
+        self.desc = Tree(capacity, n_chunks, A, S, D, *[None if t is None else t.data_ptr() for t in (
             self.state, self.xy, self.parent, self.last_action, self.has_prev, self.num_visit,
             self.edge_states, self.edge_actions, self.edge_nstates, self.edge_nactions, self.obstacle_ahead,
-            self.edge_owner, self.counters)])
+            self.edge_owner, self.hist, self.hist_n, self.counters)])
+        self.record_doubles = int(lib().ditree_record_doubles(C.byref(self.desc)))
         self.n_nodes_host = 0
 
     def reset(self, start_state):
@@ -62,6 +71,10 @@ class DeviceTree:
         self.edge_nactions[0] = 0
         if self.obstacle_ahead is not None:
             self.obstacle_ahead.zero_()
+        if self.hist is not None:                       # RRT.py:146: the root's child sees curr_state[None, None, :]
+            self.hist[0].zero_()
+            self.hist[0, 2] = s
+            self.hist_n[0] = 1
         self.counters.zero_()
         self.counters[CNT_NODES] = 1
         self.counters[CNT_GOAL] = -1
@@ -75,27 +88,35 @@ class DeviceTree:
 
 
 class RoundBuffers:
-    def __init__(self, ctx: Context, B: int, n_chunks: int, A: int):
+    def __init__(self, ctx: Context, B: int, n_chunks: int, A: int, state_dim: int = 6, action_dim: int = 2, hist: bool = False,
+                 record_doubles: int = _lib.RECORD_DOUBLES):
         dev = ctx.device
         self.B = B
+        self.S, self.D, self.with_hist, self.R = int(state_dim), int(action_dim), bool(hist), int(record_doubles)
+        S, D = self.S, self.D
         f64, i32 = torch.float64, torch.int32
         self.parent = torch.zeros(B, dtype=i32, device=dev)
         self.status = torch.zeros(B, dtype=i32, device=dev)
         self.chunks_run = torch.zeros(B, dtype=i32, device=dev)
-        self.end_state = torch.zeros(B, 6, dtype=f64, device=dev)
-        self.states = torch.zeros(B, n_chunks, A + 1, 6, dtype=f64, device=dev)
-        self.actions = torch.zeros(B, n_chunks, A, 2, dtype=f64, device=dev)
+        self.end_state = torch.zeros(B, S, dtype=f64, device=dev)
+        self.states = torch.zeros(B, n_chunks, A + 1, S, dtype=f64, device=dev)
+        self.actions = torch.zeros(B, n_chunks, A, D, dtype=f64, device=dev)
         self.chunk_steps = torch.zeros(B, n_chunks, dtype=i32, device=dev)
         self.node_id = torch.full((B,), -1, dtype=i32, device=dev)
-        # sharded rounds only (allocated on first use): exchanged 96-byte records and what they carry beyond the SoA above
-        self.records = self.last_action = self.first_action = None
+        # sharded rounds only (allocated on first use): exchanged records (96 bytes for the car) and what they carry beyond
+        # the SoA above
+        self.records = self.last_action = self.first_action = self.hist = self.hist_n = None
 
     def ensure_exchange(self, rows):
         if self.records is None or self.records.shape[0] < rows:
             dev = self.parent.device
-            self.records = torch.zeros(rows, _lib.RECORD_DOUBLES, dtype=torch.float64, device=dev)
-            self.last_action = torch.zeros(max(rows, self.B), 2, dtype=torch.float64, device=dev)
-            self.first_action = torch.zeros(max(rows, self.B), 2, dtype=torch.float64, device=dev)
+            n = max(rows, self.B)
+            self.records = torch.zeros(rows, self.R, dtype=torch.float64, device=dev)
+            self.last_action = torch.zeros(n, self.D, dtype=torch.float64, device=dev)
+            self.first_action = torch.zeros(n, self.D, dtype=torch.float64, device=dev)
+            if self.with_hist:
+                self.hist = torch.zeros(n, 3, self.S, dtype=torch.float64, device=dev)
+                self.hist_n = torch.zeros(n, dtype=torch.int32, device=dev)
 
     def fields(self):
         return (self.parent, self.status, self.chunks_run, self.end_state, self.states, self.actions,
@@ -106,11 +127,13 @@ class RoundBuffers:
         ``shard`` = candidates per rank for a sharded round (default: every row was produced here)."""
         n = self.B - lo if n is None else n
         ptrs = [t[lo:lo + n].data_ptr() if n > 0 else t.data_ptr() for t in self.fields()]
-        la = fa = None
+        la = fa = hs = hn = None
         if shard and self.last_action is not None:
             la, fa = self.last_action[lo:].data_ptr(), self.first_action[lo:].data_ptr()
+            if self.hist is not None:
+                hs, hn = self.hist[lo:].data_ptr(), self.hist_n[lo:].data_ptr()
         own_lo, own_n = (0, n) if own is None else own
-        return Round(n, *ptrs, la, fa, own_lo, own_n, shard)
+        return Round(n, *ptrs, la, fa, own_lo, own_n, shard, hs, hn)
 
 
 def allgather_round_fields(fields, per, rank, world, group=None):
@@ -171,6 +194,7 @@ def default_shard():
 
 class ExpansionEngine:
     """Batched RRT expansion on one GPU (optionally one shard of a multi-GPU round)."""
+    STATE_DIM, ACTION_DIM, HIST = 6, 2, False
 
     def __init__(self, ctx: Context, maze, start_state, goal_state, edge_length=64, action_horizon=8,
                  pred_horizon=64, local_map_size=20, local_map_scale=0.2, s_global=1.0, batch=1024,
@@ -198,11 +222,13 @@ class ExpansionEngine:
         self.exchange_events = None         # list -> one (start, end) event pair per round around pack + all-gather + unpack
         self.run_type = int(run_type)
         self.init_main_path = None          # (P, >=2) reference path of an earlier plan (run_type > 0)
-        self.tree = DeviceTree(ctx, capacity, self.n_chunks, self.A, track_obstacle_ahead=self.run_type > 0)
+        self.tree = DeviceTree(ctx, capacity, self.n_chunks, self.A, track_obstacle_ahead=self.run_type > 0,
+                               state_dim=self.STATE_DIM, action_dim=self.ACTION_DIM, hist=self.HIST)
         # sharded rounds exchange ceil(batch / world) fixed slots per rank: size the round buffers for whole slots, so a batch
         # that does not divide by the rank count is fine (the last rank's tail slots stay unused)
         per = (batch + world_size - 1) // world_size
-        self.rb = RoundBuffers(ctx, per * world_size, self.n_chunks, self.A)
+        self.rb = RoundBuffers(ctx, per * world_size, self.n_chunks, self.A, state_dim=self.STATE_DIM,
+                               action_dim=self.ACTION_DIM, hist=self.HIST, record_doubles=self.tree.record_doubles)
         self._budget = self._budget_parent = None
         if len(self.schedule) > 1:
             self._budget = torch.zeros(batch, dtype=torch.int32, device=ctx.device)
@@ -219,13 +245,18 @@ class ExpansionEngine:
     def reset(self, start_state, goal_state):
         self.start_state = np.asarray(start_state, dtype=np.float64).copy()
         self.goal_state = np.asarray(goal_state, dtype=np.float64).copy()
+        if self.start_state.shape != (self.STATE_DIM,):
+            raise ValueError(f"start_state must have {self.STATE_DIM} elements")
+        self._derive_env_goal()
+        self.tree.reset(self.start_state)
+        self.generation = getattr(self, "generation", 0) + 1      # consumers caching per-tree data (node_list) key on it
+
+    def _derive_env_goal(self):
         H, W = self.maze.shape
         # planner.reset -> env.reset(options): env.goal = centre of the goal cell (car_env.py:189-201,225-226)
         gi = np.floor((H / 2 - self.goal_state[1]) / 1.0)
         gj = np.floor((self.goal_state[0] + W / 2) / 1.0)
         self.env_goal = np.array([(gj + 0.5) * 1.0 - W / 2, H / 2 - (gi + 0.5) * 1.0])
-        self.tree.reset(self.start_state)
-        self.generation = getattr(self, "generation", 0) + 1      # consumers caching per-tree data (node_list) key on it
 
     def update_maze(self, maze):
         self.maze = np.asarray(maze, dtype=np.float32)
@@ -302,6 +333,10 @@ class ExpansionEngine:
             rd = self.rb.desc(lo, n)
             check(self.ctx._h, lib().ditree_expand_round(self.ctx._h, C.byref(self.tree.desc), C.byref(rd),
                                                           C.byref(rp), self.ctx.stream), "expand_round")
+        return self._finish_round(B, per, noise is not None, accept)
+
+    def _finish_round(self, B, per, used_denoiser, accept):
+        """The part of a round behind the expansion: the record exchange (sharded rounds) and the replicated accept."""
         if self.world > 1 or self.force_allgather:
             ev = None
             if self.exchange_events is not None:
@@ -313,7 +348,7 @@ class ExpansionEngine:
             if ev is not None:
                 ev[1].record()
                 self.exchange_events.append(ev)
-        self._used_denoiser = noise is not None
+        self._used_denoiser = bool(used_denoiser)
         if accept:
             return self.accept(B)
         return None
@@ -340,8 +375,8 @@ class ExpansionEngine:
                                                         self.ctx.stream), "round_pack")
         allgather_round_fields([rb.records], per, self.rank, self.world, self.pg)
         rd = rb.desc(0, B, shard=per)
-        check(self.ctx._h, lib().ditree_round_unpack(self.ctx._h, C.byref(rd), rb.records.data_ptr(), self.ctx.stream),
-              "round_unpack")
+        check(self.ctx._h, lib().ditree_round_unpack(self.ctx._h, C.byref(self.tree.desc), C.byref(rd), rb.records.data_ptr(),
+                                                      self.ctx.stream), "round_unpack")
 
     def accept(self, B):
         self.ensure_maze()                        # run_type > 0: the commit kernel evaluates check_obstacle_ahead
@@ -435,3 +470,129 @@ class ExpansionEngine:
         n = self.tree.n_nodes_host
         return dict(parents=self.tree.parent[:n].cpu().numpy(), states=self.tree.state[:n].cpu().numpy(),
                     counters=self.tree.counters.cpu().numpy())
+
+
+class AntExpansionEngine(ExpansionEngine):
+    """The expansion rounds of BASELINE config 3 (cfgs/antmaze.yaml: 29-d states, 8-d actions, action_horizon 2, edge length
+    48, obs_history 3, local map 16 @ 0.8, s_global 4): nearest node -> 24 chunks x [local map -> ant conditioning vector ->
+    denoiser -> 2 env steps with the reference's goal (planners/base_planner.py:296-297) and collision tests
+    (common/map_utils.py:126-219)] -> accept (planners/RRT.py:195-217), on a tree that also keeps every node's last three
+    edge rows (the history a child's first sampler call sees).
+
+    THE ENV STEP is MuJoCo in the reference (third party, no oracle here) and is NOT implemented.  ``dynamics``:
+      "tape"   ``expand_round(..., next_obs_tape=(B, n_chunks, A, 29))``: observations given from outside;
+      "model"  the build's stand-in crawler model (include/ditree.h ditree_ant_model; not MuJoCo, parity unpinned);
+      "host"   ``expand_round(..., step_fn=...)``: the caller's simulator, ``step_fn(chunk, start_states (n, 29), actions
+               (n, A, 8), rows (n,)) -> (n, A, 29)`` observations, called once per chunk for the candidates still alive.
+    """
+    STATE_DIM, ACTION_DIM, HIST = 29, 8, True
+
+    def __init__(self, ctx: Context, maze, start_state, goal_state, desired_goal=None, norm=None, edge_length=48,
+                 action_horizon=2, pred_horizon=16, local_map_size=16, local_map_scale=0.8, s_global=4.0, batch=4096,
+                 capacity=65536, k_steps=1, rank=0, world_size=1, process_group=None, early_exit=False, goal_scale=None,
+                 dynamics="tape", model=None, ball_radius=1.2, goal_factor=0.45):
+        if norm is None:
+            raise ValueError("AntExpansionEngine: norm = obs_mean[27] + obs_std[27] + act_mean[8] + act_std[8] (metadata/antmaze.pt)")
+        if dynamics not in ("tape", "model", "host"):
+            raise ValueError("dynamics must be 'tape', 'model' or 'host'")
+        self.dynamics = dynamics
+        self.model = _lib.AntModel.default() if model is None else model
+        self.ball_radius = float(ball_radius)
+        self.goal_radius = float(goal_factor) * float(s_global)          # planners/base_planner.py:297
+        self._desired_arg = None if desired_goal is None else np.asarray(desired_goal, dtype=np.float64)[:2].copy()
+        super().__init__(ctx, maze, start_state, goal_state, edge_length=edge_length, action_horizon=action_horizon,
+                         pred_horizon=pred_horizon, local_map_size=local_map_size, local_map_scale=local_map_scale,
+                         s_global=s_global, batch=batch, capacity=capacity, k_steps=k_steps, emulate_sticky_done=False,
+                         norm=np.asarray(norm, dtype=np.float64), rank=rank, world_size=world_size, process_group=process_group,
+                         early_exit=early_exit, run_type=0, goal_scale=goal_scale)
+        if self.norm.size != 70:
+            raise ValueError("norm: 27 + 27 + 8 + 8 doubles")
+
+    def _derive_env_goal(self):
+        # obs['desired_goal'] of the env (the goal cell's centre plus the env's position noise): given by the caller, else
+        # the centre of the goal cell in the scaled map
+        if self._desired_arg is not None:
+            self.env_goal = self._desired_arg.copy()
+            return
+        H, W = self.maze.shape
+        sg = float(self.s_global)
+        gi = np.floor((H / 2 * sg - self.goal_state[1]) / sg)
+        gj = np.floor((self.goal_state[0] + W / 2 * sg) / sg)
+        self.env_goal = np.array([(gj + 0.5) * sg - W / 2 * sg, H / 2 * sg - (gi + 0.5) * sg])
+
+    def _params(self, samples, cond_goal, noise, inject_actions, lo, hi, next_obs_tape=None, cond_out=None):
+        n = hi - lo
+        rp = _lib.AntRoundParams()
+        rp.n_nodes = self.tree.n_nodes_host
+        rp.samples = samples[lo:hi].data_ptr() if n else None
+        rp.cond_goal = cond_goal[lo:hi].data_ptr() if n else None
+        rp.noise = noise[lo:hi].data_ptr() if (noise is not None and n) else None
+        rp.inject_actions = inject_actions[lo:hi].data_ptr() if (inject_actions is not None and n) else None
+        rp.P, rp.K = self.P, self.k_steps
+        keep = [samples, cond_goal, noise, inject_actions, next_obs_tape, cond_out]
+        for name, arr, conv in (("t0", self.t0, _flt), ("dt", self.dt, _flt), ("norm", self.norm, _dbl),
+                                ("desired_goal", self.env_goal, _dbl), ("axis", self.axis, _dbl)):
+            a, p = conv(arr)
+            keep.append(a)
+            setattr(rp, name, p)
+        rp.goal_radius, rp.ball_radius = self.goal_radius, self.ball_radius
+        rp.lm_n, rp.lm_size, rp.s_global = self.lm_n, self.goal_scale, float(self.s_global)
+        rp.dynamics = _lib.ANT_DYN_MODEL if self.dynamics == "model" else _lib.ANT_DYN_TAPE
+        rp.next_obs_tape = next_obs_tape[lo:hi].data_ptr() if (next_obs_tape is not None and n) else None
+        rp.model = C.pointer(self.model)
+        rp.early_exit = self.early_exit
+        rp.cond_out = cond_out[lo:hi].data_ptr() if (cond_out is not None and n) else None
+        return rp, keep
+
+    def expand_round(self, samples, cond_goal, noise=None, inject_actions=None, accept=True, next_obs_tape=None, step_fn=None,
+                     cond_out=None):
+        """samples (B, 29) f64, cond_goal (B, 2) f64, noise (B, n_chunks, P, 8) f32 or inject_actions (B, n_chunks, P, 8) f64
+        [device tensors, all candidates of the round]; next_obs_tape (B, n_chunks, A, 29) f64 for dynamics='tape'; step_fn for
+        dynamics='host'; cond_out (B, n_chunks, 97) f32: receives every sampler call's conditioning vector (tests)."""
+        B = samples.shape[0]
+        if B > self.batch:
+            raise ValueError(f"round of {B} candidates exceeds engine batch {self.batch}")
+        if tuple(samples.shape) != (B, 29) or tuple(cond_goal.shape) != (B, 2):
+            raise ValueError("samples must be (B, 29), cond_goal (B, 2)")
+        shape = (B, self.n_chunks, self.P, 8)
+        for nm, t in (("noise", noise), ("inject_actions", inject_actions)):
+            if t is not None and tuple(t.shape) != shape:
+                raise ValueError(f"{nm} must be {shape}, got {tuple(t.shape)}")
+        if self.dynamics == "tape" and (next_obs_tape is None or tuple(next_obs_tape.shape) != (B, self.n_chunks, self.A, 29)):
+            raise ValueError(f"dynamics='tape': next_obs_tape must be ({B}, {self.n_chunks}, {self.A}, 29)")
+        if self.dynamics == "host" and step_fn is None:
+            raise ValueError("dynamics='host': step_fn is required")
+        lo, hi, per = self.shard(B)
+        n = hi - lo
+        self.ensure_maze()
+        rp, keep = self._params(samples, cond_goal, noise, inject_actions, lo, hi, next_obs_tape, cond_out)
+        if n > 0:
+            rd = self.rb.desc(lo, n)
+            h, L, t = self.ctx._h, lib(), C.byref(self.tree.desc)
+            if self.dynamics != "host":
+                check(h, L.ditree_expand_round_ant(h, t, C.byref(rd), C.byref(rp), self.ctx.stream), "expand_round_ant")
+            else:
+                self._host_stepped_round(rd, rp, lo, n, step_fn)
+        del keep
+        return self._finish_round(B, per, noise is not None, accept)
+
+    def _host_stepped_round(self, rd, rp, lo, n, step_fn):
+        """The caller's simulator between the two halves of every chunk (include/ditree.h ditree_ant_round_begin / _chunk_sample
+        / _chunk_step): per chunk one D2H of the alive candidates' start states and actions, one H2D of their observations."""
+        h, L, t, st = self.ctx._h, lib(), C.byref(self.tree.desc), self.ctx.stream
+        rb = self.rb
+        check(h, L.ditree_ant_round_begin(h, t, C.byref(rd), C.byref(rp), st), "ant_round_begin")
+        obs = torch.zeros(n, self.A, 29, dtype=torch.float64, device=self.ctx.device)
+        for j in range(self.n_chunks):
+            check(h, L.ditree_ant_chunk_sample(h, t, C.byref(rd), C.byref(rp), j, st), "ant_chunk_sample")
+            alive = torch.nonzero(rb.status[lo:lo + n] == _lib.ST_OK).flatten()
+            if alive.numel() == 0:
+                break
+            rows = alive.cpu().numpy()
+            acts = rb.actions[lo:lo + n, j][alive].cpu().numpy()            # (n_alive, A, 8): what chunk_sample just wrote
+            start = rb.end_state[lo:lo + n][alive].cpu().numpy()
+            o = np.asarray(step_fn(j, start, acts, rows), dtype=np.float64)
+            if o.shape != (rows.size, self.A, 29):
+                raise ValueError(f"step_fn returned {o.shape}, need {(rows.size, self.A, 29)}")
+            obs[alive] = torch.as_tensor(o, device=obs.device)
+            check(h, L.ditree_ant_chunk_step(h, t, C.byref(rd), C.byref(rp), j, obs.data_ptr(), st), "ant_chunk_step")

@@ -171,27 +171,95 @@ class Context:
         return out
 
     # ------------------------------------------------------------------ rollout
-    def car_rollout(self, state, actions, goal_xy, A=8, status=None, prev_action=None, has_prev=None, out=None):
+    def car_rollout(self, state, actions, goal_xy, A=8, status=None, prev_action=None, has_prev=None, out=None, layout=None):
         """state (B,6) f64 [updated in place], actions (B, n>=A, 2) f64.
         Returns (status, states (B,A+1,6), actions_out (B,A,2), steps).  ``out``: a previous return value whose
-        buffers are reused (the kernel writes every row, so no clearing is needed)."""
+        buffers are reused (the kernel writes every row, so no clearing is needed).
+        ``layout``: "rows" = rows packed per candidate (the reference's arrays), "soa" = step-major / component-major /
+        candidate-minor storage (every store of a wavefront is one contiguous 512-byte run; the returned tensors are
+        permuted VIEWS of it with the same (B, A+1, 6) / (B, A, 2) shapes).  Default: "soa" from 4096 candidates up."""
         dev = self.device
         _chk(state, torch.float64, "state", dev)
         _chk(actions, torch.float64, "actions", dev)
         B = state.shape[0]
+        if layout is None:
+            layout = "soa" if B >= 4096 else "rows"
+        if layout not in ("rows", "soa"):
+            raise ValueError("layout must be 'rows' or 'soa'")
         if status is None:
             status = torch.zeros(B, dtype=torch.int32, device=dev)
-        if out is not None and tuple(out[1].shape) == (B, A + 1, 6):
+        if out is not None and tuple(out[1].shape) == (B, A + 1, 6) and (out[1].stride(0) == 1) == (layout == "soa"):
             _, states, aout, steps = out
+        elif layout == "soa":
+            states = torch.zeros(A + 1, 6, B, dtype=torch.float64, device=dev).permute(2, 0, 1)
+            aout = torch.zeros(A, 2, B, dtype=torch.float64, device=dev).permute(2, 0, 1)
+            steps = torch.zeros(B, dtype=torch.int32, device=dev)
         else:
             states = torch.zeros(B, A + 1, 6, dtype=torch.float64, device=dev)
             aout = torch.zeros(B, A, 2, dtype=torch.float64, device=dev)
             steps = torch.zeros(B, dtype=torch.int32, device=dev)
         g, gp = _dbl(goal_xy)
-        check(self._h, lib().ditree_car_rollout(self._h, _ptr(state), _ptr(actions), actions.shape[1] * 2,
-                                                 _ptr(status), B, A, gp, _ptr(states), (A + 1) * 6, _ptr(aout),
-                                                 A * 2, _ptr(steps), _ptr(prev_action), _ptr(has_prev),
-                                                 self.stream), "car_rollout")
+        sl, al = _lib.Strides(*states.stride()), _lib.Strides(*aout.stride())
+        check(self._h, lib().ditree_car_rollout_ld(self._h, _ptr(state), _ptr(actions), actions.shape[1] * 2, _ptr(status), B, A,
+                                                    gp, _ptr(states), C.byref(sl), _ptr(aout), C.byref(al), _ptr(steps),
+                                                    _ptr(prev_action), _ptr(has_prev), self.stream), "car_rollout")
+        return status, states, aout, steps
+
+    # ------------------------------------------------------------------ ant: collision glue + the higher-DoF rollout slot
+    def ant_collision(self, state, ball_radius=1.2, s_global=4.0):
+        """is_colliding_ant(state, maze, ball_radius, s_global) (common/map_utils.py:126-219 as planners/base_planner.py:154-155
+        calls it) for (B, >= 7) f64 states on the uploaded maze -> (B,) u8."""
+        dev = self.device
+        _chk(state, torch.float64, "state", dev)
+        if state.dim() != 2 or state.shape[1] < 7:
+            raise ValueError("state must be (B, >= 7): x, y, z, qw, qx, qy, qz, ...")
+        B = state.shape[0]
+        out = torch.empty(B, dtype=torch.uint8, device=dev)
+        check(self._h, lib().ditree_ant_collision(self._h, _ptr(state), int(state.shape[1]), B, float(ball_radius), float(s_global),
+                                                   _ptr(out), self.stream), "ant_collision")
+        return out
+
+    def ant_rollout(self, state, actions, desired_goal, A=2, model=None, next_obs_tape=None, status=None, s_global=4.0,
+                    ball_radius=1.2, goal_factor=0.45, layout=None, want_rows=True):
+        """planners/base_planner.py:257-320 for B ant candidates (include/ditree.h ditree_ant_rollout): state (B, 29) f64
+        [updated in place], actions (B, n >= A, 8) f64.  The env step is ``model`` (an ``_lib.AntModel``: the build's stand-in,
+        NOT MuJoCo; True = the default constants) or row i of ``next_obs_tape`` (B, A, 29).
+        -> (status, states (B, A+1, 29), actions_out (B, A, 8), steps); layout as car_rollout ("soa" = permuted views)."""
+        dev = self.device
+        _chk(state, torch.float64, "state", dev)
+        _chk(actions, torch.float64, "actions", dev)
+        B = state.shape[0]
+        if tuple(state.shape) != (B, 29) or actions.dim() != 3 or actions.shape[2] != 8 or actions.shape[1] < A:
+            raise ValueError("state must be (B, 29), actions (B, >= A, 8)")
+        if (model is None) == (next_obs_tape is None):
+            raise ValueError("exactly one of model / next_obs_tape")
+        if model is True:
+            model = _lib.AntModel.default()
+        if next_obs_tape is not None:
+            _chk(next_obs_tape, torch.float64, "next_obs_tape", dev)
+            if tuple(next_obs_tape.shape) != (B, A, 29):
+                raise ValueError(f"next_obs_tape must be ({B}, {A}, 29)")
+        if layout is None:
+            layout = "soa" if B >= 4096 else "rows"
+        if status is None:
+            status = torch.zeros(B, dtype=torch.int32, device=dev)
+        states = aout = None
+        if want_rows:
+            if layout == "soa":
+                states = torch.zeros(A + 1, 29, B, dtype=torch.float64, device=dev).permute(2, 0, 1)
+                aout = torch.zeros(A, 8, B, dtype=torch.float64, device=dev).permute(2, 0, 1)
+            else:
+                states = torch.zeros(B, A + 1, 29, dtype=torch.float64, device=dev)
+                aout = torch.zeros(B, A, 8, dtype=torch.float64, device=dev)
+        steps = torch.zeros(B, dtype=torch.int32, device=dev)
+        g, gp = _dbl(np.asarray(desired_goal, dtype=np.float64)[:2])
+        sl = _lib.Strides(*states.stride()) if want_rows else None
+        al = _lib.Strides(*aout.stride()) if want_rows else None
+        check(self._h, lib().ditree_ant_rollout(self._h, C.byref(model) if model is not None else None, _ptr(state), _ptr(actions),
+                                                 actions.shape[1] * 8, _ptr(next_obs_tape), A * 29, _ptr(status), B, A, gp,
+                                                 float(goal_factor) * float(s_global), float(ball_radius), float(s_global),
+                                                 _ptr(states), C.byref(sl) if sl is not None else None, _ptr(aout),
+                                                 C.byref(al) if al is not None else None, _ptr(steps), self.stream), "ant_rollout")
         return status, states, aout, steps
 
     # ------------------------------------------------------------------ obstacle ahead
@@ -304,50 +372,6 @@ def _ctx_denoise(self, noise, local_map, cond, t0=None, dt=None, act_norm=None, 
     return actions if want_actions else xout
 
 
-def _ctx_expand_round_ant(self, obs_hist, prev_action, has_prev, cond_goal, noise, next_obs_tape, norm, act_norm=None,
-                          action_horizon=2, local_map_size=16, local_map_scale=0.8, s_global=4.0, t0=None, dt=None,
-                          want_cond=False, check_range=True):
-    """The ant chunk loop WITHOUT its physics (include/ditree.h ditree_expand_round_ant): obs_hist (B, 1..3, 29) f64,
-    prev_action (B, 8) f64, has_prev (B,) u8, cond_goal (B, 2) f64, noise (B, n_chunks, P, 8) f32, next_obs_tape
-    (B, n_chunks, A, 29) f64 [device tensors].  -> (actions (B, n_chunks, A, 8) f64, end_obs (B, 29) f64[, cond (B, n_chunks, 97)])."""
-    dev = self.device
-    for nm, t, dt_ in (("obs_hist", obs_hist, torch.float64), ("prev_action", prev_action, torch.float64),
-                       ("has_prev", has_prev, torch.uint8), ("cond_goal", cond_goal, torch.float64),
-                       ("noise", noise, torch.float32), ("next_obs_tape", next_obs_tape, torch.float64)):
-        _chk(t, dt_, nm, dev)
-    B = obs_hist.shape[0]
-    P, D, lm, G, _ = self.denoise_dims()
-    nC, A = int(noise.shape[1]), int(action_horizon)
-    if obs_hist.dim() != 3 or obs_hist.shape[2] != 29 or not 1 <= obs_hist.shape[1] <= 3:
-        raise ValueError("obs_hist must be (B, 1..3, 29)")
-    if tuple(noise.shape) != (B, nC, P, 8) or tuple(next_obs_tape.shape) != (B, nC, A, 29) or tuple(prev_action.shape) != (B, 8):
-        raise ValueError(f"noise must be ({B}, n_chunks, {P}, 8), next_obs_tape ({B}, n_chunks, {A}, 29), prev_action ({B}, 8)")
-    p = _lib.AntRoundParams()
-    p.obs_hist, p.n_hist = obs_hist.data_ptr(), int(obs_hist.shape[1])
-    p.prev_action, p.has_prev, p.cond_goal = prev_action.data_ptr(), has_prev.data_ptr(), cond_goal.data_ptr()
-    p.noise, p.next_obs_tape = noise.data_ptr(), next_obs_tape.data_ptr()
-    p.n_chunks, p.A = nC, A
-    t0 = np.zeros(1, dtype=np.float32) if t0 is None else t0
-    dt = np.ones(1, dtype=np.float32) if dt is None else dt
-    t0a, p.t0 = _flt(t0)
-    dta, p.dt = _flt(dt)
-    p.K = len(t0a)
-    nma, p.norm = _dbl(norm)
-    if nma.size != 70:
-        raise ValueError("norm: 27 + 27 + 8 + 8 doubles")
-    ana, p.act_norm = _dbl(nma[54:70] if act_norm is None else act_norm)
-    axa, p.axis = _dbl(local_axis(local_map_size, local_map_scale))
-    p.lm_n, p.lm_size, p.s_global = int(local_map_size), float(local_map_size), float(s_global)
-    actions = torch.empty(B, nC, A, 8, dtype=torch.float64, device=dev)
-    end_obs = torch.empty(B, 29, dtype=torch.float64, device=dev)
-    cond = torch.empty(B, nC, 97, dtype=torch.float32, device=dev) if want_cond else None
-    check(self._h, lib().ditree_expand_round_ant(self._h, C.byref(p), B, _ptr(actions), _ptr(end_obs), _ptr(cond), self.stream),
-          "expand_round_ant")
-    if check_range:
-        self.check_range()
-    return (actions, end_obs, cond) if want_cond else (actions, end_obs)
-
-
 def _ctx_denoise_eval(self, sample, local_map, cond, timestep, reuse_encoder=False, check_range=True):
     """One raw network evaluation net(sample, map, timestep, cond) -> (B,P,D) f32 (the DDPM branch's model call)."""
     dev = self.device
@@ -397,7 +421,6 @@ Context.denoise = _ctx_denoise
 Context.denoise_eval = _ctx_denoise_eval
 Context.debug_read = _ctx_debug_read
 Context.denoise_dims = _ctx_denoise_dims
-Context.expand_round_ant = _ctx_expand_round_ant
 Context.denoise_status = _ctx_denoise_status
 Context.check_range = _ctx_check_range
 Context._check_denoiser_shapes = _ctx_check_denoiser_shapes

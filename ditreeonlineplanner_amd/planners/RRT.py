@@ -27,7 +27,7 @@ import time
 import numpy as np
 import torch
 
-from ..engine import CNT_GOAL, CNT_ITERS, ExpansionEngine, default_shard
+from ..engine import CNT_GOAL, CNT_ITERS, AntExpansionEngine, ExpansionEngine, default_shard
 from .base_planner import BasePlanner, Node
 
 
@@ -57,6 +57,9 @@ class RRT_Planner(BasePlanner):
         self.world_size = int(kwargs.get("world_size", d_world))
         self.rank = int(kwargs.get("rank", d_rank if self.world_size == d_world else 0))
         self.process_group = kwargs.get("process_group", d_pg)
+        if self.is_ant:
+            self._init_ant_engine(sampler, kwargs)
+            return
         self._engine = ExpansionEngine(
             self.ctx, self.maze, self.start_node.state, self.goal_state, edge_length=max(self.prop_duration_schedule),
             prop_duration=self.prop_duration_schedule,
@@ -71,6 +74,58 @@ class RRT_Planner(BasePlanner):
         from concurrent.futures import ThreadPoolExecutor
         self._draw_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ditree-draw")
 
+    # ------------------------------------------------------------------ ant (BASELINE config 3)
+    def _init_ant_engine(self, sampler, kwargs):
+        """env_id = 'antmaze' (cfgs/antmaze.yaml, run_scenarios.py:123-132,225-233): 29-d states, 8-d actions, action_horizon 2,
+        local map 16 @ 0.8, global_map_scale 4.  Everything of the expand loop runs on the device -- sampling glue, denoiser,
+        the reference's collision and goal tests on every observation, accept -- EXCEPT the env step, which is MuJoCo in the
+        reference and is not part of this build: ``ant_dynamics``
+          "host" (default)  the planner steps the CALLER's env (``environment.ant_env.set_state(qpos, qvel)`` +
+                            ``environment.step(action)`` per candidate and step, planners/base_planner.py:278-279,290) between
+                            the two halves of every chunk,
+          "model"           the build's stand-in crawler model on the device (NOT MuJoCo; parity unpinned),
+          "tape"            observations from ``next_obs_tape_fn(first_candidate, B) -> (B, n_chunks, A, 29)`` (tests)."""
+        if self.run_type != 0:
+            raise NotImplementedError("antmaze: run_type 0 (the reference's check_obstacle_ahead / sampling maps are the car's)")
+        if len(self.prop_duration_schedule) != 1:
+            raise NotImplementedError("antmaze: a single prop_duration entry")
+        self.ant_dynamics = kwargs.get("ant_dynamics", "host")
+        self._tape_fn = kwargs.get("next_obs_tape_fn")
+        lm = self.local_map_size if isinstance(self.local_map_size, (int, float)) else self.local_map_size[0]
+        norm = getattr(sampler, "norm", None)
+        if norm is None:
+            raise ValueError("antmaze: the sampler must carry the ant normalisation (DiffusionSampler(env_id='antmaze').norm)")
+        desired = kwargs.get("desired_goal")
+        out = getattr(self, "_reset_out", None)
+        if desired is None and isinstance(out, tuple) and isinstance(out[0], dict) and "desired_goal" in out[0]:
+            desired = out[0]["desired_goal"]                    # the env's goal incl. its position noise (base_planner.py:296)
+        d_rank, d_world, d_pg = default_shard()
+        self.world_size = int(kwargs.get("world_size", d_world))
+        self.rank = int(kwargs.get("rank", d_rank if self.world_size == d_world else 0))
+        self.process_group = kwargs.get("process_group", d_pg)
+        if self.ant_dynamics == "host" and self.world_size > 1:
+            raise NotImplementedError("antmaze with a host-side simulator: one rank (the env object is not sharded)")
+        self._engine = AntExpansionEngine(
+            self.ctx, self.maze, self.start_node.state, self.goal_state, desired_goal=desired, norm=norm,
+            edge_length=self.prop_duration_schedule[0], action_horizon=self.action_horizon,
+            pred_horizon=getattr(sampler, "pred_horizon", 16), local_map_size=int(lm), local_map_scale=self.local_map_scale,
+            s_global=self.s_global, batch=self.batch, capacity=self.capacity, k_steps=getattr(sampler, "num_diffusion_iters", 1),
+            early_exit=kwargs.get("early_exit", True), goal_scale=getattr(sampler, "local_map_size", None),
+            dynamics=self.ant_dynamics, model=kwargs.get("ant_model"), rank=self.rank, world_size=self.world_size,
+            process_group=self.process_group)
+        from concurrent.futures import ThreadPoolExecutor
+        self._draw_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ditree-draw")
+
+    def _ant_env_step(self, chunk, start, actions, rows):
+        """planners/base_planner.py:278-279,290,298 for the alive candidates of one chunk, on the caller's env."""
+        A = actions.shape[1]
+        out = np.zeros((len(rows), A, 29))
+        for k in range(len(rows)):
+            self.env.ant_env.set_state(start[k, :15], start[k, 15:])
+            for i in range(A):
+                out[k, i], _ = self.ant_obs(self.env.step(actions[k, i]))
+        return out
+
     # ------------------------------------------------------------------ reference surface
     def reset(self, start_state=None, goal_state=None, reset_main_path=False):
         if reset_main_path:
@@ -78,18 +133,26 @@ class RRT_Planner(BasePlanner):
         if start_state is not None:
             self.start_node = Node(np.asarray(start_state, dtype=np.float64))
             self.goal_state = np.asarray(goal_state, dtype=np.float64)
-            self.options["reset_cell"] = self.env.cell_xy_to_rowcol(start_state[:2])
-            self.options["reset_deg"] = np.rad2deg(start_state[2])
-            self.options["goal_cell"] = self.env.cell_xy_to_rowcol(goal_state[:2])
+            to_rc = self.env.maze_data.cell_xy_to_rowcol if self.is_ant else self.env.cell_xy_to_rowcol
+            self.options["reset_cell"] = to_rc(start_state[:2])
+            if not self.is_ant:
+                self.options["reset_deg"] = np.rad2deg(start_state[2])
+            self.options["goal_cell"] = to_rc(goal_state[:2])
         self.failed_node_list = []
         self.results = {"iterations": 0, "time": 0, "path": None, "actions": None, "number_of_nodes": 0}
-        self.env.reset(options=self.options)
+        out = self.env.reset(options=self.options)
+        if self.is_ant:
+            if isinstance(out, tuple) and isinstance(out[0], dict) and "desired_goal" in out[0]:
+                self._engine._desired_arg = np.asarray(out[0]["desired_goal"], dtype=np.float64)[:2].copy()
+            self._engine.reset(self.start_node.state, self.goal_state)
+            return
         self._engine.reset(self.start_node.state, self.goal_state)
         self._engine.env_goal = np.asarray(self.env.goal, dtype=np.float64)
 
     def update_maze(self, new_maze):
         self.maze = np.float32(new_maze)
-        self.env.maze_map = new_maze
+        if not self.is_ant:
+            self.env.maze_map = new_maze
         self._engine.update_maze(self.maze)
 
     def adopt_maze(self, new_maze):
@@ -159,11 +222,20 @@ class RRT_Planner(BasePlanner):
         return self.init_main_path[c:, :2].copy()[k:]
 
     def draw_round(self, B, remain_init_path=None):
+        """B x [sample -> conditioning goal], element for element what the reference's loop draws and leaving both global
+        generators where it leaves them -- in bulk (planners/_draw.py: the raw generator output of the whole round is pulled
+        once; 8192 candidates in a few ms instead of 76), falling back to the loop itself for anything the bulk path does not
+        cover."""
+        from ._draw import draw_round_bulk
+        out = draw_round_bulk(self, B, remain_init_path)
+        return out if out is not None else self._draw_round_loop(B, remain_init_path)
+
+    def _draw_round_loop(self, B, remain_init_path=None):
         """B x [sample -> conditioning goal] in the reference's RNG call order (base_planner.py:162-207,
         RRT.py:134-140,153-156).  run_type 0: random_node_sample, then the goal-conditioning coin.
         run_type > 0: with a remaining reference path, np.random.choice of one of its points kept with
         probability 0.6 (else random_node_sample); the conditioning goal is the sample itself."""
-        s = np.zeros((B, 6))
+        s = np.zeros((B, self.start_node.state.shape[0]))
         c = np.zeros((B, 2))
         for i in range(B):
             if remain_init_path is not None:
@@ -192,13 +264,14 @@ class RRT_Planner(BasePlanner):
         if hasattr(self.sampler, "sample_round"):
             a = np.asarray(self.sampler.sample_round(first, B, eng.n_chunks, eng.P), dtype=np.float64)
         else:
-            a = np.empty((B, eng.n_chunks, eng.P, 2))
+            D = eng.ACTION_DIM
+            a = np.empty((B, eng.n_chunks, eng.P, D))
             for b in range(B):
                 for j in range(eng.n_chunks):
                     v = np.asarray(self.sampler(None, None, self.goal_state[:2], None), dtype=np.float64)
-                    a[b, j] = v.reshape(-1, 2) if v.size == eng.P * 2 else v.reshape(1, 2)
-        if a.shape != (B, eng.n_chunks, eng.P, 2):
-            raise ValueError(f"sampler returned actions of shape {a.shape}, need {(B, eng.n_chunks, eng.P, 2)}")
+                    a[b, j] = v.reshape(-1, D) if v.size == eng.P * D else v.reshape(1, D)
+        if a.shape != (B, eng.n_chunks, eng.P, eng.ACTION_DIM):
+            raise ValueError(f"sampler returned actions of shape {a.shape}, need {(B, eng.n_chunks, eng.P, eng.ACTION_DIM)}")
         return torch.as_tensor(np.ascontiguousarray(a), device=self.ctx.device)
 
     def plan(self):
@@ -210,7 +283,8 @@ class RRT_Planner(BasePlanner):
         start_time = time.time()
         drawn = 0
         goal = None
-        orig_prob_map = self.env.prob_map.copy()             # RRT.py:122-125
+        has_pm = hasattr(self.env, "prob_map")               # the gym ant env has none (the reference reads it: RRT.py:122)
+        orig_prob_map = self.env.prob_map.copy() if has_pm else None
         if self.run_type >= 3:
             self.env.update_prob_map_by_loc()
         remain = None
@@ -242,11 +316,17 @@ class RRT_Planner(BasePlanner):
                 pending = pool.submit(self.draw_round, round_size(nxt), remain)
             if network:
                 # every rank draws the noise of the WHOLE round (same generator state everywhere) and uses its slice
-                noise, acts = torch.randn((B, eng.n_chunks, eng.P, 2), device=dev), None
+                noise, acts = torch.randn((B, eng.n_chunks, eng.P, eng.ACTION_DIM), device=dev), None
             else:
                 noise, acts = None, self._host_actions(drawn, B)
+            extra = {}
+            if self.is_ant:
+                if self.ant_dynamics == "host":
+                    extra["step_fn"] = self._ant_env_step
+                elif self.ant_dynamics == "tape":
+                    extra["next_obs_tape"] = torch.as_tensor(np.ascontiguousarray(self._tape_fn(drawn, B)), device=dev)
             cnt = eng.expand_round(torch.as_tensor(s, device=dev), torch.as_tensor(c, device=dev), noise=noise,
-                                   inject_actions=acts)
+                                   inject_actions=acts, **extra)
             drawn += B
             lo, hi, _ = eng.shard(B)
             steps_dev += eng.rb.chunk_steps[lo:hi].sum()
@@ -259,10 +339,13 @@ class RRT_Planner(BasePlanner):
             np.random.set_state(rng_before[1])
         iters = int(cnt[CNT_ITERS]) if cnt is not None else 0
         from ..common import map_utils as _mu
-        _mu.add_cc_calls(eng.sum_over_ranks(int(steps_dev.item())))   # the counter the drivers read (run_scenarios.py:338,343)
-        self.env.prob_map = orig_prob_map
+        if not self.is_ant:                                  # is_colliding_ant does not count its calls (map_utils.py:126-136)
+            _mu.add_cc_calls(eng.sum_over_ranks(int(steps_dev.item())))   # the counter the drivers read (run_scenarios.py:338,343)
+        if has_pm:
+            self.env.prob_map = orig_prob_map
         if goal is not None:
-            self.env.done = True
+            if not self.is_ant:
+                self.env.done = True
             return self.handle_goal_reached(goal, iters, start_time)
         node = eng.fallback_node()                          # RRT.py:227-254
         if node is None:

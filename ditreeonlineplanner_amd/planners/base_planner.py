@@ -37,8 +37,9 @@ class BasePlanner(abc.ABC):
                  local_map_scale=0.2, global_map_scale=1.0, env_id="pushT", time_budget=10, **kwargs):
         if environment is None:
             raise ValueError("Environment is not defined.")
-        if "car" not in env_id.lower():
-            raise NotImplementedError("the engine covers the car environment this round")
+        self.is_ant = "ant" in env_id.lower()
+        if "car" not in env_id.lower() and not self.is_ant:
+            raise NotImplementedError("the engine covers the car and the ant environments (pushT / pointmaze / dronemaze: not built)")
         self.env = environment
         self.device = "cuda"
         self.sampler = sampler
@@ -54,16 +55,28 @@ class BasePlanner(abc.ABC):
         self.render = kwargs.get("render", False)
         self.verbose = kwargs.get("verbose", False)
         self.env_dt = self.env.dt if hasattr(self.env, "dt") else 0.1
-        start = self.env.cell_xy_to_rowcol(start_state[:2])
-        goal = self.env.cell_xy_to_rowcol(goal_state[:2])
-        self.options = {"reset_cell": start, "reset_deg": np.rad2deg(start_state[2]), "goal_cell": goal}
-        self.env.reset(options=self.options)
         self.max_v = 5
-        self.x_center = self.env.x_map_center
-        self.y_center = self.env.y_map_center
-        self.map_width = len(self.env.maze_map[0])
-        self.map_length = len(self.env.maze_map)
-        self.maze = np.float32(self.env.maze_map)
+        if self.is_ant:
+            # planners/base_planner.py:81-92: the maze geometry comes from env.maze_data (gymnasium-robotics Maze: centres
+            # already scaled by maze_size_scaling = global_map_scale)
+            md = self.env.maze_data
+            start = md.cell_xy_to_rowcol(start_state[:2])
+            goal = md.cell_xy_to_rowcol(goal_state[:2])
+            self.options = {"reset_cell": start, "goal_cell": goal}
+            self._reset_out = self.env.reset(options=self.options)
+            self.x_center, self.y_center = md.x_map_center, md.y_map_center
+            self.map_width, self.map_length = md.map_width, md.map_length
+            self.maze = np.float32(md.maze_map)
+        else:
+            start = self.env.cell_xy_to_rowcol(start_state[:2])
+            goal = self.env.cell_xy_to_rowcol(goal_state[:2])
+            self.options = {"reset_cell": start, "reset_deg": np.rad2deg(start_state[2]), "goal_cell": goal}
+            self.env.reset(options=self.options)
+            self.x_center = self.env.x_map_center
+            self.y_center = self.env.y_map_center
+            self.map_width = len(self.env.maze_map[0])
+            self.map_length = len(self.env.maze_map)
+            self.maze = np.float32(self.env.maze_map)
         self.save_bad_edges = False
         self.failed_node_list = []
         self._debug = kwargs.get("debug", False)
@@ -92,6 +105,10 @@ class BasePlanner(abc.ABC):
         one-step rollout leaves the pose unchanged, so its collision flag is the pose's."""
         ctx = self.ctx
         ctx.upload_maze(self.maze)
+        if self.is_ant:
+            # is_colliding_ant(state, self.maze, 1.2, self.s_global) (planners/base_planner.py:154-155)
+            st = torch.as_tensor(np.asarray(state, dtype=np.float64).reshape(1, -1).copy(), device=ctx.device)
+            return bool(ctx.ant_collision(st, 1.2, self.s_global)[0].item())
         st = np.zeros((1, 6))
         st[0, :3] = np.asarray(state, dtype=np.float64)[:3]
         s = torch.as_tensor(st, device=ctx.device)
@@ -103,6 +120,8 @@ class BasePlanner(abc.ABC):
         """planners/base_planner.py:257-320."""
         if action_sequence is None:
             raise ValueError("Action sequence is None.")
+        if self.is_ant:
+            return self._propagate_ant(np.asarray(state, dtype=np.float64), np.array(action_sequence, dtype=np.float64))
         ctx = self.ctx
         A = self.action_horizon
         action_sequence = np.asarray(action_sequence, dtype=np.float64)
@@ -140,6 +159,33 @@ class BasePlanner(abc.ABC):
         acts = aout.cpu().numpy()[0]
         return obs, done, acts, st_full[: len(acts) + 1][None, :]
 
+    def ant_obs(self, step_result):
+        """planners/base_planner.py:298: the 29-d planner state of an env step's observation dict."""
+        obs = step_result[0] if isinstance(step_result, tuple) else step_result
+        return np.hstack((obs["achieved_goal"], obs["observation"])).astype(np.float64), np.asarray(obs["desired_goal"], dtype=np.float64)
+
+    def _propagate_ant(self, state, action_sequence):
+        """planners/base_planner.py:257-320, ant branches: the env step is the CALLER's simulator (MuJoCo in the reference;
+        nothing of it is built here), the goal test (:296-297) runs on the host value and check_collision (:154-155,306) on the
+        device (ditree_ant_collision)."""
+        A = self.action_horizon
+        self.env.ant_env.set_state(state[:15], state[15:])
+        states = np.zeros((A + 1, state.shape[0]))
+        states[0] = state
+        obs, done = state, False
+        for i in range(len(action_sequence[:A])):
+            obs, desired = self.ant_obs(self.env.step(action_sequence[i]))
+            d = obs[:2] - desired
+            done = bool(np.linalg.norm(d) < 0.45 * self.s_global)
+            states[i + 1] = obs
+            if self.check_collision(obs):
+                return obs, None, action_sequence[:i], states[:i][None, :]
+            if done:
+                action_sequence[i + 1:] = 0
+                break
+        action_sequence = action_sequence[:A]
+        return obs, done, action_sequence, states[: len(action_sequence) + 1][None, :]
+
     # ------------------------------------------------------------------ sampling (host, reference RNG order)
     def sample_row_col_from_probability_map(self):
         """planners/base_planner.py:157-160: one categorical draw over the env's sampling-probability map."""
@@ -152,6 +198,12 @@ class BasePlanner(abc.ABC):
         """planners/base_planner.py:162-207 (car): python ``random`` then ``np.random``; run_type >= 2 draws the
         position as the centre of a cell of the sampling-probability map instead of uniformly."""
         if random.random() > self.goal_sample_rate:
+            if "ant" in self.env_id.lower():                      # planners/base_planner.py:193-200
+                state = np.zeros((1, 29))
+                x = np.random.uniform(-self.s_global * self.map_width / 2, self.s_global * self.map_width / 2, size=(batch_size, 1))
+                y = np.random.uniform(-self.s_global * self.map_length / 2, self.s_global * self.map_length / 2, size=(batch_size, 1))
+                state[:, :2] = np.concatenate((x, y), axis=1)
+                return state
             if getattr(self, "run_type", 0) >= 2:
                 rows, cols = self.sample_row_col_from_probability_map()
                 x, y = self.env.cell_rowcol_to_xy(np.array([rows[0], cols[0]]))

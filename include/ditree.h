@@ -18,8 +18,9 @@
  *     is enqueued asynchronously on it; nothing synchronises the device.
  *   - Return value: 0 = ok, negative = DITREE_E_*; ditree_last_error(ctx) gives text
  *     valid until the next call on that ctx.  No exceptions, no exit().
- *   - Layouts are the reference's: states (.., 6) f64 = x, y, psi, v, D, delta;
- *     actions (.., 2) f64 = dD, ddelta; mazes row-major (rows, cols) f32 in {0, 1}.
+ *   - Layouts are the reference's: car states (.., 6) f64 = x, y, psi, v, D, delta; car actions (.., 2) f64 = dD, ddelta;
+ *     ant states (.., 29) f64 = achieved_goal (x, y) | observation (z, qw, qx, qy, qz, 8 joints, 14 velocities)
+ *     (planners/base_planner.py:298), ant actions (.., 8); mazes row-major (rows, cols) f32 in {0, 1}.
  */
 #ifndef DITREE_H
 #define DITREE_H
@@ -30,7 +31,8 @@
 extern "C" {
 #endif
 
-#define DITREE_VERSION 300          /* 0.3.0: + denoise_status, build_id, mppi_step, expand_round_ant, path_after_obstacle */
+#define DITREE_VERSION 400          /* 0.4.0: runtime state / action width of the tree (car 6 / 2, ant 29 / 8), the ant round as a
+                                       real expansion round (collision, goal, accept), ant_rollout + stand-in model, row strides */
 
 #define DITREE_OK 0
 #define DITREE_E_ARG (-1)           /* bad argument (null pointer, size out of range) */
@@ -124,6 +126,66 @@ int32_t ditree_car_rollout(ditree_ctx* ctx, double* state_io, const double* acti
                            int32_t* steps_out, double* prev_action_io, uint8_t* has_prev_io,
                            void* stream);
 
+/* Where element (candidate b, row i, component k) of a per-candidate row block lives: base + b * cand + i * row + k * comp
+ * doubles.  Rows packed per candidate (the reference's arrays): {rows * width, width, 1}.  Step-major, component-major,
+ * candidate-minor -- {1, width * B, B} -- makes every store of a wavefront (64 consecutive candidates) one contiguous
+ * 512-byte run instead of 64 fragments at a stride of rows * width * 8 bytes; what the large standalone rollouts use. */
+typedef struct { int64_t cand, row, comp; } ditree_strides;
+
+/* ditree_car_rollout with explicit layouts for the two row outputs (NULL = packed per candidate, i.e. ditree_car_rollout). */
+int32_t ditree_car_rollout_ld(ditree_ctx* ctx, double* state_io, const double* actions, int64_t act_stride,
+                              int32_t* status_io, int32_t B, int32_t A, const double* goal_xy /*[host] 2*/,
+                              double* states_out, const ditree_strides* states_ld, double* actions_out,
+                              const ditree_strides* actions_ld, int32_t* steps_out, double* prev_action_io,
+                              uint8_t* has_prev_io, void* stream);
+
+/* ------------------------------------------------------------------ ant: collision glue, stand-in dynamics, rollout */
+
+/* common/map_utils.py:126-136 is_colliding_ant(state, maze, ant_radius, map_scale) as planners/base_planner.py:154-155 calls
+ * it (1.2, s_global): upside down when R[2][2] = 1 - 2 (qx^2 + qy^2) < 0 with (qw, qx, qy, qz) = state[3:7]
+ * (common/se3_utils.py:155-164), else the single-ball is_colliding_maze (common/map_utils.py:139-219: out of the map ->
+ * collision; side walls when the ball crosses the cell's edge, beyond the map counting as a wall; corner cells when closer
+ * than the radius, cells outside the map skipped) on the uploaded maze.
+ *   state [dev] (B, stride >= 7) f64; out [dev] (B,) u8. */
+int32_t ditree_ant_collision(ditree_ctx* ctx, const double* state, int32_t stride, int32_t B, double ball_radius,
+                             double s_global, uint8_t* out, void* stream);
+
+/* The ant's env step is MuJoCo 3.1.6 behind gymnasium-robotics 1.3.1 AntMaze_Large-v4 (requirements.txt:59,117; call sites
+ * planners/base_planner.py:278-279,290): third party, not in the reference repository, no oracle -- NOT implemented.
+ * What stands in for it in the higher-DoF rollout slot, PARITY UNPINNED BY CONSTRUCTION and labelled so wherever it runs:
+ * this build's own surrogate of a four-legged crawler with the ant's interface (29-d observation, 8-d action clipped to
+ * [-1, 1], frame_skip sub-steps of h seconds): per leg a hip and an ankle as damped second-order actuators with soft stops;
+ * a loaded foot (load = (1 + tanh(contact_gain (ankle - ank_rest))) / 2) swept by its hip pushes the torso the other way
+ * (planar force + yaw torque); uneven foot lift tilts the torso against an uprighting torque; the height follows the mean
+ * lift; the quaternion integrates the body angular velocity and is re-normalised.  Defined by DESIGN.md and restated in
+ * numpy as oracle/ant.py ant_model_step (tests hold the kernel to it at 1e-9). */
+typedef struct {
+  double h;                          /* integration step [s] (0.01) */
+  double frame_skip;                 /* sub-steps per env step (5) */
+  double k_act, k_spr, k_dmp, k_lim; /* actuator gain, joint spring, joint damping, soft-stop stiffness */
+  double hip_lim, ank_lo, ank_hi, ank_rest;
+  double contact_gain, leg_r, k_push, c_lin;
+  double z0, z_gain, k_z, c_z;
+  double k_lift, c_ang, k_up, k_yaw;
+  double cphi, sphi;                 /* cos / sin of the first leg's mount angle (the others by symmetry) */
+} ditree_ant_model;
+
+/* planners/base_planner.py:257-320 for B ant candidates: A env steps, after each the goal test
+ * ||obs[:2] - desired_goal|| < goal_radius (:296-297, goal_radius = 0.45 * s_global) and check_collision (:154-155,306;
+ * ditree_ant_collision); collision wins, on goal the remaining action rows are zeroed (:315), unexecuted state rows stay 0.
+ * The env step itself is `model` (the stand-in above) when model != NULL, else row i of next_obs_tape (test / measurement
+ * infrastructure: the observation after every env step given from outside; with the real simulator the caller steps it on
+ * the host between ditree_ant_chunk_sample and ditree_ant_chunk_step).
+ *   state_io [dev] (B, 29) f64 in: chunk start, out: `obs`; actions [dev] (B, act_stride) f64 rows of 8;
+ *   next_obs_tape [dev] (B, tape_stride) f64 rows of 29 or NULL; status_io as ditree_car_rollout;
+ *   states_out [dev] A + 1 rows of 29 per candidate, actions_out [dev] A rows of 8, laid out by states_ld / actions_ld
+ *   (NULL = packed per candidate); steps_out [dev] (B,) i32. */
+int32_t ditree_ant_rollout(ditree_ctx* ctx, const ditree_ant_model* model, double* state_io, const double* actions,
+                           int64_t act_stride, const double* next_obs_tape, int64_t tape_stride, int32_t* status_io,
+                           int32_t B, int32_t A, const double* desired_goal_xy /*[host] 2*/, double goal_radius,
+                           double ball_radius, double s_global, double* states_out, const ditree_strides* states_ld,
+                           double* actions_out, const ditree_strides* actions_ld, int32_t* steps_out, void* stream);
+
 /* lidar_sim/lidar_2d_sim.py:18-98 Lidar2DSim.scan for B poses (pose = x_col, y_row, yaw
  * in cell units) against `maze` [dev] (rows, cols) f32 (the *true* world, which may
  * differ from the uploaded known maze).  181 rays, arange(-180, 182, 2) degrees.
@@ -139,6 +201,7 @@ int32_t ditree_lidar_scan(ditree_ctx* ctx, const double* poses, int32_t B, const
 typedef struct {
   int32_t capacity;          /* node slots */
   int32_t n_chunks, A;       /* edge_length / action_horizon, action_horizon */
+  int32_t state_dim, action_dim;   /* S, D: 6 / 2 (car), 29 / 8 (ant); every "(.., 6)" / "(.., 2)" below reads (.., S) / (.., D) */
   double* state;             /* (cap, 6) */
   double* xy;                /* (cap, 2)  copy of state[:, :2] for the NN scan */
   int32_t* parent;           /* (cap,) */
@@ -152,6 +215,10 @@ typedef struct {
   uint8_t* obstacle_ahead;   /* (cap,) or NULL: planners/RRT.py:61-81 flag of every appended node (run_type > 0) */
   int32_t* edge_owner;       /* (cap,) or NULL: rank that holds the node's edge rows (sharded rounds keep the trajectories
                                 on the producing rank); -1 = every rank (root, frozen-env edges) */
+  double* hist;              /* (cap, 3, S) or NULL: the last <= 3 rows of the node's filtered edge states, valid rows at the
+                                END -- what the first sampler call of a child sees with obs_history 3 (planners/RRT.py:146-147,
+                                policies/fm_policy.py:96-102; the ant).  Replicated on every rank (it travels in the record). */
+  int32_t* hist_n;           /* (cap,) valid rows of hist (root: 1 = the start state) */
   int32_t* counters;         /* [0] n_nodes, [1] goal node (-1 none), [2] env.done latched
                                 (car_env.py:254,266 "sticky done"), [3] chunk iterations,
                                 [4] candidates processed, [5] sticky-done triggered */
@@ -176,16 +243,21 @@ typedef struct {
   double* first_action;      /* (B, 2) or NULL: actions[b, 0, 0, :] (the frozen-env edge of the sticky-done emulation) */
   int32_t own_lo, own_n;
   int32_t shard;             /* candidates per rank: owner of candidate b = b / shard (0 = single rank) */
+  double* hist;              /* (B, 3, S) or NULL: trees with `hist`, sharded rounds: the exchanged end-of-edge history */
+  int32_t* hist_n;           /* (B,) */
 } ditree_round;
 
-/* Candidate record exchanged between ranks once per round: 12 doubles = 96 bytes,
- * [end_state 6 | last_action 2 | first_action 2 | (parent, status) as two i32 | (chunks_run, 0) as two i32].
- * Edge trajectories stay on the producing rank.  pack: rows of `round` (this rank's slice) -> records_out (round->B, 12);
- * unpack: records (B, 12) of ALL candidates -> parent / status / chunks_run / end_state / last_action / first_action. */
-#define DITREE_RECORD_DOUBLES 12
+/* Candidate record exchanged between ranks once per round: S + 2 D + 2 doubles -- car: 12 = 96 bytes --
+ * [end_state S | last_action D | first_action D | (parent, status) as two i32 | (chunks_run, hist_n) as two i32], followed by
+ * [hist 3 S] for trees with `hist` (ant: 29 + 16 + 2 + 87 = 134 doubles).  ditree_record_doubles gives the count.
+ * Edge trajectories stay on the producing rank.  pack: rows of `round` (this rank's slice) -> records_out (round->B, R);
+ * unpack: records (B, R) of ALL candidates -> parent / status / chunks_run / end_state / last_action / first_action [/ hist]. */
+#define DITREE_RECORD_DOUBLES 12    /* the car's record */
+int32_t ditree_record_doubles(const ditree_tree* tree);
 int32_t ditree_round_pack(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round, double* records_out,
                           void* stream);
-int32_t ditree_round_unpack(ditree_ctx* ctx, const ditree_round* round, const double* records, void* stream);
+int32_t ditree_round_unpack(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round, const double* records,
+                            void* stream);
 
 /* The per-round exchange for hosts without torch.distributed: an RCCL communicator inside the ctx (librccl is opened at
  * run time; one process per GPU, ranks of ONE node over xGMI).
@@ -410,39 +482,63 @@ int32_t ditree_chunk_budget(ditree_ctx* ctx, const ditree_tree* tree, const doub
 int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
                             const ditree_round_params* p, void* stream);
 
-/* The chunk loop of planners/RRT.py:157-194 for the ANT (cfgs/antmaze.yaml: action_horizon 2, edge length 48 = 24 chunks,
- * pred_horizon 16, obs_history 3; run_scenarios.py:123-132) WITHOUT its physics: the env step is MuJoCo through
- * gymnasium-robotics (planners/base_planner.py:81-92,278-298), which has no oracle in this build and is NOT implemented.
- * What is: per chunk [create_local_map at the chunk's start state (stride-29 observations, 16 x 16 @ 0.8, s_global 4) ->
- * ant conditioning vector incl. quaternion -> rot6d and the 3-step history (policies/fm_policy.py:77-143) -> denoiser
- * (input_dim 8) -> un-normalised 8-d actions, the first action_horizon rows kept], with `prev_states = curr_states_seq` and
- * `prev_actions = curr_action_seq` (RRT.py:186-188) carried on the device.  The observations after every env step come
- * from `next_obs_tape` -- test / measurement infrastructure, the ant analogue of ditree_round_params.inject_actions.
- * The loaded denoiser must be the ant network (action_dim 8, cond 97).  No collision / goal tests (they need the physics):
- * every candidate runs all chunks. */
+/* One expansion round of the ANT (BASELINE config 3; cfgs/antmaze.yaml + run_scenarios.py:123-132: action_horizon 2, edge
+ * length 48 = 24 chunks, pred_horizon 16, obs_history 3, local map 16 x 16 @ 0.8, s_global 4) against a tree with state_dim
+ * 29, action_dim 8 and `hist`: planners/RRT.py:131-194 batched --
+ *   nearest node (RRT.py:49-51) -> its state, last action and the last <= 3 rows of its edge (RRT.py:144-147) ->
+ *   n_chunks x [create_local_map at (state[0], state[1], state[2]) (RRT.py:158-166: element 2 -- the torso height -- is what
+ *   the reference passes as the rotation) -> ant conditioning vector (policies/fm_policy.py:77-143: normalise, quaternion ->
+ *   rot6d of the normalised values, 3-step history, previous action, tanh of the goal offset with yaw 0) -> denoiser (input_dim 8)
+ *   -> the first A un-normalised actions -> A env steps with goal + collision test (ditree_ant_rollout) ->
+ *   prev_states = curr_states_seq, prev_actions = curr_action_seq (RRT.py:186-190)].
+ * Fills `round` (status / chunks_run / chunk_steps / states (B, n_chunks, A + 1, 29) / actions (B, n_chunks, A, 8) /
+ * end_state); ditree_accept then appends the nodes (emulate_sticky = 0: the ant env has no latched `done`).
+ * THE ENV STEP (MuJoCo, not in the reference repository, no oracle) is one of:
+ *   DITREE_ANT_DYN_TAPE   next_obs_tape (B, n_chunks, A, 29): observations given from outside (tests, measurement);
+ *   DITREE_ANT_DYN_MODEL  the build's stand-in model (ditree_ant_model; parity unpinned, not MuJoCo);
+ *   the caller's own simulator, one chunk at a time: ditree_ant_round_begin, then per chunk ditree_ant_chunk_sample (actions of
+ *   the chunk -> round->actions[:, j], start states in round->end_state), the host steps its env, ditree_ant_chunk_step with
+ *   the observations.  ditree_expand_round_ant is exactly that sequence with the tape / model in the middle. */
+#define DITREE_ANT_DYN_TAPE 0
+#define DITREE_ANT_DYN_MODEL 1
 typedef struct {
-  const double* obs_hist;        /* [dev] (B, n_hist, 29): states the first sampler call sees (parent edge's last rows) */
-  int32_t n_hist;                /* 1..3 */
-  const double* prev_action;     /* [dev] (B, 8) last action of the parent edge */
-  const uint8_t* has_prev;       /* [dev] (B,) */
+  int32_t n_nodes;               /* tree size to search */
+  const double* samples;         /* [dev] (B, 29): columns 0, 1 used (the KD-tree is over x, y, RRT.py:23,50) */
   const double* cond_goal;       /* [dev] (B, 2) */
-  const float* noise;            /* [dev] (B, n_chunks, P, 8) f32 */
-  const double* next_obs_tape;   /* [dev] (B, n_chunks, A, 29) f64: the observation after every env step */
-  int32_t n_chunks, A;           /* edge_length / action_horizon, action_horizon (>= 2) */
+  const float* noise;            /* [dev] (B, n_chunks, P, 8) f32, or NULL with inject_actions */
+  const double* inject_actions;  /* [dev] (B, n_chunks, P, 8) f64 or NULL: bypass the denoiser (tests: action tapes) */
+  int32_t P;                     /* pred_horizon (16) */
   int32_t K;                     /* flow steps */
   const float* t0;               /* [host] K */
   const float* dt;               /* [host] K */
-  const double* norm;            /* [host] 70: obs_mean[27], obs_std[27], act_mean[8], act_std[8] (ditree_cond_vector_ant) */
-  const double* act_norm;        /* [host] 16: act_mean[8], act_std[8] of the un-normalisation */
+  const double* norm;            /* [host] 70: obs_mean[27], obs_std[27], act_mean[8], act_std[8] (metadata/antmaze.pt) */
+  const double* desired_goal;    /* [host] 2: obs['desired_goal'] of the env (base_planner.py:296) */
+  double goal_radius;            /* 0.45 * s_global */
+  double ball_radius;            /* 1.2 (base_planner.py:155) */
   const double* axis;            /* [host] local-map axis, lm_n doubles */
   int32_t lm_n;                  /* local_map_size (16) */
   double lm_size;                /* divisor of the goal conditioning */
   double s_global;               /* 4 */
+  int32_t dynamics;              /* DITREE_ANT_DYN_* (ditree_expand_round_ant only) */
+  const double* next_obs_tape;   /* [dev] (B, n_chunks, A, 29) f64 for DITREE_ANT_DYN_TAPE */
+  const ditree_ant_model* model; /* [host] for DITREE_ANT_DYN_MODEL */
+  int32_t early_exit;            /* != 0: later chunks run on the still-alive candidates only (RRT.py:179-184) */
+  float* cond_out;               /* [dev] (B, n_chunks, 97) f32 or NULL: the conditioning vector of every sampler call (tests) */
 } ditree_ant_round_params;
-/* actions_out [dev] (B, n_chunks, A, 8) f64; end_obs [dev] (B, 29) or NULL; cond_out [dev] (B, n_chunks, 97) f32 or NULL (the
- * conditioning vector of every sampler call, for tests). */
-int32_t ditree_expand_round_ant(ditree_ctx* ctx, const ditree_ant_round_params* p, int32_t B, double* actions_out,
-                                double* end_obs, float* cond_out, void* stream);
+int32_t ditree_expand_round_ant(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
+                                const ditree_ant_round_params* p, void* stream);
+/* The same round with the caller's simulator between the two halves of a chunk (j = 0 .. n_chunks - 1, in order):
+ *   begin:  status / counters reset, nearest node, parent state -> round->end_state, history + previous action -> ctx;
+ *   sample: local map, conditioning, denoiser for the candidates that are still alive; round->actions[:, j] <- the A actions;
+ *   step:   next_obs [dev] (B, A, 29) f64 = the observation after each of the A env steps from round->end_state[b] with
+ *           round->actions[b, j] (rows of candidates that are not alive are ignored; a candidate that collides or reaches the
+ *           goal at step i ignores the rows after i) -> tests, round->states[:, j], status, history for the next chunk. */
+int32_t ditree_ant_round_begin(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
+                               const ditree_ant_round_params* p, void* stream);
+int32_t ditree_ant_chunk_sample(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
+                                const ditree_ant_round_params* p, int32_t j, void* stream);
+int32_t ditree_ant_chunk_step(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
+                              const ditree_ant_round_params* p, int32_t j, const double* next_obs, void* stream);
 
 #ifdef __cplusplus
 }

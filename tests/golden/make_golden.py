@@ -878,6 +878,250 @@ def gen_online(out):
           "oracle == reference")
 
 
+# --------------------------------------------------------------------------- ant (BASELINE config 3): glue pinned by the reference
+def ant_poses(rng, maze, n, sg):
+    """Poses for is_colliding_ant: uniform over the scaled map (+ a margin outside), a third snapped onto cell boundaries /
+    exactly one ball radius (1.2) or the corner distance from them, quaternions upright, tilted past 90 deg, and random."""
+    H, W = maze.shape
+    s = np.zeros((n, 29))
+    s[:, 0] = rng.uniform(-W / 2 * sg - 2, W / 2 * sg + 2, n)
+    s[:, 1] = rng.uniform(-H / 2 * sg - 2, H / 2 * sg + 2, n)
+    nb = n // 4
+    off = [0.0, 1e-12, -1e-12, 1.2, -1.2, 1.2 + 1e-12, -1.2 - 1e-12, 1.2 - 1e-12, 0.8, -0.8, 2.0, -2.0]
+    s[:nb, 0] = np.round(s[:nb, 0] / sg * 2) / 2 * sg + rng.choice(off, nb)
+    s[nb:2 * nb, 1] = np.round(s[nb:2 * nb, 1] / sg * 2) / 2 * sg + rng.choice(off, nb)
+    # near cell corners: the diagonal test (map_utils.py:202-215)
+    k = slice(2 * nb, 3 * nb)
+    ang = rng.uniform(0, 2 * np.pi, nb)
+    rad = rng.choice([1.2, 1.2 - 1e-9, 1.2 + 1e-9, 0.9, 1.5], nb)
+    s[k, 0] = np.round(s[k, 0] / sg) * sg + rad * np.cos(ang)
+    s[k, 1] = np.round(s[k, 1] / sg) * sg + rad * np.sin(ang)
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    up = rng.random(n) < 0.6
+    q[up] = np.array([1.0, 0, 0, 0]) + rng.normal(0, 0.25, (int(up.sum()), 4))
+    edge = rng.random(n) < 0.1                       # body z axis (almost) horizontal: 1 - 2 (qx^2 + qy^2) ~ 0
+    th = rng.uniform(0, 2 * np.pi, n)
+    q[edge, 0], q[edge, 3] = 0.0, np.sqrt(0.5)
+    q[edge, 1] = np.sqrt(0.5) * np.cos(th[edge]) + rng.choice([0.0, 1e-9, -1e-9], int(edge.sum()))
+    q[edge, 2] = np.sqrt(0.5) * np.sin(th[edge])
+    s[:, 3:7] = q
+    s[:, 2] = rng.uniform(0.3, 0.9, n)
+    s[:, 7:] = rng.normal(0, 1, (n, 22))
+    s[-3:, 0] = [np.nan, np.inf, -np.inf]            # NaN / inf positions: floor().astype(int) -> out of the map
+    return s
+
+
+def gen_ant_collision(out):
+    """The reference's own is_colliding_ant(state, maze, 1.2, s_global) (common/map_utils.py:126-219, called at
+    planners/base_planner.py:154-155) and goal test (:296-297) on 4096 states x 4 mazes; oracle == reference asserted."""
+    from oracle import ant as OA
+    rng = np.random.default_rng(401)
+    sg = 4.0
+    for name in ("Race_Track", "boxes", "random_huge", "narrow_short"):
+        maze = load_maze(name)
+        st = ant_poses(rng, maze, 4096, sg)
+        with np.errstate(invalid="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                exp = np.array([bool(ref_mu.is_colliding_ant(s, maze, 1.2, sg)) for s in st])
+        mine = OA.is_colliding_ant(st, maze, 1.2, sg)
+        assert (exp == mine).all(), f"ant collision mismatch on {name}: {np.nonzero(exp != mine)[0][:10]}"
+        out[f"antcol_{name}_states"] = st[:, :7].copy()
+        out[f"antcol_{name}_expected"] = exp
+        print(f"ant collision {name}: {exp.mean():.3f} colliding ({int((OA.body_z_up(st[:, 3:7]) < 0).sum())} upside down), oracle == reference")
+    # a unit-scale call (ball_radius 0.1 defaults are the point-maze's; the engine takes both as parameters)
+    maze = load_maze("boxes")
+    st = ant_poses(rng, maze, 1024, 1.0)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = np.array([bool(ref_mu.is_colliding_ant(s, maze, 0.3, 1.0)) for s in st])
+    assert (exp == OA.is_colliding_ant(st, maze, 0.3, 1.0)).all()
+    out["antcol_unit_states"], out["antcol_unit_expected"] = st[:, :7].copy(), exp
+
+
+class _AntMazeData:
+    """What planners/base_planner.py:81-92 reads from ``env.maze_data`` (gymnasium-robotics ``Maze``: map_length = rows,
+    map_width = cols, centres already multiplied by maze_size_scaling)."""
+
+    def __init__(self, maze, s):
+        self.maze_map = np.asarray(maze)
+        self.maze_size_scaling = s
+        self.map_length, self.map_width = self.maze_map.shape
+        self.x_map_center = self.map_width / 2 * s
+        self.y_map_center = self.map_length / 2 * s
+
+    def cell_xy_to_rowcol(self, xy):
+        i = np.floor((self.y_map_center - xy[1]) / self.maze_size_scaling)
+        j = np.floor((xy[0] + self.x_map_center) / self.maze_size_scaling)
+        return np.array([i, j])
+
+    def cell_rowcol_to_xy(self, rc):
+        return np.array([(rc[1] + 0.5) * self.maze_size_scaling - self.x_map_center,
+                         self.y_map_center - (rc[0] + 0.5) * self.maze_size_scaling])
+
+
+class _AntEnvStandIn:
+    """The surface of the gym AntMaze env the reference planner touches (planners/base_planner.py:81-92,278-298;
+    planners/RRT.py:30,122 also read ``prob_map`` / set ``run_type``), with the MuJoCo step replaced by ``step_fn`` -- the
+    tape or the build's surrogate model (oracle/ant.py).  Generation-time scaffolding: the REFERENCE's planner code runs on it."""
+
+    def __init__(self, maze, s_global, desired_xy, step_fn, counter):
+        self.maze_data = _AntMazeData(maze, s_global)
+        self.prob_map = np.zeros_like(np.asarray(maze, dtype=np.float64))
+        self.ant_env = self
+        self.desired = np.asarray(desired_xy, dtype=np.float64)
+        self.step_fn, self.counter = step_fn, counter
+        self.state = np.zeros(29)
+        self.chunk, self.i, self.last_cand = -1, 0, -1
+
+    def reset(self, options=None, **kw):
+        return None, {}
+
+    def set_state(self, qpos, qvel):                        # base_planner.py:278-279: once per chunk
+        self.state = np.concatenate([qpos, qvel]).astype(np.float64)
+        cand = self.counter["cand"] - 1
+        if cand != self.last_cand:
+            self.chunk, self.last_cand = -1, cand
+        self.chunk += 1
+        self.i = 0
+
+    def step(self, action):
+        cand = self.counter["cand"] - 1
+        self.state = self.step_fn(np.array([cand]), self.chunk, self.i, self.state[None], np.asarray(action, dtype=np.float64)[None])[0]
+        self.i += 1
+        obs = {"achieved_goal": self.state[:2].copy(), "desired_goal": self.desired.copy(), "observation": self.state[2:].copy()}
+        return obs, 0.0, False, False, {}
+
+
+class _AntRecordingSampler(torch.nn.Module):
+    """Action tape + a record of what every sampler call was handed (RRT.py:146-147,168-171,186-190)."""
+
+    def __init__(self, tape, counter):
+        super().__init__()
+        self.tape, self.counter = tape, counter
+        self.chunk, self.last_cand = 0, -1
+        self.calls = []
+
+    def forward(self, prev_states, prev_actions=None, goal=None, local_map=None):
+        cand = self.counter["cand"] - 1
+        if cand != self.last_cand:
+            self.chunk, self.last_cand = 0, cand
+        ps = np.asarray(prev_states)
+        assert ps.ndim == 3 and ps.shape[0] == 1
+        h = ps[0, -3:]
+        hist = np.zeros((3, 29))
+        hist[3 - len(h):] = h
+        pa = np.zeros(8) if prev_actions is None else np.asarray(prev_actions)[-1]
+        self.calls.append(dict(cand=cand, chunk=self.chunk, hist=hist, n_hist=len(h), prev=pa, has_prev=prev_actions is not None and len(prev_actions) > 0,
+                               goal=np.asarray(goal, dtype=np.float64).copy(), lmap=np.asarray(local_map.cpu().numpy() if hasattr(local_map, "cpu") else local_map)[0].astype(np.uint8)))
+        a = self.tape.actions(np.array([cand]), self.chunk)
+        self.chunk += 1
+        return a
+
+
+def run_reference_ant_planner(maze_name, start_rc, goal_rc, n_candidates, seed, dynamics):
+    """The reference's RRT_Planner(env_id='antmaze') (planners/RRT.py:113-257 with base_planner.py's ant branches) on the
+    stand-in env; cfgs/antmaze.yaml + run_scenarios.py:123-132: action_horizon 2, prop_duration [48], pred_horizon 16,
+    local map 16 @ 0.8, s_global 4."""
+    from oracle import ant as OA
+    import random
+    maze = load_maze(maze_name)
+    sg, A, H, P = 4.0, 2, 48, 16
+    md = _AntMazeData(maze, sg)
+    start = np.zeros(29)
+    start[:2] = md.cell_rowcol_to_xy(np.array(start_rc))
+    start[2], start[3] = 0.75, 1.0                                   # run_scenarios.py:228-230
+    if dynamics == "model":
+        start[7:15] = np.tile([0.0, OA.AntModel.ank_rest], 4)
+    goal = np.zeros(29)
+    goal[:2] = md.cell_rowcol_to_xy(np.array(goal_rc))
+    desired = goal[:2] + np.array([0.3, -0.2])                       # the env's goal carries position noise
+    atape = OA.AntActionTape(seed, P)
+    if dynamics == "tape":
+        otape = OA.AntObsTape(seed + 1, maze, sg, H // A, A, desired_xy=desired, goal_every=29, step=0.12)
+        step_fn = otape.step_fn()
+    else:
+        step_fn = lambda cand, chunk, i, cur, act: OA.ant_model_step(cur, act)     # noqa: E731
+    counter = {"cand": 0}
+    env = _AntEnvStandIn(maze, sg, desired, step_fn, counter)
+    smp = _AntRecordingSampler(atape, counter)
+    random.seed(42)
+    np.random.seed(42)
+    planner = ref_rrt.RRT_Planner(start, goal, env_id="antmaze", environment=env, sampler=smp, prediction_type="actions",
+                                  action_horizon=A, local_map_size=16, local_map_scale=0.8, global_map_scale=sg,
+                                  goal_conditioning_bias=0.85, prop_duration=[H], time_budget=n_candidates, max_iter=300,
+                                  verbose=False)
+    planner.device = "cpu"
+    orig_nearest = planner.nearest_node
+
+    def counted_nearest(sample):
+        counter["cand"] += 1
+        return orig_nearest(sample)
+    planner.nearest_node = counted_nearest
+    real_time = ref_rrt.time.time
+    ref_rrt.time.time = lambda: float(counter["cand"])
+    try:
+        random.seed(42)
+        np.random.seed(42)
+        path, actions = planner.plan()
+    finally:
+        ref_rrt.time.time = real_time
+    parents, states = _tree_of(planner)
+    # the oracle planner, B = 1, same tapes
+    pl = OA.OracleAntPlanner(maze, start, goal, desired, atape.sampler(), step_fn, edge_length=H, action_horizon=A)
+    rec = []
+    inner = pl.sampler
+
+    def rec_sampler(cand_idx, chunk, hist, prev_a, has_prev, cond_goal, lm):
+        for k, c in enumerate(cand_idx):
+            rec.append((int(c), chunk, hist[k], prev_a[k], bool(has_prev[k]), cond_goal[k], lm[k]))
+        return inner(cand_idx, chunk, hist, prev_a, has_prev, cond_goal, lm)
+    pl.sampler = rec_sampler
+    reached, opath, oactions = pl.plan(ORRT.RandomTape(42), counter["cand"], batch=1)
+    assert np.array_equal(parents, np.array(pl.parents)), "ant trace: parents differ"
+    assert np.array_equal(states, np.array(pl.states)), "ant trace: node states differ"
+    assert planner.results["iterations"] == pl.iterations, (planner.results["iterations"], pl.iterations)
+    assert (path is None) == (opath is None) and (path is None or (np.array_equal(path, opath) and np.array_equal(actions, oactions)))
+    assert len(rec) == len(smp.calls)
+    for (c, j, hist, pa, hp, g, lm), call in zip(rec, smp.calls):
+        assert (c, j) == (call["cand"], call["chunk"]) and len(hist) == call["n_hist"] and hp == call["has_prev"]
+        assert np.array_equal(hist, call["hist"][3 - call["n_hist"]:]) and np.array_equal(g, call["goal"])
+        assert (not hp) or np.array_equal(pa, call["prev"])
+        assert np.array_equal(lm.astype(np.uint8), call["lmap"])
+    goal_idx = None if not reached else pl.goal_node
+    return dict(maze_name=maze_name, start=start, goal=goal, desired=desired, seed=seed, parents=parents, states=states,
+                reached=bool(reached), path=path, actions=actions, iterations=planner.results["iterations"],
+                candidates=counter["cand"], calls=smp.calls, goal_node=-1 if goal_idx is None else goal_idx)
+
+
+def gen_ant_traces(out):
+    cases = [("tape_boxes", "boxes", (17, 2), (2, 17), 260, 11, "tape"),
+             ("tape_xlarge", "random_xlarge", (1, 1), (3, 7), 260, 12, "tape"),
+             ("tape_val7", "val_maze_7", (1, 5), (5, 3), 200, 13, "tape"),
+             ("model_boxes", "boxes", (17, 2), (2, 17), 160, 14, "model"),
+             ("model_val7", "val_maze_7", (1, 5), (5, 3), 160, 15, "model")]
+    for tag, maze_name, s_rc, g_rc, n, seed, dyn in cases:
+        r = run_reference_ant_planner(maze_name, s_rc, g_rc, n, seed, dyn)
+        pre = f"anttrace_{tag}_"
+        for k in ("start", "goal", "desired", "parents", "states"):
+            out[pre + k] = r[k]
+        out[pre + "maze"] = load_maze(maze_name)
+        out[pre + "meta"] = np.array([r["seed"], r["candidates"], r["iterations"], int(r["reached"]), r["goal_node"], 1 if dyn == "model" else 0])
+        out[pre + "path"] = np.zeros((0, 29), np.float32) if r["path"] is None else r["path"]
+        out[pre + "actions"] = np.zeros((0, 8), np.float32) if r["actions"] is None else r["actions"]
+        calls = r["calls"][:1500]                       # what the first sampler calls were handed
+        out[pre + "call_key"] = np.array([[c["cand"], c["chunk"], c["n_hist"], int(c["has_prev"])] for c in calls], dtype=np.int32)
+        out[pre + "call_hist"] = np.array([c["hist"] for c in calls])
+        out[pre + "call_prev"] = np.array([c["prev"] for c in calls])
+        out[pre + "call_goal"] = np.array([c["goal"] for c in calls])
+        out[pre + "call_lmap"] = np.packbits(np.array([c["lmap"] for c in calls]), axis=None)
+        print(f"ant trace {tag}: {r['candidates']} candidates, {len(r['parents'])} nodes, {r['iterations']} chunk iterations, "
+              f"reached {r['reached']}, {len(r['calls'])} sampler calls -- oracle == reference planner")
+
+
 def main():
     if sys.argv[1:] == ["probmaps"]:          # quick check of the run_type >= 2 pieces only (writes nothing)
         gen_prob_maps({})
@@ -887,6 +1131,12 @@ def main():
         net = dict(np.load(os.path.join(HERE, "network.npz"), allow_pickle=False))
         gen_sampler_ant(net)
         np.savez_compressed(os.path.join(HERE, "network.npz"), **net)
+        return
+    if sys.argv[1:] == ["antglue"]:           # ant collision / goal / planner-trace fixtures -> ant.npz
+        ant = {}
+        gen_ant_collision(ant)
+        gen_ant_traces(ant)
+        np.savez_compressed(os.path.join(HERE, "ant.npz"), **ant)
         return
     if sys.argv[1:] == ["dyntext"]:           # add the source-text dynamics vectors to geometry.npz (other entries kept)
         geo = dict(np.load(os.path.join(HERE, "geometry.npz"), allow_pickle=False))
@@ -925,6 +1175,10 @@ def main():
     online = {}
     gen_online(online)
     np.savez_compressed(os.path.join(HERE, "online.npz"), **online)
+    ant = {}
+    gen_ant_collision(ant)
+    gen_ant_traces(ant)
+    np.savez_compressed(os.path.join(HERE, "ant.npz"), **ant)
     with open(os.path.join(HERE, "timesteps.json"), "w") as f:
         json.dump(meta, f, indent=1)
     print("wrote golden fixtures to", HERE)

@@ -14,7 +14,7 @@ def test_header_symbols_exported():
     h = _lib.lib()
     for name in declared:
         assert hasattr(h, name), name
-    assert h.ditree_version() == 300
+    assert h.ditree_version() == 400
 
 
 def test_no_oracle_import_in_product():

@@ -1,7 +1,7 @@
 """BASELINE config 3 (cfgs/antmaze.yaml + fm_policy): the ant-sized denoiser and its glue on the GPU.
 
 The ant's DYNAMICS (MuJoCo through gymnasium-robotics) have no oracle here and are not built; everything
-around them is: sampler pre-processing incl. quaternion -> rot6d (policies/fm_policy.py:77-82, common/se3_utils.py:177-189),
+around them is (the round itself: tests/test_gpu_ant_round.py): sampler pre-processing incl. quaternion -> rot6d (policies/fm_policy.py:77-82, common/se3_utils.py:177-189),
 the 16 x 16 @ 0.8 local map with s_global = 4 (run_scenarios.py:123-132; tests/test_gpu_geometry.py), and the denoiser at
 input_dim 8, pred_horizon 16, cond 97 (+ 400).  The oracle's U-Net at these dimensions is bit-identical to the reference class
 (golden `unet_ant_*`, tests/test_oracle_golden.py); its sampler pre-processing equals the reference on the `sampler_ant_*` cases."""
@@ -189,122 +189,4 @@ def test_ant_sampler_facade(ctx, ant_net):
     assert np.abs(a - a_ref).max() < 1e-4, np.abs(a - a_ref).max()
 
 
-# ------------------------------------------------------------------------------------------ the ant ROUND without physics
-def _ant_round_inputs(B, n_chunks, A, n_hist, seed=31):
-    """Synthetic but shaped like the real thing: unit quaternions, positions inside boxes.csv scaled by s_global = 4, a
-    next-observation tape that drifts (so local maps and conditioning change from chunk to chunk)."""
-    from tests.util import load_maze
-    rng = np.random.default_rng(seed)
-    maze = load_maze("boxes")
-    Hh, W = maze.shape
-    free = np.argwhere(maze[1:-1, 1:-1] == 0) + 1
-    cell = free[rng.integers(0, len(free), B)]
-
-    def obs_rows(n, base_xy):
-        o = rng.normal(0.0, 1.0, (B, n, 29))
-        o[..., 0] = base_xy[:, None, 0] + np.cumsum(rng.normal(0.0, 0.15, (B, n)), axis=1)
-        o[..., 1] = base_xy[:, None, 1] + np.cumsum(rng.normal(0.0, 0.15, (B, n)), axis=1)
-        o[..., 2] = rng.uniform(0.4, 0.8, (B, n))
-        q = rng.normal(size=(B, n, 4))
-        o[..., 3:7] = q / np.linalg.norm(q, axis=-1, keepdims=True)
-        return o
-    xy0 = np.stack([((cell[:, 1] + 0.5) - W / 2) * 4.0, (Hh / 2 - (cell[:, 0] + 0.5)) * 4.0], axis=1)
-    hist = obs_rows(n_hist, xy0)
-    tape = obs_rows(n_chunks * A, hist[:, -1, :2]).reshape(B, n_chunks, A, 29)
-    prev = rng.uniform(-1, 1, (B, 8))
-    has_prev = (rng.random(B) < 0.8)
-    goal = rng.uniform(-30, 30, (B, 2))
-    g = torch.Generator().manual_seed(seed)
-    noise = torch.randn(B, n_chunks, 16, 8, generator=g)
-    return maze, hist, tape, prev, has_prev, goal, noise
-
-
-def _oracle_ant_round(net, maze, hist, tape, prev, has_prev, goal, noise, act_mean, act_std):
-    """planners/RRT.py:157-194 for the ant with the MuJoCo step replaced by the tape: per chunk create_local_map (16 x 16 @ 0.8,
-    s_global 4, centre scaled), the reference's conditioning vector, the oracle network, the first A un-normalised actions;
-    prev_states = the chunk's A + 1 states, prev_actions = its action rows."""
-    from oracle import geometry as G
-    B, nC, A = tape.shape[:3]
-    meta = dict(OS.ANT_META)
-    states = hist.copy()                                  # (B, h, 29) what the sampler sees
-    pa, hp = prev.copy(), has_prev.copy()
-    acts = np.zeros((B, nC, A, 8))
-    conds = np.zeros((B, nC, 97), dtype=np.float32)
-    center = G.map_center(maze, 4.0)
-    for j in range(nC):
-        cur = states[:, -1]
-        lm = G.create_local_map(maze, cur[:, 0], cur[:, 1], cur[:, 2], 16, 0.8, 4.0, center)
-        cv = OS.ant_cond_vector(states, pa, hp, goal, local_map_size=16, meta=meta)
-        conds[:, j] = cv
-        x = OS.flow_sample(net, noise[:, j].numpy(), OS.scale_local_map(lm), cv, k_steps=1)
-        a = x.astype(np.float64) * act_std + act_mean
-        acts[:, j] = a[:, :A]
-        states = np.concatenate([cur[:, None], tape[:, j]], axis=1)            # curr_states_seq: A + 1 rows
-        pa, hp = a[:, A - 1].copy(), np.ones(B, dtype=bool)
-    return acts, conds, states[:, -1]
-
-
-@pytest.mark.parametrize("n_hist", [1, 3])
-def test_ant_round_sequencing_against_oracle(ctx, ant_net, n_hist):
-    """20 candidates x 24 chunks of A = 2 (cfgs/antmaze.yaml): history carry-over, previous action, stride-29 local maps,
-    8-d un-normalisation with non-trivial statistics -- against the oracle driven by the same next-observation tape."""
-    B, nC, A = 20, 24, 2
-    maze, hist, tape, prev, has_prev, goal, noise = _ant_round_inputs(B, nC, A, n_hist)
-    rng = np.random.default_rng(9)
-    act_mean, act_std = rng.normal(0, 0.3, 8), rng.uniform(0.6, 1.5, 8)
-    norm = ant_norm()
-    norm[54:62], norm[62:70] = act_mean, act_std
-    meta_backup = {k: v.copy() for k, v in OS.ANT_META.items()}
-    OS.ANT_META["Actions_mean"], OS.ANT_META["Actions_std"] = act_mean, act_std
-    try:
-        a_ref, c_ref, end_ref = _oracle_ant_round(ant_net, maze, hist, tape, prev, has_prev, goal, noise, act_mean, act_std)
-    finally:
-        OS.ANT_META.update(meta_backup)
-    ctx.upload_maze(maze)
-    for prec, tol in ((1, 2e-5), (2, 2e-5)):
-        _ant_bind(ctx, ant_net, prec, B)
-        a, end_obs, cond = ctx.expand_round_ant(dev(hist), dev(prev), dev(has_prev.astype(np.uint8)), dev(goal), noise.cuda(),
-                                                dev(tape), norm, want_cond=True)
-        a, cond = a.cpu().numpy(), cond.cpu().numpy()
-        assert np.array_equal(end_obs.cpu().numpy(), end_ref)
-        # chunk 0 sees only given inputs: conditioning to float32 rounding; later chunks carry the previous action computed by
-        # the network (its 1e-6 deviation passes through the normalisation)
-        assert np.abs(cond[:, 0] - c_ref[:, 0]).max() < 2e-6
-        assert np.abs(cond[:, :, :87] - c_ref[:, :, :87]).max() < 2e-6           # history slots: tape only, every chunk
-        assert np.abs(cond - c_ref).max() < 5e-5
-        r = float(np.linalg.norm(a - a_ref) / np.linalg.norm(a_ref))
-        assert r < tol, (prec, r)
-        assert np.abs(a - a_ref).max() < 50 * tol * np.abs(a_ref).max()
-
-
-def test_ant_round_full_size_properties(ctx, ant_net):
-    """BASELINE config 3's batch: 4096 candidates x 24 chunks through ditree_expand_round_ant (f16x3).  Size-independent
-    properties: rows are independent (a 32-row subset run alone gives the same rows bit for bit), the history really is
-    carried (a tape change in chunk 5 changes the actions of chunks >= 6 and only those), results are finite."""
-    B, nC, A = 4096, 24, 2
-    maze, hist, tape, prev, has_prev, goal, noise = _ant_round_inputs(B, nC, A, 3, seed=77)
-    norm = ant_norm()
-    ctx.upload_maze(maze)
-    _ant_bind(ctx, ant_net, 2, B)
-    args = lambda sl: (dev(hist[sl]), dev(prev[sl]), dev(has_prev[sl].astype(np.uint8)), dev(goal[sl]),      # noqa: E731
-                       noise[sl].contiguous().cuda(), dev(tape[sl]), norm)
-    a_full, end_full = ctx.expand_round_ant(*args(slice(None)))
-    a_full = a_full.cpu().numpy()
-    assert np.isfinite(a_full).all() and a_full.shape == (B, nC, A, 8)
-    rows = np.sort(np.random.default_rng(1).choice(B, 32, replace=False))
-    a_sub, _ = ctx.expand_round_ant(*args(rows))
-    assert np.array_equal(a_sub.cpu().numpy(), a_full[rows])
-    tape2 = tape.copy()
-    tape2[rows, 5] += 0.37
-    a_mod, _ = ctx.expand_round_ant(dev(hist[rows]), dev(prev[rows]), dev(has_prev[rows].astype(np.uint8)), dev(goal[rows]),
-                                    noise[rows].contiguous().cuda(), dev(tape2[rows]), norm)
-    a_mod = a_mod.cpu().numpy()
-    assert np.array_equal(a_mod[:, :6], a_full[rows][:, :6])
-    assert (np.abs(a_mod[:, 6:] - a_full[rows][:, 6:]).reshape(32, -1).max(axis=1) > 0).all()
-    # the car network is refused
-    from ditreeonlineplanner_amd.model import NoisePredNet
-    from ditreeonlineplanner_amd._lib import DitreeError
-    car = NoisePredNet(seed=0)
-    car.bind(ctx, precision=2, max_batch=64)
-    with pytest.raises((DitreeError, ValueError), match="not the ant network|noise must be"):
-        ctx.expand_round_ant(*args(slice(0, 8)))
+# The ant ROUND (tree, collision / goal tests, accept) is tests/test_gpu_ant_round.py.

@@ -244,9 +244,25 @@ def test_round3_entry_points_argument_and_call_order_errors(ctx):
     nxt, a, done = m.step(np.array([-8.5, -8.5, 0, 0, 0, 0.0]))
     assert done is False and np.isfinite(nxt).all()
     # the ant round without the ant network / with malformed inputs
+    from ditreeonlineplanner_amd.engine import AntExpansionEngine
     z = lambda *shape, dt=f64: torch.zeros(*shape, dtype=dt, device="cuda")      # noqa: E731
+    st = np.zeros(29)
+    st[2], st[3] = 0.75, 1.0
+    eng = AntExpansionEngine(ctx, maze, st, st, norm=np.ones(70), batch=4, capacity=64, edge_length=4, dynamics="tape")
     with pytest.raises(DitreeError, match="not loaded"):
-        ctx.expand_round_ant(z(4, 3, 29), z(4, 8), z(4, dt=torch.uint8), z(4, 2), z(4, 2, 16, 8, dt=torch.float32), z(4, 2, 2, 29), np.ones(70))
+        eng.expand_round(z(4, 29), z(4, 2), noise=z(4, 2, 16, 8, dt=torch.float32), next_obs_tape=z(4, 2, 2, 29))
+    with pytest.raises(ValueError, match="next_obs_tape"):
+        eng.expand_round(z(4, 29), z(4, 2), inject_actions=z(4, 2, 16, 8))
+    with pytest.raises(ValueError, match="samples must be"):
+        eng.expand_round(z(4, 6), z(4, 2), inject_actions=z(4, 2, 16, 8), next_obs_tape=z(4, 2, 2, 29))
+    # a car tree handed to the ant round, and the reverse
+    from ditreeonlineplanner_amd.engine import ExpansionEngine
+    car = ExpansionEngine(ctx, maze, np.zeros(6), np.zeros(6), batch=4, capacity=64)
+    rp, keep = eng._params(z(4, 29), z(4, 2), None, z(4, 2, 16, 8), 0, 4, z(4, 2, 2, 29))
+    with pytest.raises(DitreeError, match="state_dim 29"):
+        check(ctx._h, lib().ditree_expand_round_ant(ctx._h, C.byref(car.tree.desc), C.byref(car.rb.desc(0, 4)), C.byref(rp), ctx.stream), "x")
+    with pytest.raises(DitreeError, match="sticky-done"):
+        check(ctx._h, lib().ditree_accept(ctx._h, C.byref(eng.tree.desc), C.byref(eng.rb.desc(0, 4)), 1, ctx.stream), "x")
 
 
 def test_rounds_on_a_side_stream_equal_rounds_on_the_default_stream(ctx):
@@ -303,13 +319,23 @@ def test_round3_kernels_at_their_smallest_and_odd_sizes(ctx):
     one = dev(np.array([[-8.5, -8.5]], dtype=np.float32))
     check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, one.data_ptr(), 2, 1, (C.c_float * 2)(0.0, 0.0), out.data_ptr(), ctx.stream), "x")
     assert out.cpu().tolist() == [0, -1]
-    # a one-candidate, one-chunk ant round
+    # a one-candidate, one-chunk ant round from the root (1-row history), model and tape dynamics, action_horizon 1 and 2
+    from ditreeonlineplanner_amd.engine import AntExpansionEngine
     from ditreeonlineplanner_amd.model import NoisePredNet
     net = NoisePredNet(input_dim=8, additional_global_cond_dim=97, pred_horizon=16, local_map_size=16, seed=0)
     net.bind(ctx, precision=_lib.PREC_F16X3, max_batch=1)
     rng = np.random.default_rng(0)
-    hist = rng.normal(size=(1, 1, 29))
-    hist[..., 3:7] = np.array([0.0, 0.0, 0.0, 1.0])
-    a, end = ctx.expand_round_ant(dev(hist), dev(np.zeros((1, 8))), dev(np.zeros(1, dtype=np.uint8)), dev(np.zeros((1, 2))),
-                                  torch.randn(1, 1, 16, 8, device="cuda"), dev(rng.normal(size=(1, 1, 2, 29))), np.concatenate([np.zeros(27), np.ones(27), np.zeros(8), np.ones(8)]))
-    assert a.shape == (1, 1, 2, 8) and torch.isfinite(a).all() and end.shape == (1, 29)
+    st = np.zeros(29)
+    st[:2], st[2], st[3] = [-30.0, -30.0], 0.75, 1.0
+    norm = np.concatenate([np.zeros(27), np.ones(27), np.zeros(8), np.ones(8)])
+    for A, dyn in ((2, "model"), (1, "tape"), (3, "tape")):
+        eng = AntExpansionEngine(ctx, maze, st, st, norm=norm, batch=1, capacity=8, edge_length=A, action_horizon=A, dynamics=dyn)
+        obs = rng.normal(size=(1, 1, A, 29))
+        obs[..., :2] = [-30.0, -30.0]
+        obs[..., 3:7] = [1.0, 0, 0, 0]
+        cnt = eng.expand_round(dev(np.zeros((1, 29))), dev(np.zeros((1, 2))), noise=torch.randn(1, 1, 16, 8, device="cuda"),
+                               next_obs_tape=dev(obs) if dyn == "tape" else None)
+        assert int(cnt[0]) == 2 and torch.isfinite(eng.rb.actions).all() and eng.rb.actions.shape == (1, 1, A, 8)
+        n = min(3, A + 1)
+        assert int(eng.tree.hist_n[1]) == n
+        assert torch.equal(eng.tree.hist[1, 3 - n:], eng.tree.edge_states[1, A + 1 - n: A + 1])
