@@ -13,11 +13,14 @@ when N > 1).  Per-GPU batch is fixed (weak scaling); every candidate runs all 4 
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Other workloads of BASELINE.json's config list (each prints its own one-line JSON with `roofline`):
-    --workload rollout       config 5: 65 536 car rollouts x T = 16 steps, the rollout kernel alone (no denoiser)
+    --workload rollout       config 5: 65 536 car rollouts x T = 16 steps, the rollout kernel alone (no denoiser);
+                             --model ant: the higher-DoF rollout slot on the build's stand-in 29-state / 8-action model (NOT MuJoCo)
     --workload mppi          config 5: 65 536 MPPI rollouts (the build's own controller: costs, soft-min update, executed step),
                              sharded over --gpus N with two tiny all-reduces per controller step
     --workload lidar-round   config 4: a round of 8 192 candidates + one 181-ray lidar scan per candidate end pose
-    --workload ant-denoise   config 3: the ant-sized denoiser + glue, 4 096 candidates x 24 calls (dynamics blocked on an oracle)
+    --workload ant-round     config 3: a round of 4 096 ant candidates x H = 48 (24 chunks): ant-sized denoiser + glue + the reference's
+                             ant collision / goal tests + accept into the 29-d tree; the env step (MuJoCo in the reference, no oracle) is
+                             the build's stand-in model or a tape (--ant-dynamics), labelled in the line
     --workload geometry      the geometry kernels alone (NN, local map, cond vector, rollout chunk, lidar) with GB/s each
 """
 import argparse
@@ -194,7 +197,8 @@ def recorded_traffic(tag, precision=None, kernel=None):
     """`roofline.traffic` of the side workloads: HBM-side bytes per launch recorded by a separate rocprofv3 --pmc pass of the
     same command (profiles/run_profiles.sh; FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), committed under profiles/.  Counters
     cannot be read inside a timed run, so the field says "recorded" and names its file; null when no pass is committed."""
-    name = f"r03_{tag}" + (f"_{precision}" if precision else "") + "_pmc_traffic.json"
+    base = f"_{tag}" + (f"_{precision}" if precision else "") + "_pmc_traffic.json"
+    name = next((r + base for r in ("r04", "r03") if os.path.exists(os.path.join(REPO, "profiles", r + base))), "r04" + base)
     path = os.path.join(REPO, "profiles", name)
     try:
         with open(path) as f:
@@ -361,6 +365,84 @@ def run_rollout(args):
                             **recorded_traffic("rollout", kernel="car_rollout_kernel"), "kernel": "car_rollout_kernel", "avg_launch_ms": avg_ms,
                             "algorithmic_bytes_per_launch": alg,
                             "note": "FP64 transcendental-bound in practice (3 sincos + tanh + 9 sqrt/hypot per step): see DESIGN.md"},
+               "outcome": {"ok": int((st == 0).sum()), "goal": int((st == 1).sum()), "collided": int((st == 2).sum())}, **comm}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_rollout_ant(args):
+    """The higher-DoF dynamics slot (BASELINE configs 3 / 5 "antmaze") measured alone: K rollouts of
+    T = 16 env steps of the build's STAND-IN 29-state / 8-action crawler model (frame_skip 5 sub-steps each; NOT MuJoCo, parity
+    unpinned), every step followed by the reference's ant goal test and is_colliding_ant, rows stored step-major / candidate-
+    minor.  Algorithmic bytes per rollout: 232 + 64 T (actions) + 232 T (states) + 8."""
+    rank, world, local, dist, rehearse = _dist_setup(args)
+    from ditreeonlineplanner_amd.ops import Context
+    K = args.batch if args.batch_set else 65536
+    T = args.horizon or 16
+    maze = load_maze("boxes")
+    ctx = Context(local)
+    dev = ctx.device
+    ctx.upload_maze(maze)
+    nodes, *_ = ant_synth(maze, K, 1, 1, 20260104 + rank)
+    rng = np.random.default_rng(99 + rank)
+    act = np.clip(rng.uniform(-1, 1, (K, 1, 8)) + rng.normal(0, 0.4, (K, T, 8)), -1.2, 1.2)
+    s0 = torch.as_tensor(nodes, device=dev)
+    a = torch.as_tensor(np.ascontiguousarray(act), device=dev)
+    state = s0.clone()
+    status = torch.zeros(K, dtype=torch.int32, device=dev)
+    Hh, W = maze.shape
+    goal = np.array([((17 + 0.5) - W / 2) * 4.0, (Hh / 2 - (2 + 0.5)) * 4.0])
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    it = [0]
+    out = {}
+    import ctypes as C
+    from ditreeonlineplanner_amd import _lib
+    from ditreeonlineplanner_amd._lib import check, lib
+    from ditreeonlineplanner_amd.ops import _dbl, _ptr
+    states = torch.zeros(T + 1, 29, K, dtype=torch.float64, device=dev).permute(2, 0, 1)
+    aout = torch.zeros(T, 8, K, dtype=torch.float64, device=dev).permute(2, 0, 1)
+    steps_t = torch.zeros(K, dtype=torch.int32, device=dev)
+    model = _lib.AntModel.default()
+    sl, al = _lib.Strides(*states.stride()), _lib.Strides(*aout.stride())
+    g, gp = _dbl(goal)
+
+    def step():
+        state.copy_(s0)
+        status.zero_()
+        timed = it[0] >= args.warmup
+        if timed:
+            ev[it[0] - args.warmup][0].record()
+        check(ctx._h, lib().ditree_ant_rollout(ctx._h, C.byref(model), _ptr(state), _ptr(a), T * 8, None, 0, _ptr(status), K, T, gp,
+                                               0.45 * 4.0, 1.2, 4.0, _ptr(states), C.byref(sl), _ptr(aout), C.byref(al), _ptr(steps_t),
+                                               ctx.stream), "ant_rollout")
+        if timed:
+            ev[it[0] - args.warmup][1].record()
+        it[0] += 1
+
+    elapsed = _timed(step, args, dist, world, dev, rehearse)
+    comm = comm_info(dist, rehearse, dev)
+    k_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
+    if rank == 0:
+        st = status.cpu().numpy() & 0xFF
+        executed = int(steps_t.sum().item())
+        avg_ms = float(np.mean(k_ms))
+        alg = K * (232 + 64 * T + 232 * T + 8)
+        ach = alg / (avg_ms * 1e-3) / 1e9
+        res = {"metric": "ant-model rollouts/sec (T=16 env steps x 5 sub-steps of the build's stand-in 29-state / 8-action crawler model, NOT MuJoCo; "
+                         "goal test + is_colliding_ant per step; no denoiser)",
+               "value": K * world * args.steps / elapsed, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": _data(rehearse) + "; dynamics: stand-in model, parity unpinned, not MuJoCo",
+               "config": {"workload": f"BASELINE config 5's antmaze variant / SURVEY 8(f)4: {K} rollouts x T={T} of the higher-DoF rollout kernel per GPU on "
+                                      "boxes.csv x 4 (stand-in dynamics; the reference has neither an ant MPPI script nor the ant physics in its repository)",
+                          "rollouts_per_gpu": K, "horizon": T, "frame_skip": 5, "parallelism": f"rollouts sharded x{world}, no collective"},
+               "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                            **recorded_traffic("rollout_ant", kernel="ant_rollout_kernel"), "kernel": "ant_rollout_kernel<true>",
+                            "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg,
+                            "executed_env_steps_per_launch": executed,
+                            "note": "rows stored step-major / candidate-minor (512 contiguous bytes per wave store); the kernel is bound by its "
+                                    "sequential FP64 chain with one wave per SIMD, see DESIGN.md"},
                "outcome": {"ok": int((st == 0).sum()), "goal": int((st == 1).sum()), "collided": int((st == 2).sum())}, **comm}
         print(json.dumps(res), flush=True)
     if dist is not None:
@@ -636,82 +718,202 @@ def run_lidar_round(args):
         dist.destroy_process_group()
 
 
-def run_ant_denoise(args):
-    """BASELINE config 3 (cfgs/antmaze.yaml + fm_policy, B = 4096 candidates, H = 48): the part of it that has an oracle --
-    per candidate 24 chunks (action_horizon 2) x [16 x 16 @ 0.8 local map (s_global 4), ant conditioning vector incl.
-    quaternion -> rot6d and the 3-step history, ResNet-18-GN encoder on 16 x 16, FiLM U-Net at input_dim 8 / pred_horizon 16 /
-    cond 497, flow step, un-normalise] = 24 x 1.536 GFLOP = 36.86 GFLOP, sequenced on the device by ditree_expand_round_ant
-    (history and previous action carried between the chunks).  The MuJoCo dynamics between the chunks have no oracle here and
-    are NOT built: the observations after every env step come from a synthetic tape."""
+def ant_synth(maze, N0, B, n_chunks, seed):
+    """Seeded synthetic snapshot + round inputs of BASELINE config 3: N0 nodes in free cells of the maze scaled by s_global = 4
+    (inside the cell with a margin the 1.2 ball never leaves), upright torsos, joints at rest, 3-row histories; samples as
+    planners/base_planner.py:193-207 (0.15 goal rate), conditioning coin as planners/RRT.py:153-156."""
+    rng = np.random.default_rng(seed)
+    Hh, W = maze.shape
+    free = np.argwhere(maze[1:-1, 1:-1] == 0) + 1
+    cell = free[rng.integers(0, len(free), N0)]
+    nodes = np.zeros((N0, 29))
+    nodes[:, 0] = ((cell[:, 1] + 0.5) - W / 2) * 4.0 + rng.uniform(-0.6, 0.6, N0)
+    nodes[:, 1] = (Hh / 2 - (cell[:, 0] + 0.5)) * 4.0 + rng.uniform(-0.6, 0.6, N0)
+    nodes[:, 2] = rng.uniform(0.5, 0.8, N0)
+    q = np.array([1.0, 0, 0, 0]) + rng.normal(0, 0.05, (N0, 4))
+    nodes[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    nodes[:, 7:15] = np.tile([0.0, 0.87], 4) + rng.normal(0, 0.05, (N0, 8))
+    nodes[:, 15:] = rng.normal(0, 0.3, (N0, 14))
+    hist = np.repeat(nodes[:, None, :], 3, axis=1)
+    hist[:, :2, 7:] += rng.normal(0, 0.03, (N0, 2, 22))
+    goal = np.zeros(29)
+    goal[:2] = [((17 + 0.5) - W / 2) * 4.0, (Hh / 2 - (2 + 0.5)) * 4.0]
+    is_goal = rng.random(B) <= 0.15
+    samples = np.zeros((B, 29))
+    samples[:, 0] = rng.uniform(-4.0 * W / 2, 4.0 * W / 2, B)
+    samples[:, 1] = rng.uniform(-4.0 * Hh / 2, 4.0 * Hh / 2, B)
+    samples[is_goal] = goal
+    coin = rng.random(B) > 0.85
+    cond = np.where(coin[:, None], samples[:, :2], goal[None, :2])
+    noise = torch.randn(B, n_chunks, 16, 8, generator=torch.Generator().manual_seed(seed))
+    last_action = rng.uniform(-1, 1, (N0, 8))
+    return nodes, hist, last_action, goal, samples, cond, noise
+
+
+def ant_cpu_baseline(maze, nodes, hist, last_action, goal, samples, cond, noise, state_dict, norm, n_cand=128, batch=64):
+    """The oracle (kind "port": numpy f64 glue incl. the reference-pinned collision / goal tests and the stand-in model, torch-CPU
+    fp32 denoiser) on a bounded sample of the same round."""
+    from oracle import ant as OA
+    from oracle import denoiser as OD
+    from oracle import sampler as OS
+    n_thr = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(n_thr)
+    net = OD.init_noise_pred_net(input_dim=8, action_dim=8, obs_dim=29, obs_history=3, action_history=1).eval()
+    net.load_state_dict(state_dict)
+    nz = noise.numpy()
+    meta = dict(Observations_mean=norm[:27], Observations_std=norm[27:54], Actions_mean=norm[54:62], Actions_std=norm[62:70])
+
+    def sampler(cand_idx, chunk, h, prev_a, has_prev, cond_goal, lm):
+        cv = OS.ant_cond_vector(h, prev_a, has_prev, cond_goal, meta=meta)
+        x = OS.flow_sample(net, nz[cand_idx, chunk], OS.scale_local_map(lm), cv, k_steps=1)
+        return x.astype(np.float64) * meta["Actions_std"] + meta["Actions_mean"]
+    pl = OA.OracleAntPlanner(maze, nodes[0], goal, goal[:2], sampler, lambda c, j, i, cur, act: OA.ant_model_step(cur, act))
+    N0 = len(nodes)
+    pl.states = [s for s in nodes]
+    pl.parents = [-1] + list(range(0, N0 - 1))
+    pl.last_action = [np.zeros(8)] + [a for a in last_action[1:]]
+    pl.has_prev = [False] + [True] * (N0 - 1)
+    pl.edge_states = [None] + [h for h in hist[1:]]
+    pl.edge_actions = [None] * N0
+    t0 = time.perf_counter()
+    done = 0
+    while done < n_cand:
+        pl.candidates = done
+        pl.goal_node = None
+        pl.expand_round(samples[done:done + batch], cond[done:done + batch])
+        del pl.states[N0:], pl.parents[N0:], pl.last_action[N0:], pl.has_prev[N0:], pl.edge_states[N0:], pl.edge_actions[N0:]
+        done += batch
+    dt = time.perf_counter() - t0
+    return {"value": n_cand / dt, "unit": "candidate expansions/s", "cores": n_thr, "kind": "port",
+            "sample": f"{n_cand} candidates of the same round in rounds of {batch} (oracle: numpy f64 glue + stand-in model, torch-CPU fp32 "
+                      f"denoiser, {n_thr} threads; early exit as the reference abandons collided edges)", "seconds": dt}
+
+
+def run_ant_round(args):
+    """BASELINE config 3 (cfgs/antmaze.yaml + fm_policy, B = 4096 candidates, H = 48) as a real expansion round: nearest node
+    over a 1024-node snapshot -> 24 chunks (action_horizon 2) x [16 x 16 @ 0.8 local map (s_global 4), ant conditioning vector
+    incl. quaternion -> rot6d and the 3-step history, ResNet-18-GN encoder on 16 x 16, FiLM U-Net at input_dim 8 / pred_horizon
+    16 / cond 497, flow step, un-normalise, 2 env steps each followed by the reference's goal test and is_colliding_ant] ->
+    accept into the 29-d tree.  24 x 1.536 GFLOP = 36.86 GFLOP per candidate when every chunk runs.
+    THE ENV STEP is the build's stand-in crawler model (`--ant-dynamics model`, default) or a next-observation tape (`tape`):
+    MuJoCo (the reference's physics) has no oracle here and is NOT built -- said so in `metric`, `data` and `config`.  The headline
+    `value` runs every chunk of every candidate (no early exit, as the car headline); `early_exit` reports the compacted rate."""
     rank, world, local, dist, rehearse = _dist_setup(args)
     from ditreeonlineplanner_amd import _lib
+    from ditreeonlineplanner_amd.engine import CNT_GOAL, CNT_NODES, AntExpansionEngine
     from ditreeonlineplanner_amd.model import NoisePredNet
     from ditreeonlineplanner_amd.ops import Context
-    B = args.batch if args.batch_set else 4096
-    n_calls, A_ant = 48 // 2, 2
+    Bper = args.batch if args.batch_set else 4096
+    Btot = Bper * world
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch must divide by the number of GPUs")
+        Btot = args.global_batch
+        Bper = Btot // world
+    nC, A_ant = 48 // 2, 2
     prec = args.precision
+    dyn = args.ant_dynamics
     maze = load_maze("boxes")
     ctx = Context(local)
     dev = ctx.device
-    ctx.upload_maze(maze)
     net = NoisePredNet(input_dim=8, additional_global_cond_dim=97, pred_horizon=16, local_map_size=16, seed=0)
-    net.bind(ctx, precision=_lib.PREC_NAMES[prec], max_batch=B)
-    rng = np.random.default_rng(20260104 + rank)
-    Hh, W = maze.shape
-    free = np.argwhere(maze[1:-1, 1:-1] == 0) + 1
-    cell = free[rng.integers(0, len(free), B)]
-    xy0 = np.stack([((cell[:, 1] + 0.5) - W / 2) * 4.0, (Hh / 2 - (cell[:, 0] + 0.5)) * 4.0], axis=1)
-
-    def obs_rows(n):
-        o = rng.normal(0.0, 1.0, (B, n, 29))
-        o[..., 0] = xy0[:, None, 0] + np.cumsum(rng.normal(0.0, 0.05, (B, n)), axis=1)
-        o[..., 1] = xy0[:, None, 1] + np.cumsum(rng.normal(0.0, 0.05, (B, n)), axis=1)
-        o[..., 2] = rng.uniform(0.4, 0.8, (B, n))
-        q = rng.normal(size=(B, n, 4))
-        o[..., 3:7] = q / np.linalg.norm(q, axis=-1, keepdims=True)
-        return o
-    hist = torch.as_tensor(obs_rows(3), device=dev)
-    tape = torch.as_tensor(obs_rows(n_calls * A_ant).reshape(B, n_calls, A_ant, 29), device=dev)
-    prev = torch.as_tensor(rng.uniform(-1, 1, (B, 8)), device=dev)
-    hasp = torch.ones(B, dtype=torch.uint8, device=dev)
-    goal = torch.as_tensor(rng.uniform(-30, 30, (B, 2)), device=dev)
-    g = torch.Generator(device="cpu").manual_seed(20260104)
-    noise = torch.randn(B, n_calls, 16, 8, generator=g).to(dev)
+    net.bind(ctx, precision=_lib.PREC_NAMES[prec], max_batch=Bper)
     with open(os.path.join(REPO, "ditreeonlineplanner_amd", "data", "metadata_antmaze.json")) as f:
         md = json.load(f)
     norm = np.array(md["Observations_mean"] + md["Observations_std"] + md["Actions_mean"] + md["Actions_std"])
+    nodes, hist, last_action, goal, samples, cond, noise = ant_synth(maze, N0, Btot, nC, 20260104)
+    force_dist = world == 1 and dist is not None
 
-    def step():
-        ctx.expand_round_ant(hist, prev, hasp, goal, noise, tape, norm, action_horizon=A_ant, check_range=False)
+    def make_engine(early_exit):
+        eng = AntExpansionEngine(ctx, maze, nodes[0], goal, norm=norm, batch=Btot, capacity=N0 + Btot, dynamics=dyn,
+                                 early_exit=early_exit, rank=rank, world_size=world)
+        eng.force_allgather = force_dist
+        t = eng.tree
+        nd = torch.as_tensor(nodes, device=dev)
+        t.state[:N0] = nd
+        t.xy[:N0] = nd[:, :2]
+        t.parent[:N0] = torch.arange(-1, N0 - 1, device=dev, dtype=torch.int32).clamp(min=0)
+        t.parent[0] = -1
+        t.has_prev[1:N0] = 1
+        t.last_action[1:N0] = torch.as_tensor(last_action[1:], device=dev)
+        t.hist[:N0] = torch.as_tensor(hist, device=dev)
+        t.hist_n[:N0] = 3
+        t.hist_n[0] = 1
+        return eng
+    s_dev, c_dev, n_dev = torch.as_tensor(samples, device=dev), torch.as_tensor(cond, device=dev), noise.to(dev)
+    tape = None
+    if dyn == "tape":
+        rng = np.random.default_rng(7)
+        tp = np.zeros((Btot, nC * A_ant, 29))
+        base = nodes[rng.integers(0, N0, Btot)]
+        tp[:] = base[:, None, :]
+        tp[:, :, :2] += np.cumsum(rng.normal(0, 0.05, (Btot, nC * A_ant, 2)), axis=1)
+        tape = torch.as_tensor(tp.reshape(Btot, nC, A_ant, 29), device=dev)
+    comm = comm_info(dist, rehearse, dev)
 
+    def run(eng):
+        t = eng.tree
+
+        def step():
+            eng.expand_round(s_dev, c_dev, noise=n_dev, next_obs_tape=tape)
+            t.counters[CNT_NODES] = N0
+            t.counters[CNT_GOAL] = -1
+            t.n_nodes_host = N0
+        return step
+    eng = make_engine(False)
+    step = run(eng)
     for _ in range(args.warmup):
         step()
     ctx.profile(1)
     elapsed = _timed(step, dataclass_replace(args, warmup=0), dist, world, dev, rehearse)
     prof = ctx.profile_read(prec)
     ctx.profile(0)
-    ctx.check_range()                                     # f16 range guard, once for the whole loop
-    comm = comm_info(dist, rehearse, dev)
+    ctx.check_range()
+    lo, hi, _ = eng.shard(Btot)
+    st = eng.rb.status[lo:hi].cpu().numpy() & 0xFF
+    run_chunks = eng.rb.chunks_run[lo:hi].cpu().numpy()
+    ee = None
+    if not args.no_early_exit_line:
+        eng2 = make_engine(True)
+        step2 = run(eng2)
+        for _ in range(max(1, args.warmup)):
+            step2()
+        n2 = max(2, args.steps // 2)
+        el2 = _timed(step2, dataclass_replace(args, warmup=0, steps=n2), dist, world, dev, rehearse)
+        ee = {"value": Btot * n2 / el2, "ms_per_step": 1e3 * el2 / n2, "denoiser_calls_per_candidate": float(run_chunks.mean()),
+              "note": "later chunks run on the still-alive candidates only (planners/RRT.py:179-184); same tree, bit for bit"}
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        cpu = ant_cpu_baseline(maze, nodes, hist, last_action, goal, samples, cond, noise, sd, norm)
     if rank == 0:
         mac = 752_250_880 + 15_749_120
-        alg = 2.0 * mac * B * n_calls * args.steps
+        alg = 2.0 * mac * Bper * nC * args.steps
         all_ms = sum(v["ms"] for v in prof.values())
         peak = 157.3 if prec == "f32" else (PEAK_BF16_TFLOPS / 3.0 if prec in ("f16x3", "bf16x3") else PEAK_BF16_TFLOPS)
         ach = alg / (all_ms * 1e-3) / 1e12
-        res = {"metric": "candidate tree-expansions/sec (antmaze, H=48; denoiser + glue + chunk sequencing, dynamics NOT built: next observations from a tape)",
-               "value": B * world * args.steps / elapsed, "unit": "candidate expansions/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": prec, "data": _data(rehearse),
-               "config": {"workload": f"BASELINE config 3: cfgs/antmaze.yaml + fm_policy, batch={B} candidates per GPU, H=48 = 24 chunks x "
+        stand_in = ("the build's stand-in crawler model (NOT MuJoCo, parity unpinned)" if dyn == "model"
+                    else "a synthetic next-observation tape (NOT MuJoCo)")
+        res = {"metric": f"candidate tree-expansions/sec (antmaze, H=48; env step = {stand_in})",
+               "value": Btot * args.steps / elapsed, "unit": "candidate expansions/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+               "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": prec,
+               "data": _data(rehearse) + f"; env step: {stand_in}",
+               "config": {"workload": f"BASELINE config 3: cfgs/antmaze.yaml + fm_policy, batch={Bper} candidates per GPU, H=48 = 24 chunks x "
                                       "[local map 16x16@0.8 s_global 4, ant cond vector (rot6d, 3-step history), encoder + U-Net P=16 D=8 cond 497, "
-                                      "flow step, 2 of 16 actions kept], sequenced by ditree_expand_round_ant; NO dynamics (MuJoCo: no oracle), "
-                                      "next observations from a synthetic tape", "batch_per_gpu": B, "calls_per_candidate": n_calls},
+                                      "flow step, 2 of 16 actions kept, 2 env steps + goal test + is_colliding_ant each] -> accept into the 29-d tree; "
+                                      f"{N0}-node snapshot, boxes.csv x 4, seeded random weights; env step: {stand_in}",
+                          "batch_per_gpu": Bper, "global_batch": Btot, "calls_per_candidate": nC, "ant_dynamics": dyn,
+                          "parallelism": f"candidates sharded x{world}, one {eng.tree.record_doubles * 8}-byte record all-gather per round"},
                "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                            **recorded_traffic("ant_denoise", prec),
+                            **recorded_traffic("ant_round", prec),
                             "kernel": "all MFMA kernels of the denoiser (L = 8 / 4 levels: plain GEMM + gn1d_short_kernel, unfused; split formats: 3 MFMAs per product)",
                             "per_kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
-                            "algorithmic_gflop_per_candidate": 2.0 * mac * n_calls / 1e9,
-                            "note": "events around every MFMA launch inside the timed region (costs a few %)"}, **comm}
+                            "algorithmic_gflop_per_candidate": 2.0 * mac * nC / 1e9,
+                            "note": "events around every MFMA launch inside the timed region (costs a few %)"},
+               "outcome": {"ok": int((st == 0).sum()), "goal": int((st == 1).sum()), "collided": int((st == 2).sum()),
+                           "mean_chunks_until_end": float(run_chunks.mean())},
+               "early_exit": ee, "cpu_baseline": cpu, **comm}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -727,7 +929,12 @@ def dataclass_replace(args, **kw):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="expand", choices=["expand", "rollout", "mppi", "lidar-round", "ant-denoise", "geometry"])
+    ap.add_argument("--workload", default="expand", choices=["expand", "rollout", "mppi", "lidar-round", "ant-round", "geometry"])
+    ap.add_argument("--model", default="car", choices=["car", "ant"],
+                    help="rollout / mppi workloads: the dynamics behind the rollout-kernel interface.  ant = the build's stand-in "
+                         "29-state / 8-action crawler model (NOT MuJoCo, parity unpinned)")
+    ap.add_argument("--ant-dynamics", default="model", choices=["model", "tape"],
+                    help="ant-round workload: the env step (MuJoCo is not built): the stand-in model or a next-observation tape")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="fixed GLOBAL round size split over the GPUs (strong scaling); default: --batch per GPU (weak)")
     ap.add_argument("--horizon", type=int, default=0, help="rollout workload: steps per rollout (default 16)")
@@ -754,13 +961,13 @@ def main():
     if os.environ.get("DITREE_BENCH_DRYRUN", "0") == "1":
         return run_dry(args)
     if args.workload == "rollout":
-        return run_rollout(args)
+        return run_rollout_ant(args) if args.model == "ant" else run_rollout(args)
     if args.workload == "mppi":
         return run_mppi(args)
     if args.workload == "lidar-round":
         return run_lidar_round(args)
-    if args.workload == "ant-denoise":
-        return run_ant_denoise(args)
+    if args.workload == "ant-round":
+        return run_ant_round(args)
     if args.workload == "geometry":
         return run_geometry(args)
 

@@ -93,8 +93,10 @@ class RRT_Planner(BasePlanner):
         self._tape_fn = kwargs.get("next_obs_tape_fn")
         lm = self.local_map_size if isinstance(self.local_map_size, (int, float)) else self.local_map_size[0]
         norm = getattr(sampler, "norm", None)
-        if norm is None:
-            raise ValueError("antmaze: the sampler must carry the ant normalisation (DiffusionSampler(env_id='antmaze').norm)")
+        if norm is None:                                        # a non-network sampler: the packaged copy of metadata/antmaze.pt
+            from ..policies.fm_policy import load_metadata
+            md = load_metadata("antmaze")
+            norm = np.concatenate([md["Observations_mean"], md["Observations_std"], md["Actions_mean"], md["Actions_std"]])
         desired = kwargs.get("desired_goal")
         out = getattr(self, "_reset_out", None)
         if desired is None and isinstance(out, tuple) and isinstance(out[0], dict) and "desired_goal" in out[0]:

@@ -279,3 +279,62 @@ def test_sharded_mppi_controller_follows_the_single_rank_trajectory(tmp_path):
     assert np.abs(a["traj"] - b0["traj"]).max() < 1e-9 and np.abs(a["acts"] - b0["acts"]).max() < 1e-9
     assert int(a["coll"]) == int(b0["coll"]) and abs(float(a["ess"]) - float(b0["ess"])) < 1e-6 * float(a["ess"])
     assert a["traj"][-1, 0] > a["traj"][0, 0] + 0.2                     # it moves along the corridor
+
+
+def _gpu_ant_worker(rank, world, port, out_path, B=41):
+    """Sharded ANT rounds (29-d tree, 134-double records incl. every candidate's end-of-edge history): tape dynamics + action tape."""
+    sys.path.insert(0, REPO)
+    _init(rank, world, port)
+    from ditreeonlineplanner_amd.engine import AntExpansionEngine
+    from ditreeonlineplanner_amd.ops import Context
+    from oracle import ant as OA
+    from oracle import rrt as ORRT
+    from oracle import sampler as OS
+    from tests.test_oracle_ant import trace_setup
+    g, pre, pl, atape, otape, m = trace_setup("tape_boxes")
+    md = OS.ANT_META
+    norm = np.concatenate([md["Observations_mean"], md["Observations_std"], md["Actions_mean"], md["Actions_std"]])
+    ctx = Context(0)
+    eng = AntExpansionEngine(ctx, m["maze"], g[pre + "start"], g[pre + "goal"], desired_goal=g[pre + "desired"], norm=norm, batch=B,
+                             capacity=2048, dynamics="tape", rank=rank, world_size=world, early_exit=True)
+    assert eng.tree.record_doubles == 29 + 16 + 2 + 87
+    tape = ORRT.RandomTape(42)
+    done, goal = 0, None
+    for _ in range(3):
+        s, c = np.zeros((B, 29)), np.zeros((B, 2))
+        for i in range(B):
+            s[i], c[i] = OA.draw_candidate_ant(tape, 20, 20, 4.0, g[pre + "goal"])
+        cand = np.arange(done, done + B)
+        acts = np.stack([atape.actions(cand, j) for j in range(eng.n_chunks)], axis=1)
+        cnt = eng.expand_round(torch.as_tensor(s).cuda(), torch.as_tensor(c).cuda(), inject_actions=torch.as_tensor(acts).cuda(),
+                               next_obs_tape=torch.as_tensor(otape.rows(cand)).cuda())
+        done += B
+        if int(cnt[1]) >= 0:
+            goal = int(cnt[1])
+            break
+    snap = eng.tree_snapshot()
+    n = len(snap["parents"])
+    node = goal if goal is not None else eng.fallback_node()
+    path, actions = eng.path_to(node)
+    np.savez(out_path.format(rank=rank), parents=snap["parents"], states=snap["states"], counters=snap["counters"], path=path,
+             actions=actions, hist=eng.tree.hist[:n].cpu().numpy(), hist_n=eng.tree.hist_n[:n].cpu().numpy(),
+             last_action=eng.tree.last_action[:n].cpu().numpy(), owner=eng.tree.edge_owner[:n].cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_ant_round_builds_identical_tree(tmp_path):
+    """2 and 3 ranks (a ragged split of 41 candidates) build the 1-rank ant tree bit for bit -- node states, parents, the
+    histories and last actions a child's first sampler call needs (carried by the records), and the collective path walk."""
+    out = str(tmp_path / "a{w}_r{rank}.npz")
+    mp.spawn(_gpu_ant_worker, args=(1, 29691, out.replace("{w}", "1")), nprocs=1, join=True)
+    a = np.load(out.replace("{w}", "1").format(rank=0))
+    for world, port in ((2, 29692), (3, 29693)):
+        mp.spawn(_gpu_ant_worker, args=(world, port, out.replace("{w}", str(world))), nprocs=world, join=True)
+        for r in range(world):
+            b = np.load(out.replace("{w}", str(world)).format(rank=r))
+            for k in ("parents", "states", "hist", "hist_n", "last_action", "path", "actions"):
+                assert np.array_equal(a[k], b[k]), (world, r, k)
+            assert np.array_equal(a["counters"][:5], b["counters"][:5])
+            assert len(np.unique(b["owner"][1:])) == world
+    assert len(a["parents"]) > 10 and a["path"].shape[1] == 29
