@@ -120,7 +120,7 @@ SIGNATURES = {
                                   _vp, C.POINTER(Strides), _vp, C.POINTER(Strides), _vp, _vp]),
     "ditree_lidar_scan": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ditree_obstacle_ahead": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
-    "ditree_path_after_obstacle": (_i32, [_vp, _vp, _i32, _i32, _pf, _vp, _vp]),
+    "ditree_path_after_obstacle": (_i32, [_vp, _vp, _i32, _i32, _pd, _i32, _vp, _vp]),
     "ditree_fallback_select": (_i32, [_vp, C.POINTER(Tree), _i32, _pd, _pd, _i32, _vp, _vp]),
     "ditree_follow_plan": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _pd, _f64, _f64, _vp, _vp, _vp]),
     "ditree_accept": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), _i32, _vp]),

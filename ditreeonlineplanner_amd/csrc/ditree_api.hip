@@ -322,12 +322,13 @@ int32_t ditree_follow_plan(ditree_ctx* ctx, double* state_io, const float* actio
   return DITREE_OK;
 }
 
-int32_t ditree_path_after_obstacle(ditree_ctx* ctx, const float* path, int32_t stride, int32_t P, const float* cur_xy,
-                                   int32_t* out2, void* stream) {
+int32_t ditree_path_after_obstacle(ditree_ctx* ctx, const float* path, int32_t stride, int32_t P, const double* cur_xy,
+                                   int32_t f32_state, int32_t* out2, void* stream) {
   if (!ctx) return DITREE_E_ARG;
   if (!ctx->maze) return set_err(ctx, DITREE_E_STATE, "path_after_obstacle: no maze uploaded");
   if (!path || !cur_xy || !out2 || P < 1 || stride < 2) return set_err(ctx, DITREE_E_ARG, "path_after_obstacle: bad argument");
-  launch_path_after_obstacle(path, stride, P, cur_xy[0], cur_xy[1], ctx->maze, ctx->rows, ctx->cols, out2, (hipStream_t)stream);
+  launch_path_after_obstacle(path, stride, P, cur_xy[0], cur_xy[1], f32_state != 0, ctx->maze, ctx->rows, ctx->cols, out2,
+                             (hipStream_t)stream);
   HIP_TRY(ctx, hipGetLastError());
   return DITREE_OK;
 }

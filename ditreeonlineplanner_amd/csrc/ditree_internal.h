@@ -90,8 +90,8 @@ void launch_cond_vector_ant(const double* obs, int n_rows, const int32_t* hist_n
 void launch_cond_vector(const double* state, const double* prev_action, const uint8_t* has_prev,
                         const double* cond_goal, const int32_t* idx, int B, const NormArg& nm, double lm_size,
                         float* out, hipStream_t s);
-void launch_path_after_obstacle(const float* path, int stride, int P, float cx, float cy, const unsigned char* maze, int rows,
-                                int cols, int32_t* out, hipStream_t s);
+void launch_path_after_obstacle(const float* path, int stride, int P, double cx, double cy, int f32_state, const unsigned char* maze,
+                                int rows, int cols, int32_t* out, hipStream_t s);
 // ant_kernels.hip
 struct AntModelArg;
 void launch_ant_collision(const unsigned char* maze, int rows, int cols, const double* state, int stride, int B, double ball_radius,

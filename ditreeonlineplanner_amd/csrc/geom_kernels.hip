@@ -243,31 +243,38 @@ void launch_cond_vector_ant(const double* obs, int n_rows, const int32_t* hist_n
 }
 
 // ------------------------------------------------------------------------- reference path behind the obstacle
-// planners/RRT.py:83-111 extract_path_after_obstacle in the path's float32 arithmetic: c = argmin_i ||cur - path_i|| (first
-// occurrence, np.linalg.norm along axis 1 = sqrt(dx*dx + dy*dy) in f32); over rest = path[c:], cells by cell_xy_to_rowcol
-// (f32, floor); i_b = first rest index in an occupied cell (none: -1, the reference then indexes the LAST point); then the
+// planners/RRT.py:83-111 extract_path_after_obstacle: c = argmin_i ||cur - path_i|| (first occurrence, np.linalg.norm along
+// axis 1 = sqrt(dx*dx + dy*dy)) in the dtype numpy gives `env.state[:2] - path[:, :2]` -- float64 when the env state is float64
+// (after any env step; the f32 path is promoted), float32 right after env.reset (car_env.py:215 builds a float32 state) --;
+// over rest = path[c:], cells by cell_xy_to_rowcol (the path's f32, floor); i_b = first rest index in an occupied cell (none: -1, the reference then indexes the LAST point); then the
 // reference's while loop walks to the first free point j >= i_b and returns rest[j + 1:] (k = j + 1; the blocked run reaching
 // the end gives k = len(rest); no crossing gives k = -1, i.e. the last point alone when that one is free).
 // out[0] = c, out[1] = k.  One work-group; the path is a few hundred to a few thousand points.
 __global__ void __launch_bounds__(256)
-path_after_obstacle_kernel(const float* __restrict__ path, int stride, int P, float cx, float cy,
+path_after_obstacle_kernel(const float* __restrict__ path, int stride, int P, double cx, double cy, int f32_state,
                            const unsigned char* __restrict__ maze, int rows, int cols, int32_t* __restrict__ out) {
-  __shared__ float s_d[256];
+  __shared__ double s_d[256];
   __shared__ int s_i[256];
   __shared__ int s_c, s_ib, s_j;
   const int tid = threadIdx.x;
-  float best = __builtin_huge_valf();
+  double best = __builtin_huge_val();
   int bi = 0x7fffffff;
   for (int i = tid; i < P; i += 256) {
-    const float dx = cx - path[(size_t)i * stride], dy = cy - path[(size_t)i * stride + 1];
-    const float d = sqrtf(dx * dx + dy * dy);
+    double d;
+    if (f32_state) {
+      const float dx = (float)cx - path[(size_t)i * stride], dy = (float)cy - path[(size_t)i * stride + 1];
+      d = (double)sqrtf(dx * dx + dy * dy);
+    } else {
+      const double dx = cx - (double)path[(size_t)i * stride], dy = cy - (double)path[(size_t)i * stride + 1];
+      d = sqrt(dx * dx + dy * dy);
+    }
     if (d < best) { best = d; bi = i; }
   }
   s_d[tid] = best; s_i[tid] = bi;
   __syncthreads();
   for (int o = 128; o >= 1; o >>= 1) {
     if (tid < o) {
-      const float od = s_d[tid + o];
+      const double od = s_d[tid + o];
       const int oi = s_i[tid + o];
       if (od < s_d[tid] || (od == s_d[tid] && oi < s_i[tid])) { s_d[tid] = od; s_i[tid] = oi; }
     }
@@ -301,9 +308,9 @@ path_after_obstacle_kernel(const float* __restrict__ path, int stride, int P, fl
   __syncthreads();
   if (tid == 0) { out[0] = c; out[1] = s_j == 0x7fffffff ? n : s_j + 1; }
 }
-void launch_path_after_obstacle(const float* path, int stride, int P, float cx, float cy, const unsigned char* maze, int rows,
-                                int cols, int32_t* out, hipStream_t s) {
-  hipLaunchKernelGGL(path_after_obstacle_kernel, dim3(1), dim3(256), 0, s, path, stride, P, cx, cy, maze, rows, cols, out);
+void launch_path_after_obstacle(const float* path, int stride, int P, double cx, double cy, int f32_state, const unsigned char* maze,
+                                int rows, int cols, int32_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(path_after_obstacle_kernel, dim3(1), dim3(256), 0, s, path, stride, P, cx, cy, f32_state, maze, rows, cols, out);
 }
 
 // ------------------------------------------------------------------------- rollout

@@ -209,7 +209,9 @@ class RRT_Planner(BasePlanner):
     def extract_path_after_obstacle(self):
         """RRT.py:83-111: xy of ``init_main_path`` from the point nearest to the env state onwards, cut to what lies behind
         the first blocked stretch.  On the device (ditree_path_after_obstacle: nearest point, cell lookup and the two
-        searches in one launch on the known maze), in the path's float32 arithmetic as the reference's arrays."""
+        searches in one launch on the known maze).  The nearest-point distances are formed in the dtype numpy gives
+        ``env.state[:2] - path`` (float64 unless the env state is float32, as right after env.reset), the cells in the
+        path's float32."""
         import ctypes as C
         from .._lib import check, lib
         eng = self._engine
@@ -217,9 +219,11 @@ class RRT_Planner(BasePlanner):
         path = np.ascontiguousarray(self.init_main_path, dtype=np.float32)
         p_dev = torch.as_tensor(path, device=self.ctx.device)
         out = torch.zeros(2, dtype=torch.int32, device=self.ctx.device)
-        cur = (C.c_float * 2)(*np.asarray(self.env.state[:2], dtype=np.float32))
+        st = np.asarray(self.env.state)
+        cur = (C.c_double * 2)(*[float(v) for v in st[:2]])
         check(self.ctx._h, lib().ditree_path_after_obstacle(self.ctx._h, p_dev.data_ptr(), int(path.shape[1]), int(path.shape[0]),
-                                                            cur, out.data_ptr(), self.ctx.stream), "path_after_obstacle")
+                                                            cur, int(st.dtype == np.float32), out.data_ptr(), self.ctx.stream),
+              "path_after_obstacle")
         c, k = (int(v) for v in out.cpu().numpy())
         return self.init_main_path[c:, :2].copy()[k:]
 

@@ -284,13 +284,15 @@ int32_t ditree_accept(ditree_ctx* ctx, const ditree_tree* tree, const ditree_rou
 int32_t ditree_obstacle_ahead(ditree_ctx* ctx, const double* state, int32_t stride, int32_t B,
                               uint8_t* out, void* stream);
 
-/* planners/RRT.py:83-111 extract_path_after_obstacle on the uploaded (known) maze, in the path's float32 arithmetic: out2[0] =
- * index c of the path point nearest to cur_xy (first occurrence), out2[1] = k such that the remaining reference path is
- * path[c:][k:] -- the points behind the first blocked stretch (k = -1: the path crosses no obstacle, the reference then
- * keeps its last point only; k = P - c: nothing remains).  path [dev] (P, stride >= 2) f32 rows x, y, ...; cur_xy [host] 2 f32
+/* planners/RRT.py:83-111 extract_path_after_obstacle on the uploaded (known) maze: out2[0] = index c of the path point
+ * nearest to cur_xy (first occurrence; np.linalg.norm(env.state[:2] - path[:, :2], axis=1) in the dtype numpy gives the
+ * difference: f32_state != 0 when env.state is float32 -- right after env.reset, car_env.py:215 -- else float64 with the f32
+ * path promoted), out2[1] = k such that the remaining reference path is path[c:][k:] -- the points behind the first blocked
+ * stretch, cells looked up in the path's float32 (k = -1: the path crosses no obstacle, the reference then keeps its last
+ * point only; k = P - c: nothing remains).  path [dev] (P, stride >= 2) f32 rows x, y, ...; cur_xy [host] 2 f64
  * (env.state[:2]); out2 [dev] 2 x i32. */
-int32_t ditree_path_after_obstacle(ditree_ctx* ctx, const float* path, int32_t stride, int32_t P, const float* cur_xy /*[host] 2*/,
-                                   int32_t* out2, void* stream);
+int32_t ditree_path_after_obstacle(ditree_ctx* ctx, const float* path, int32_t stride, int32_t P, const double* cur_xy /*[host] 2*/,
+                                   int32_t f32_state, int32_t* out2, void* stream);
 
 /* planners/RRT.py:233-254 fallback node when the budget ends without reaching the goal, over nodes
  * 1..n-1 of the tree: path == NULL: argmin ||xy - goal|| + 1e4 * obstacle_ahead; path != NULL

@@ -66,13 +66,16 @@ def rollout_costs(maze, state, U, path_xy, goal_xy, noise, lam, sigma, w_track, 
         x[idx] = xn
         coll = G.is_colliding_car(xn, maze)
         reached = G.goal_reached(xn, goal_xy)
-        d2 = np.empty(idx.size)
-        for n, k in enumerate(idx):                      # windowed nearest path point, first occurrence of the minimum
-            lo, hi = max(ip[k] - window_back, 0), min(ip[k] + window_fwd, P - 1)
-            dd = (path[lo:hi + 1, 0] - xn[n, 0]) ** 2 + (path[lo:hi + 1, 1] - xn[n, 1]) ** 2
-            j = int(np.argmin(dd))
-            ip[k] = lo + j
-            d2[n] = dd[j]
+        # windowed nearest path point, first occurrence of the minimum: all alive rollouts at once over the (window_back +
+        # window_fwd + 1)-wide index window, positions outside [max(ip - back, 0), min(ip + fwd, P - 1)] masked out
+        w = ip[idx][:, None] + np.arange(-window_back, window_fwd + 1)[None, :]
+        ok = (w >= 0) & (w <= P - 1)
+        wc = np.clip(w, 0, P - 1)
+        dd = (path[wc, 0] - xn[:, None, 0]) ** 2 + (path[wc, 1] - xn[:, None, 1]) ** 2
+        dd = np.where(ok, dd, np.inf)
+        j = np.argmin(dd, axis=1)
+        ip[idx] = w[np.arange(idx.size), j]
+        d2 = dd[np.arange(idx.size), j]
         cost[idx] = cost[idx] + w_track * d2
         cost[idx] = cost[idx] + lam * ((U[t, 0] * eps[idx, t, 0]) / (sigma[0] * sigma[0]) + (U[t, 1] * eps[idx, t, 1]) / (sigma[1] * sigma[1]))
         cost[idx[coll]] = cost[idx[coll]] + w_collision

@@ -111,6 +111,36 @@ def cell_center_f32(xy, maze):
     return G.cell_rowcol_to_xy(rc, maze).astype(np.float32)
 
 
+def path_after_obstacle(init_main_path, cur_xy, maze):
+    """planners/RRT.py:83-111 extract_path_after_obstacle: the xy of ``init_main_path`` (float32, as generate_final_path_env
+    returns it) from the point nearest to ``cur_xy`` = env.state[:2] onwards, cut to what lies behind the first blocked
+    stretch.  numpy's dtype rules are part of the function: ``curr_state - path`` is float64 when the env state is float64
+    (the f32 path is promoted; the norm and its argmin are then float64) and float32 when the state is float32, as right after
+    env.reset; the cell lookup (cell_xy_to_rowcol of every f32 path point) stays float32 either way."""
+    maze = np.asarray(maze)
+    P = np.asarray(init_main_path)[:, :2]
+    cur = np.asarray(cur_xy)
+    cur = cur[:2].astype(np.float32) if cur.dtype == np.float32 else cur[:2].astype(np.float64)
+    closest = int(np.argmin(np.linalg.norm(cur - P, axis=1)))                       # RRT.py:86-87
+    rest = P[closest:].copy()
+    H, W = maze.shape
+    if rest.dtype == np.float32:
+        rc = np.stack([np.floor((np.float32(H / 2) - rest[:, 1]) / np.float32(1)), np.floor((rest[:, 0] + np.float32(W / 2)) / np.float32(1))],
+                      axis=1).astype(int)
+    else:
+        rc = np.stack([np.floor((H / 2 - rest[:, 1]) / 1), np.floor((rest[:, 0] + W / 2) / 1)], axis=1).astype(int)
+    k = -1
+    for i, pnt in enumerate(rc):
+        if maze[pnt[0], pnt[1]] == 1:
+            k = i
+            break
+    cp = rc[k]
+    while maze[cp[0], cp[1]] == 1 and k < len(rc):
+        cp = rc[k]
+        k += 1
+    return rest[k:]
+
+
 class OracleTree:
     def __init__(self, start_state, n_chunks, A):
         self.states = [np.asarray(start_state, dtype=np.float64).copy()]
@@ -270,26 +300,9 @@ class OraclePlanner:
 
     # ------------------------------------------------------------------ driver
     def remaining_reference_path(self):
-        """RRT.py:83-111 extract_path_after_obstacle (float32 arithmetic, as the reference's arrays):
-        the part of init_main_path behind the first obstacle it crosses, seen from the env state
-        (= centre of the start cell after planner.reset)."""
-        P = np.asarray(self.init_main_path)[:, :2].astype(np.float32)
-        cur = np.float32(cell_center_f32(self.start_state[:2], self.maze))
-        closest = int(np.argmin(np.linalg.norm(cur - P, axis=1)))
-        rest = P[closest:].copy()
-        H, W = self.maze.shape
-        rc = np.stack([np.floor((np.float32(H / 2) - rest[:, 1]) / np.float32(1)), np.floor((rest[:, 0] + np.float32(W / 2)) / np.float32(1))],
-                      axis=1).astype(int)
-        k = -1
-        for i, pnt in enumerate(rc):
-            if self.maze[pnt[0], pnt[1]] == 1:
-                k = i
-                break
-        cp = rc[k]
-        while self.maze[cp[0], cp[1]] == 1 and k < len(rc):
-            cp = rc[k]
-            k += 1
-        return rest[k:]
+        """RRT.py:83-111 extract_path_after_obstacle seen from the env state right after planner.reset (= centre of the
+        start cell, a FLOAT32 array: car_env.py:215-229)."""
+        return path_after_obstacle(self.init_main_path, cell_center_f32(self.start_state[:2], self.maze), self.maze)
 
     def plan(self, tape: RandomTape, n_candidates: int, batch: int = 1):
         """Run rounds of ``batch`` candidates until the goal is reached or ``n_candidates``

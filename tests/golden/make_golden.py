@@ -878,6 +878,59 @@ def gen_online(out):
           "oracle == reference")
 
 
+def gen_path_after_obstacle(out):
+    """The reference's RRT_Planner.extract_path_after_obstacle (planners/RRT.py:83-111) itself, on float32 paths with float64
+    AND float32 env states -- incl. states placed so that the nearest path point differs between float32 and float64
+    arithmetic (the reference's result then depends on the dtype of env.state: numpy promotion is part of its behaviour)."""
+    maze = load_maze("boxes")
+    rng = np.random.default_rng(77)
+
+    class _E:
+        def __init__(self, st):
+            self.state = st
+
+        def cell_xy_to_rowcol(self, xy, floor_enable=True):
+            return G.cell_xy_to_rowcol(xy, maze, floor_enable=floor_enable)
+    cases = []
+    for k in range(40):
+        # an L-shaped path through the free bottom corridor (row 18) and up column 18, with jitter, as float32
+        n1, n2 = int(rng.integers(40, 200)), int(rng.integers(40, 200))
+        a, b, c = G.cell_rowcol_to_xy([18, 1], maze), G.cell_rowcol_to_xy([18, 18], maze), G.cell_rowcol_to_xy([1, 18], maze)
+        p = np.concatenate([a + (b - a) * np.linspace(0, 1, n1)[:, None], b + (c - b) * np.linspace(0, 1, n2)[1:, None]])
+        p = (p + rng.normal(0, 0.02, p.shape)).astype(np.float32)
+        path = np.zeros((len(p), 6), dtype=np.float32)
+        path[:, :2] = p
+        mz = maze.copy()
+        if k % 4 != 3:                                   # an obstacle written onto the path (as a lidar scan would)
+            i = int(rng.integers(10, len(p) - 5))
+            rc = G.cell_xy_to_rowcol(p[i].astype(np.float64), maze)
+            mz[int(rc[0]), int(rc[1])] = 1
+        j = int(rng.integers(0, len(p) - 1))
+        if k % 2 == 0:                                   # between two path points, a hair off the f32 bisector
+            mid = (p[j].astype(np.float64) + p[j + 1].astype(np.float64)) / 2
+            st = np.zeros(6)
+            st[:2] = mid + rng.normal(0, 1e-9, 2)
+        else:
+            st = np.zeros(6)
+            st[:2] = p[j].astype(np.float64) + rng.normal(0, 0.3, 2)
+        for dt in (np.float64, np.float32):
+            pl = ref_rrt.RRT_Planner.__new__(ref_rrt.RRT_Planner)
+            pl.env, pl.maze, pl.init_main_path = _E(st.astype(dt)), mz, path
+            exp = pl.extract_path_after_obstacle()
+            mine = ORRT.path_after_obstacle(path, st.astype(dt), mz)
+            assert exp.dtype == mine.dtype and np.array_equal(exp, mine), (k, dt)
+            cases.append((path[:, :2].copy(), st[:2].copy(), dt == np.float32, mz, exp))
+    out["pao_n"] = np.array(len(cases))
+    differ = 0
+    for i, (p, st, f32, mz, exp) in enumerate(cases):
+        out[f"pao_{i}_path"], out[f"pao_{i}_state"], out[f"pao_{i}_f32"] = p, st, np.array(f32)
+        out[f"pao_{i}_maze"] = np.packbits(mz.astype(np.uint8), axis=None)
+        out[f"pao_{i}_expected"] = exp
+        if i % 2 == 1 and len(cases[i - 1][4]) != len(exp):
+            differ += 1
+    print(f"extract_path_after_obstacle: {len(cases)} cases (float64 / float32 env states; {differ} pairs where the dtype changes the result), oracle == reference")
+
+
 # --------------------------------------------------------------------------- ant (BASELINE config 3): glue pinned by the reference
 def ant_poses(rng, maze, n, sg):
     """Poses for is_colliding_ant: uniform over the scaled map (+ a margin outside), a third snapped onto cell boundaries /
@@ -1132,6 +1185,11 @@ def main():
         gen_sampler_ant(net)
         np.savez_compressed(os.path.join(HERE, "network.npz"), **net)
         return
+    if sys.argv[1:] == ["pao"]:               # extract_path_after_obstacle cases -> traces.npz (other entries kept)
+        tr = dict(np.load(os.path.join(HERE, "traces.npz"), allow_pickle=False))
+        gen_path_after_obstacle(tr)
+        np.savez_compressed(os.path.join(HERE, "traces.npz"), **tr)
+        return
     if sys.argv[1:] == ["antglue"]:           # ant collision / goal / planner-trace fixtures -> ant.npz
         ant = {}
         gen_ant_collision(ant)
@@ -1168,6 +1226,7 @@ def main():
     gen_traces_run_type1(traces)
     gen_traces_run_type23(traces)
     gen_trace_schedule(traces)
+    gen_path_after_obstacle(traces)
     gen_prob_maps(geo)
     np.savez_compressed(os.path.join(HERE, "geometry.npz"), **geo)
     np.savez_compressed(os.path.join(HERE, "network.npz"), **net)

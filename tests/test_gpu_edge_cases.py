@@ -205,19 +205,19 @@ def test_round3_entry_points_argument_and_call_order_errors(ctx):
     # path_after_obstacle before a maze
     out = torch.zeros(2, dtype=torch.int32, device="cuda")
     path = torch.zeros(8, 6, dtype=torch.float32, device="cuda")
-    cur = (C.c_float * 2)(0.0, 0.0)
+    cur = (C.c_double * 2)(0.0, 0.0)
     with pytest.raises(DitreeError, match="no maze"):
-        check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, path.data_ptr(), 6, 8, cur, out.data_ptr(), ctx.stream), "path_after_obstacle")
+        check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, path.data_ptr(), 6, 8, cur, 1, out.data_ptr(), ctx.stream), "path_after_obstacle")
     ctx.upload_maze(maze)
     with pytest.raises(DitreeError, match="bad argument"):
-        check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, path.data_ptr(), 1, 8, cur, out.data_ptr(), ctx.stream), "path_after_obstacle")
+        check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, path.data_ptr(), 1, 8, cur, 1, out.data_ptr(), ctx.stream), "path_after_obstacle")
     # a path that crosses nothing: k = -1 (the reference keeps its last point); a path that ends inside an obstacle: k = len
     free_row = np.stack([np.linspace(-8.5, 8.5, 40), np.full(40, -8.5)], axis=1).astype(np.float32)           # bottom corridor
     p_dev = dev(free_row)
-    check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, p_dev.data_ptr(), 2, 40, (C.c_float * 2)(-8.5, -8.5), out.data_ptr(), ctx.stream), "x")
+    check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, p_dev.data_ptr(), 2, 40, (C.c_double * 2)(-8.5, -8.5), 0, out.data_ptr(), ctx.stream), "x")
     assert out.cpu().tolist() == [0, -1]
     into_wall = np.stack([np.linspace(-8.5, 9.5, 40), np.full(40, -8.5)], axis=1).astype(np.float32)         # ends in the border wall
-    check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, dev(into_wall).data_ptr(), 2, 40, (C.c_float * 2)(-8.5, -8.5), out.data_ptr(), ctx.stream), "x")
+    check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, dev(into_wall).data_ptr(), 2, 40, (C.c_double * 2)(-8.5, -8.5), 0, out.data_ptr(), ctx.stream), "x")
     c, k = out.cpu().tolist()
     assert c == 0 and k == 40
     # MPPI: construction limits, step before a reference path, bad stage mask / lanes through the C-ABI
@@ -317,7 +317,7 @@ def test_round3_kernels_at_their_smallest_and_odd_sizes(ctx):
     out = torch.zeros(2, dtype=torch.int32, device="cuda")
     ctx.upload_maze(maze)
     one = dev(np.array([[-8.5, -8.5]], dtype=np.float32))
-    check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, one.data_ptr(), 2, 1, (C.c_float * 2)(0.0, 0.0), out.data_ptr(), ctx.stream), "x")
+    check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, one.data_ptr(), 2, 1, (C.c_double * 2)(0.0, 0.0), 0, out.data_ptr(), ctx.stream), "x")
     assert out.cpu().tolist() == [0, -1]
     # a one-candidate, one-chunk ant round from the root (1-row history), model and tape dynamics, action_horizon 1 and 2
     from ditreeonlineplanner_amd.engine import AntExpansionEngine

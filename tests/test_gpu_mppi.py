@@ -258,3 +258,33 @@ def test_known_obstacle_bends_the_controls_away_from_the_reference_path(ctx):
     assert out["unknown"][0] < 0.3                                 # drives through the cell it does not know about
     assert out["known"][1] is not None or out["known"][0] > 0.55   # never inside the occupied cell (half-width 0.5 + ball)
     assert out["known"][0] > 0.55, out["known"]
+
+
+def test_controller_step_at_config5_size(ctx):
+    """BASELINE config 5 as written: ONE controller step at K = 65 536 rollouts, T = 16, on-device noise -- against the numpy
+    restatement on the mirrored counter-hash noise: collided / goal flags exact, beta, eta, effective sample size and the
+    updated controls 1e-9 (relative where the quantity scales with K)."""
+    K, T = 65536, 16
+    m, maze, path, start = make(ctx, K, T, seed=4242)
+    state = np.array([path[250, 0], path[250, 1] - 0.15, -0.35, 2.8, 0.5, 0.02])       # towards the bottom wall: a share collides
+    rng = np.random.default_rng(8)
+    U = np.stack([rng.normal(0.5, 1.0, T), rng.normal(0.0, 0.3, T)], axis=1)
+    m.counter = 3
+    m._state.copy_(torch.as_tensor(state))
+    m._U.copy_(torch.as_tensor(U))
+    w = torch.zeros(K, dtype=torch.float64, device=ctx.device)
+    m.launch(UPD, weights=w)
+    kw = kw_of(m)
+    eps = OM.device_noise(4242, 3, K, T, kw["sigma"])
+    rc, rf, i0 = OM.rollout_costs(maze, state, U, path, m.env.goal, eps, **kw)
+    Un, wn, beta, eta, ess = OM.update(U, rc, eps, kw["lam"])
+    res = m._result.cpu().numpy()
+    flags = m._flags.cpu().numpy()
+    assert int(res[5]) == i0
+    assert np.array_equal(flags, rf), (np.bincount(flags, minlength=3), np.bincount(rf, minlength=3))
+    assert int(res[6]) == int((rf == 2).sum()) and 1000 < int(res[6]) < K - 1000
+    assert np.abs(m._costs.cpu().numpy() - rc).max() < 1e-9 * max(1.0, np.abs(rc).max())
+    assert abs(res[3] - beta) < 1e-9 * max(1.0, abs(beta)) and abs(res[4] - eta) < 1e-9 * eta and abs(res[7] - ess) < 1e-7 * ess
+    assert np.abs(m._U.cpu().numpy() - Un).max() < 1e-9
+    wg = w.cpu().numpy()
+    assert abs(wg.sum() - 1.0) < 1e-10 and np.abs(wg - wn).max() < 1e-9

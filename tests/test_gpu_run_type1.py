@@ -227,3 +227,34 @@ def test_planner_facade_run_type1(ctx):
     before = env3.prob_map.copy()
     path3, _ = pl3.plan()
     assert np.array_equal(env3.prob_map, before) and pl3.results["iterations"] > 0
+
+
+def test_extract_path_after_obstacle_against_the_reference_function(ctx):
+    """ditree_path_after_obstacle against goldens written by the reference's OWN RRT_Planner.extract_path_after_obstacle
+    (planners/RRT.py:83-111; tests/golden/make_golden.py pao): float32 paths, float64 and float32 env states -- numpy forms the
+    nearest-point distances in float64 when env.state is float64 (the f32 path is promoted) and in float32 right after
+    env.reset; the kernel does the same.  Checked: the nearest index itself and the returned remainder of the path."""
+    import ctypes as C
+    from ditreeonlineplanner_amd._lib import check, lib
+    g = golden("traces")
+    n = int(g["pao_n"])
+    assert n >= 80
+    seen64 = seen32 = 0
+    for i in range(n):
+        path, st, f32 = g[f"pao_{i}_path"], g[f"pao_{i}_state"], bool(g[f"pao_{i}_f32"])
+        mz = np.unpackbits(g[f"pao_{i}_maze"])[:400].reshape(20, 20).astype(np.float32)
+        exp = g[f"pao_{i}_expected"]
+        ctx.upload_maze(mz)
+        p_dev = dev(path)
+        out = torch.zeros(2, dtype=torch.int32, device="cuda")
+        cur = st.astype(np.float32).astype(np.float64) if f32 else st
+        check(ctx._h, lib().ditree_path_after_obstacle(ctx._h, p_dev.data_ptr(), 2, len(path), (C.c_double * 2)(*cur), int(f32),
+                                                        out.data_ptr(), ctx.stream), "path_after_obstacle")
+        c, k = (int(v) for v in out.cpu().numpy())
+        c_ref = int(np.argmin(np.linalg.norm((st.astype(np.float32) if f32 else st) - path, axis=1)))
+        assert c == c_ref, (i, f32, c, c_ref)
+        got = path[c:][k:]
+        assert np.array_equal(got, exp) and np.array_equal(ORRT.path_after_obstacle(path, st.astype(np.float32) if f32 else st, mz), exp)
+        seen64 += not f32
+        seen32 += f32
+    assert seen64 >= 40 and seen32 >= 40
