@@ -1051,9 +1051,17 @@ def main():
         eng.early_exit = 1
         e2 = _timed(step, args, dist, world, dev, rehearse)
         run = eng.rb.chunks_run[:Btot].float().mean().item()
+        rs = ctx.round_stats()
+        q = rs["candidates_per_wave"]
         ee = {"value": Btot * args.steps / e2, "ms_per_step": 1e3 * e2 / args.steps,
               "mean_denoiser_calls_per_candidate": run,
-              "note": "alive-candidate compaction on; informational, not comparable with `value`"}
+              "speedup_over_value": (Btot * args.steps / e2) / (Btot * args.steps / elapsed),
+              "tile_waves_per_layer": {"this_round": rs["tile_waves"], "denoiser_calls": rs["denoiser_calls"],
+                                       "candidates_per_wave": q, "without_early_exit": (H // A) * -(-Bper // q),
+                                       "one_ragged_call_per_chunk_would_cost": "sum over chunks of ceil(alive / candidates_per_wave)",
+                                       "ideal": run * Bper / q},
+              "note": "chunks run for alive candidates only, denoiser calls packed to whole tile-waves from the pool of ready "
+                      "(candidate, chunk) items (same tree, bit for bit); informational, not comparable with `value`"}
         eng.early_exit = 0
 
     # The plain bf16 instantiation beside the headline: 3x the rate, but 8 significand bits -- its round-level deviation

@@ -74,7 +74,7 @@ class RoundParams(C.Structure):
                 ("t0", C.POINTER(C.c_float)), ("dt", C.POINTER(C.c_float)), ("norm", C.POINTER(C.c_double)),
                 ("goal_xy", C.POINTER(C.c_double)), ("axis", C.POINTER(C.c_double)), ("lm_n", C.c_int32),
                 ("lm_size", C.c_double), ("s_global", C.c_double), ("early_exit", C.c_int32),
-                ("chunk_budget", C.c_void_p)]
+                ("ddpm_coef", C.POINTER(C.c_float)), ("step_noise", C.c_void_p), ("chunk_budget", C.c_void_p)]
 
 
 class AntRoundParams(C.Structure):
@@ -83,7 +83,8 @@ class AntRoundParams(C.Structure):
                 ("dt", C.POINTER(C.c_float)), ("norm", C.POINTER(C.c_double)), ("desired_goal", C.POINTER(C.c_double)),
                 ("goal_radius", C.c_double), ("ball_radius", C.c_double), ("axis", C.POINTER(C.c_double)), ("lm_n", C.c_int32),
                 ("lm_size", C.c_double), ("s_global", C.c_double), ("dynamics", C.c_int32), ("next_obs_tape", C.c_void_p),
-                ("model", C.POINTER(AntModel)), ("early_exit", C.c_int32), ("cond_out", C.c_void_p)]
+                ("model", C.POINTER(AntModel)), ("early_exit", C.c_int32), ("ddpm_coef", C.POINTER(C.c_float)),
+                ("step_noise", C.c_void_p), ("cond_out", C.c_void_p)]
 
 
 class MppiParams(C.Structure):
@@ -135,6 +136,7 @@ SIGNATURES = {
     "ditree_load_weights": (_i32, [_vp, _vp, _i64, C.c_char_p, _vp]),
     "ditree_denoise_reserve": (_i32, [_vp, _i32, _i32]),
     "ditree_denoise": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _pf, _pf, _pd, _vp, _vp, _vp]),
+    "ditree_denoise_ddpm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _pf, _pf, _pd, _vp, _vp, _vp]),
     "ditree_denoise_eval": (_i32, [_vp, _vp, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp]),
     "ditree_denoise_dims": (_i32, [_vp, C.POINTER(_i32)]),
     "ditree_denoise_status": (_i32, [_vp, C.POINTER(_i32), C.c_char_p, _i64, _i32, _vp]),
@@ -145,6 +147,7 @@ SIGNATURES = {
     "ditree_ant_round_begin": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), C.POINTER(AntRoundParams), _vp]),
     "ditree_ant_chunk_sample": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), C.POINTER(AntRoundParams), _i32, _vp]),
     "ditree_ant_chunk_step": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), C.POINTER(AntRoundParams), _i32, _vp, _vp]),
+    "ditree_round_stats": (_i32, [_vp, C.POINTER(_i32)]),
     "ditree_expand_round": (_i32, [_vp, C.POINTER(Tree), C.POINTER(Round), C.POINTER(RoundParams), _vp]),
 }
 

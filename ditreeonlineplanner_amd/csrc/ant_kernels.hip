@@ -84,13 +84,22 @@ ant_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, A
                    double s_global, double* __restrict__ states_out, ditree_strides sl, double* __restrict__ actions_out,
                    ditree_strides al, int32_t* __restrict__ steps_out, int64_t steps_stride, int32_t* __restrict__ chunks_run,
                    double* __restrict__ prev_action_io, uint8_t* __restrict__ has_prev_io, double* __restrict__ hist_out,
-                   int32_t* __restrict__ hist_n, const int32_t* __restrict__ idx, int act_dense) {
+                   int32_t* __restrict__ hist_n, const int32_t* __restrict__ idx, int act_dense, int chunk_from_counter,
+                   AntChunkStrides cs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   stage_maze_ant(lds, maze, rows * cols);
   const int ob = blockIdx.x * blockDim.x + threadIdx.x;
   if (ob >= B) return;
   const int b = idx ? idx[ob] : ob;
   if (status_io[b] != DITREE_ST_OK) return;
+  if (chunk_from_counter) {                               // pool-scheduled early-exit rounds: rows of one launch at different chunks
+    const int j = chunks_run[b];
+    if (states_out) states_out += (size_t)j * cs.states;
+    if (actions_out) actions_out += (size_t)j * cs.actions_out;
+    if (steps_out) steps_out += j;
+    if (!act_dense) actions += (size_t)j * cs.actions_in;
+    if (!MODEL) tape += (size_t)j * cs.tape;
+  }
   double s[ANT_S];
 #pragma unroll
   for (int k = 0; k < ANT_S; ++k) s[k] = state_io[(size_t)b * ANT_S + k];
@@ -169,7 +178,7 @@ void launch_ant_rollout(const unsigned char* maze, int rows, int cols, const Ant
                         int A, double gx, double gy, double goal_radius, double ball_radius, double s_global, double* states_out,
                         ditree_strides sl, double* actions_out, ditree_strides al, int32_t* steps_out, int64_t steps_stride,
                         int32_t* chunks_run, double* prev_action_io, uint8_t* has_prev_io, double* hist_out, int32_t* hist_n,
-                        const int32_t* idx, int act_dense, hipStream_t s) {
+                        const int32_t* idx, int act_dense, hipStream_t s, int chunk_from_counter, AntChunkStrides cs) {
   const size_t lds = ((size_t)rows * cols + 15) & ~(size_t)15;
   // one wave per work-group while the batch is small (a round's 4096 candidates: 64 CUs instead of 16), four once every SIMD
   // has a wave anyway
@@ -178,10 +187,11 @@ void launch_ant_rollout(const unsigned char* maze, int rows, int cols, const Ant
   if (model)
     hipLaunchKernelGGL(ant_rollout_kernel<true>, grid, dim3(blk), lds, s, maze, rows, cols, *model, state_io, actions, act_stride, tape,
                        tape_stride, status_io, B, A, gx, gy, goal_radius, ball_radius, s_global, states_out, sl, actions_out, al,
-                       steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, hist_out, hist_n, idx, act_dense);
+                       steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, hist_out, hist_n, idx, act_dense,
+                       chunk_from_counter, cs);
   else
     hipLaunchKernelGGL(ant_rollout_kernel<false>, grid, dim3(blk), lds, s, maze, rows, cols, AntModelArg{}, state_io, actions,
                        act_stride, tape, tape_stride, status_io, B, A, gx, gy, goal_radius, ball_radius, s_global, states_out, sl,
                        actions_out, al, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, hist_out, hist_n, idx,
-                       act_dense);
+                       act_dense, chunk_from_counter, cs);
 }

@@ -71,9 +71,24 @@ void launch_time_embed(float t, const float* W1, const float* b1, const float* W
                        hipStream_t s);
 void launch_prep_cond(const float* temb, const float* map_emb, int E, int E_ld, const float* cond, int G, void* out, int B,
                       int Kpad, int fmt, long long plane, hipStream_t s, int* sat = nullptr);
+// What the last projection does with the network output v of a sampler step:
+//   FLOW  x += v * dt                     (policies/fm_policy.py:183-196)
+//   RAW   x  = v                          (one raw network evaluation)
+//   DDPM  x0 = clip((x - sb v) / sa, -1, 1); x = c0 x0 + c1 x + sigma z   (policies/fm_policy.py:164-182 with a DDPM scheduler:
+//         epsilon prediction, clip_sample, fixed_small variance; z = the step's standard-normal noise, row r of it for dense row r
+//         = z[(z_idx ? z_idx[r] : z_row0 + r) * z_row + (l * D + d)]; sigma == 0 at the last step)
+struct FlowStep {
+  int mode;                 // 0 FLOW, 1 RAW, 2 DDPM
+  float dt;
+  float sb, sa, c0, c1, sigma;
+  const float* z;
+  long long z_row;
+  const int* z_idx;
+  int z_row0;
+};
 void launch_final_proj_flow(const void* Y, int C, int Lp, long long plane, const float* W, const float* bias, int D, float* x,
-                            float dt, const double* act_norm /*[mu[D], sigma[D]]*/, double* actions, int B, int P, int fmt,
-                            hipStream_t s, int raw = 0);
+                            FlowStep fs, const double* act_norm /*[mu[D], sigma[D]]*/, double* actions, int B, int P, int fmt,
+                            hipStream_t s);
 struct TapList {          // live (kh, kw) taps of a Conv2d on a small map
   int n;
   signed char kh[49], kw[49];

@@ -66,6 +66,11 @@ struct DenoiserState {
   int D = 2, P = 64, E = 400, G = 7, cond_dim = 663, lm = 20;
   int dims[3] = {512, 1024, 2048};
   bool loaded = false;
+  // DDPM loop of the NEXT denoise call (set by denoise_run_ddpm around denoise_core): coef (K, 5) = sb, sa, c0, c1, sigma per step
+  const float* ddpm_coef = nullptr;
+  const float* ddpm_z = nullptr;           // [dev] step noise, row r / step k at r * z_row + k * z_step
+  long long ddpm_z_row = 0, ddpm_z_step = 0;
+  int ddpm_row0 = 0;                       // first row of the current sub-batch (dense calls)
   // workspace
   int prec = -1, Bmax = 0;     // prec: the DITREE_PREC_* the workspace was built for; Bmax: samples the WORKSPACE holds
   int Buser = 0;               // samples the caller reserved for: calls up to this size are served in sub-batches of <= Bmax
@@ -995,6 +1000,33 @@ static int denoise_core_one(ditree_ctx* ctx, const float* noise, int64_t noise_s
                             const double* act_norm, double* actions, float* x_out, hipStream_t s, float t_scale, int raw,
                             int reuse_encoder);
 
+// The DDPM branch of the sampler (policies/fm_policy.py:164-182) as K steps inside the library: timesteps[k] is what the
+// sinusoidal embedding sees (the scheduler's integer k, NOT scaled by 20), coef (K, 5) the step's sb, sa, c0, c1, sigma,
+// z [dev] the standard-normal step noise (row r, step k at r * z_row + k * z_step; rows by noise_idx like the start noise).
+int denoise_run_ddpm(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const int32_t* noise_idx, const float* local_map,
+                     const float* cond, int B, int K, const float* timesteps, const float* coef, const float* z, int64_t z_row,
+                     int64_t z_step, const double* act_norm, double* actions, float* x_out, hipStream_t s) {
+  DenoiserState* st = ctx->dn;
+  if (!st || !st->loaded) return set_err(ctx, DITREE_E_STATE, "denoise: weights not loaded");
+  if (!coef || !timesteps || K < 1) return set_err(ctx, DITREE_E_ARG, "denoise_ddpm: schedule missing");
+  std::vector<float> ones((size_t)K, 1.0f);
+  st->ddpm_coef = coef; st->ddpm_z = z; st->ddpm_z_row = z_row; st->ddpm_z_step = z_step; st->ddpm_row0 = 0;
+  const int rc = denoise_core(ctx, noise, noise_stride, noise_idx, local_map, cond, B, K, timesteps, ones.data(), act_norm, actions,
+                              x_out, s, 1.0f, 0, 0);
+  st->ddpm_coef = nullptr; st->ddpm_z = nullptr;
+  return rc;
+}
+
+// Candidates per full wave of 256-row x 256-channel tiles over the chip's 256 CUs at the U-Net levels (all levels have the same
+// number of tiles: rows halve as channels double): 256 * 65536 / (P * down_dims[0]) -- 512 for the car network (P 64, 512
+// channels), 2048 for the ant network (P 16).  What early-exit rounds pack their denoiser calls to.
+int denoise_wave_quantum(ditree_ctx* ctx) {
+  DenoiserState* st = ctx->dn;
+  if (!st || !st->loaded) return 512;
+  const long long q = 256ll * 65536ll / ((long long)st->P * st->dims[0]);
+  return (int)std::max(64ll, std::min(q, 65536ll));
+}
+
 int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const int32_t* noise_idx, const float* local_map,
                 const float* cond, int B, int K, const float* t0, const float* dt, const double* act_norm, double* actions,
                 float* x_out, hipStream_t s) {
@@ -1017,15 +1049,18 @@ static int denoise_core(ditree_ctx* ctx, const float* noise, int64_t noise_strid
                             t_scale, raw, reuse_encoder);
   if (!noise || !local_map || !cond) return set_err(ctx, DITREE_E_ARG, "denoise: bad argument");
   const size_t PD = (size_t)st->P * st->D, LM = (size_t)st->lm * st->lm;
+  const int row0 = st->ddpm_row0;
   for (int b0 = 0; b0 < B; b0 += st->Bmax) {
     const int bn = std::min(st->Bmax, B - b0);
+    st->ddpm_row0 = row0 + (noise_idx ? 0 : b0);
     // (the map embedding of a previous call covers one sub-batch only: larger calls recompute it)
     const int rc = denoise_core_one(ctx, noise_idx ? noise : noise + (size_t)b0 * noise_stride, noise_stride,
                                     noise_idx ? noise_idx + b0 : nullptr, local_map + (size_t)b0 * LM, cond + (size_t)b0 * st->G, bn,
                                     K, t0, dt, act_norm, actions ? actions + (size_t)b0 * PD : nullptr,
                                     x_out ? x_out + (size_t)b0 * PD : nullptr, s, t_scale, raw, 0);
-    if (rc) return rc;
+    if (rc) { st->ddpm_row0 = row0; return rc; }
   }
+  st->ddpm_row0 = row0;
   return DITREE_OK;
 }
 
@@ -1099,9 +1134,19 @@ static int denoise_core_one(ditree_ctx* ctx, const float* noise, int64_t noise_s
     for (auto& op : st->unet_ops) op(B, Bp, s);
     const bool last = (k == K - 1);
     st->note_other();
+    FlowStep fs{};
+    fs.mode = raw ? 1 : 0;
+    fs.dt = dt[k];
+    if (st->ddpm_coef) {
+      const float* c = st->ddpm_coef + 5 * k;
+      fs.mode = 2; fs.sb = c[0]; fs.sa = c[1]; fs.c0 = c[2]; fs.c1 = c[3]; fs.sigma = c[4];
+      fs.z = st->ddpm_z ? st->ddpm_z + (long long)k * st->ddpm_z_step : nullptr;
+      fs.z_row = st->ddpm_z_row; fs.z_idx = noise_idx; fs.z_row0 = st->ddpm_row0;
+      if (fs.sigma != 0.0f && !fs.z) return set_err(ctx, DITREE_E_ARG, "denoise: a DDPM step with sigma > 0 needs step noise");
+    }
     launch_final_proj_flow(st->final_h.p, st->final_h.C, st->final_h.Lp(), st->final_h.plane, st->dev_f["unet.final_conv.1.weight"],
-                           st->dev_f["unet.final_conv.1.bias"], st->D, st->x_cur, dt[k], act_norm,
-                           (last && actions) ? actions : nullptr, B, st->P, uf, s, raw);
+                           st->dev_f["unet.final_conv.1.bias"], st->D, st->x_cur, fs, act_norm,
+                           (last && actions) ? actions : nullptr, B, st->P, uf, s);
   }
   } catch (const std::exception& e) {
     return set_err(ctx, DITREE_E_ARG, std::string("denoise: ") + e.what());
@@ -1189,6 +1234,17 @@ int32_t ditree_denoise(ditree_ctx* ctx, const float* noise, const float* local_m
   if (!ctx->dn) return set_err(ctx, DITREE_E_STATE, "denoise: weights not loaded");
   return denoise_run(ctx, noise, (int64_t)ctx->dn->P * ctx->dn->D, nullptr, local_map, cond, B, K, t0, dt, act_norm, actions, x_out,
                      (hipStream_t)stream);
+}
+
+int32_t ditree_denoise_ddpm(ditree_ctx* ctx, const float* noise, const float* step_noise, const float* local_map, const float* cond,
+                            int32_t B, int32_t K, const float* timesteps, const float* coef, const double* act_norm,
+                            double* actions, float* x_out, void* stream) {
+  if (!ctx) return DITREE_E_ARG;
+  if (!ctx->dn) return set_err(ctx, DITREE_E_STATE, "denoise_ddpm: weights not loaded");
+  if (B == 0) return DITREE_OK;
+  const int64_t PD = (int64_t)ctx->dn->P * ctx->dn->D;
+  return denoise_run_ddpm(ctx, noise, PD, nullptr, local_map, cond, B, K, timesteps, coef, step_noise, (int64_t)K * PD, PD, act_norm,
+                          actions, x_out, (hipStream_t)stream);
 }
 
 int32_t ditree_denoise_eval(ditree_ctx* ctx, const float* sample, const float* local_map, const float* cond, int32_t B,

@@ -2397,8 +2397,8 @@ template <int PREC, int D>
 __global__ void __launch_bounds__(256) final_proj_flow_kernel(const void* __restrict__ Y, int C, int Lp, long long plane,
                                                               const float* __restrict__ W /*[D][C]*/,
                                                               const float* __restrict__ bias,
-                                                              float* __restrict__ x /*[B][P][D] in/out*/, float dt,
-                                                              ActNormArg nm, double* __restrict__ actions, int B, int P, int raw) {
+                                                              float* __restrict__ x /*[B][P][D] in/out*/, FlowStep fs,
+                                                              ActNormArg nm, double* __restrict__ actions, int B, int P) {
   const long long pos = blockIdx.x * 4LL + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (pos >= (long long)B * P) return;
@@ -2446,19 +2446,33 @@ __global__ void __launch_bounds__(256) final_proj_flow_kernel(const void* __rest
     for (int d = 1; d < D; ++d) if (lane == d) { sv = s[d]; sg = nm.sg[d]; mu = nm.mu[d]; }
     const float v = sv + bias[lane];
     const long long xi = pos * D + lane;
-    const float xn = raw ? v : x[xi] + v * dt;              // naction + vel_pred * dt[k]; raw: the network output itself
+    float xn;
+    if (fs.mode == 0) {
+      xn = x[xi] + v * fs.dt;                                 // naction + vel_pred * dt[k]
+    } else if (fs.mode == 1) {
+      xn = v;                                                 // raw: the network output itself
+    } else {                                                  // DDPM step, float32 as the scheduler's tensors
+      const float xc = x[xi];
+      float x0 = (xc - fs.sb * v) / fs.sa;
+      x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+      xn = fs.c0 * x0 + fs.c1 * xc;
+      if (fs.sigma != 0.0f) {
+        const long long zr = fs.z_idx ? (long long)fs.z_idx[b] : (long long)fs.z_row0 + b;
+        xn += fs.sigma * fs.z[zr * fs.z_row + (long long)l * D + lane];
+      }
+    }
     x[xi] = xn;
     if (actions != nullptr) actions[xi] = (double)xn * sg + mu;     // float32 * float64 -> float64 (:203)
   }
 }
 // act_norm = [mu[0..D), sigma[0..D)] (host)
 void launch_final_proj_flow(const void* Y, int C, int Lp, long long plane, const float* W, const float* bias, int D, float* x,
-                            float dt, const double* act_norm, double* actions, int B, int P, int fmt, hipStream_t s, int raw) {
+                            FlowStep fs, const double* act_norm, double* actions, int B, int P, int fmt, hipStream_t s) {
   long long pos = (long long)B * P;
   dim3 grid((unsigned)((pos + 3) / 4)), block(256);
   ActNormArg nm{};
   for (int d = 0; d < D && d < 8; ++d) { nm.mu[d] = act_norm[d]; nm.sg[d] = act_norm[D + d]; }
-#define CALLD(F, DD) DN_LAUNCH((final_proj_flow_kernel<F, DD>), grid, block, 0, s, Y, C, Lp, plane, W, bias, x, dt, nm, actions, B, P, raw)
+#define CALLD(F, DD) DN_LAUNCH((final_proj_flow_kernel<F, DD>), grid, block, 0, s, Y, C, Lp, plane, W, bias, x, fs, nm, actions, B, P)
 #define CALL(F) do { if (D == 2) CALLD(F, 2); else if (D == 8) CALLD(F, 8); else throw std::runtime_error("final projection: action_dim must be 2 or 8"); } while (0)
   DISPATCH_FMT(fmt, CALL)
 #undef CALL

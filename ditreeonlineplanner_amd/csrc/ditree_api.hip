@@ -15,11 +15,24 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
                            double* states_out, ditree_strides states_stride, double* actions_out, ditree_strides actout_stride,
                            int32_t* steps_out, int64_t steps_stride, int32_t* chunks_run, double* prev_action_io,
                            uint8_t* has_prev_io, const int32_t* idx, int act_dense, hipStream_t s, const int32_t* budget,
-                           int chunk_j);
+                           int chunk_j, ChunkStrides cs = ChunkStrides{0, 0, 0});
 int denoise_run(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const int32_t* noise_idx, const float* local_map,
                 const float* cond, int B, int K, const float* t0, const float* dt, const double* act_norm, double* actions,
                 float* x_out, hipStream_t s);
+int denoise_run_ddpm(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const int32_t* noise_idx, const float* local_map,
+                     const float* cond, int B, int K, const float* timesteps, const float* coef, const float* z, int64_t z_row,
+                     int64_t z_step, const double* act_norm, double* actions, float* x_out, hipStream_t s);
 void denoise_destroy(ditree_ctx* ctx);
+
+// One sampler call of a round: K flow steps, or (coef != NULL) the DDPM loop with the round's (B, n_chunks, K, P, D) step noise.
+// row_noise_stride: floats between the noise rows the index list (or the dense row number) addresses.
+static int round_sampler(ditree_ctx* ctx, const float* noise, int64_t noise_stride, const int32_t* nidx, const float* lmap,
+                         const float* cond, int n, int K, const float* t0, const float* dt, const float* coef, const float* z,
+                         int64_t z_row, int64_t PD, const double* act_norm, double* actions, hipStream_t s) {
+  if (coef)
+    return denoise_run_ddpm(ctx, noise, noise_stride, nidx, lmap, cond, n, K, t0, coef, z, z_row, PD, act_norm, actions, nullptr, s);
+  return denoise_run(ctx, noise, noise_stride, nidx, lmap, cond, n, K, t0, dt, act_norm, actions, nullptr, s);
+}
 
 int set_err(ditree_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
@@ -63,12 +76,13 @@ void ditree_ctx_destroy(ditree_ctx* ctx) {
   if (ctx->cond) hipFree(ctx->cond);
   if (ctx->act64) hipFree(ctx->act64);
   if (ctx->alive_idx) hipFree(ctx->alive_idx);
+  if (ctx->alive_nrow) hipFree(ctx->alive_nrow);
   if (ctx->alive_cnt) hipFree(ctx->alive_cnt);
   if (ctx->alive_cnt_host) hipHostFree(ctx->alive_cnt_host);
   if (ctx->path_dev) hipFree(ctx->path_dev);
   if (ctx->mppi_partial) hipFree(ctx->mppi_partial);
   if (ctx->mppi_minkey) hipFree(ctx->mppi_minkey);
-  void* ant[] = {ctx->ant_hist, ctx->ant_hist_n, ctx->ant_idx, ctx->ant_prev, ctx->ant_hasprev, ctx->ant_cond, ctx->ant_lmap, ctx->ant_act};
+  void* ant[] = {ctx->ant_hist, ctx->ant_hist_n, ctx->ant_idx, ctx->ant_nrow, ctx->ant_prev, ctx->ant_hasprev, ctx->ant_cond, ctx->ant_lmap, ctx->ant_act};
   for (void* q : ant) if (q) hipFree(q);
   delete ctx;
 }
@@ -512,7 +526,7 @@ static int ensure_scratch(ditree_ctx* ctx, int B, int lm_n, int P) {
   if (B <= ctx->scratch_B && lm_n <= ctx->scratch_lm && P <= ctx->scratch_P) return DITREE_OK;
   HIP_TRY(ctx, hipDeviceSynchronize());
   void** ptrs[] = {(void**)&ctx->cur_state, (void**)&ctx->prev_action, (void**)&ctx->has_prev, (void**)&ctx->lmap,
-                   (void**)&ctx->cond, (void**)&ctx->act64, (void**)&ctx->alive_idx, (void**)&ctx->alive_cnt};
+                   (void**)&ctx->cond, (void**)&ctx->act64, (void**)&ctx->alive_idx, (void**)&ctx->alive_nrow, (void**)&ctx->alive_cnt};
   int nb = B > ctx->scratch_B ? B : ctx->scratch_B;
   int nl = lm_n > ctx->scratch_lm ? lm_n : ctx->scratch_lm;
   int np = P > ctx->scratch_P ? P : ctx->scratch_P;
@@ -528,6 +542,7 @@ static int ensure_scratch(ditree_ctx* ctx, int B, int lm_n, int P) {
   HIP_TRY(ctx, hipMalloc((void**)&ctx->cond, (size_t)nb * 7 * sizeof(float)));
   HIP_TRY(ctx, hipMalloc((void**)&ctx->act64, (size_t)nb * np * 2 * sizeof(double)));
   HIP_TRY(ctx, hipMalloc((void**)&ctx->alive_idx, (size_t)nb * sizeof(int32_t)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->alive_nrow, (size_t)nb * sizeof(int32_t)));
   HIP_TRY(ctx, hipMalloc((void**)&ctx->alive_cnt, 16));
   if (!ctx->alive_cnt_host) HIP_TRY(ctx, hipHostMalloc((void**)&ctx->alive_cnt_host, 16, hipHostMallocDefault));
   ctx->scratch_B = nb;
@@ -551,7 +566,8 @@ static int check_ant_round(ditree_ctx* ctx, const ditree_tree* tree, const ditre
   if (need_sampler) {
     if (!p->noise && !p->inject_actions) return set_err(ctx, DITREE_E_ARG, "expand_round_ant: neither noise nor inject_actions");
     if (!p->inject_actions) {
-      if (!p->t0 || !p->dt || p->K < 1) return set_err(ctx, DITREE_E_ARG, "expand_round_ant: flow schedule missing");
+      if (!p->t0 || (!p->dt && !p->ddpm_coef) || p->K < 1) return set_err(ctx, DITREE_E_ARG, "expand_round_ant: flow schedule missing");
+      if (p->ddpm_coef && !p->step_noise && p->K > 1) return set_err(ctx, DITREE_E_ARG, "expand_round_ant: the DDPM branch needs step_noise");
       int32_t d5[5];
       if (ditree_denoise_dims(ctx, d5) != DITREE_OK) return DITREE_E_STATE;
       if (d5[1] != ANT_D || d5[3] != 97 || p->lm_n != d5[2] || p->P != d5[0])
@@ -567,7 +583,7 @@ static int check_ant_round(ditree_ctx* ctx, const ditree_tree* tree, const ditre
 static int ensure_ant_scratch(ditree_ctx* ctx, int B, int P, int lm) {
   if (B <= ctx->ant_B && P <= ctx->ant_P && lm <= ctx->ant_lm) return DITREE_OK;
   HIP_TRY(ctx, hipDeviceSynchronize());
-  void** ptrs[] = {(void**)&ctx->ant_hist, (void**)&ctx->ant_hist_n, (void**)&ctx->ant_idx, (void**)&ctx->ant_prev,
+  void** ptrs[] = {(void**)&ctx->ant_hist, (void**)&ctx->ant_hist_n, (void**)&ctx->ant_idx, (void**)&ctx->ant_nrow, (void**)&ctx->ant_prev,
                    (void**)&ctx->ant_hasprev, (void**)&ctx->ant_cond, (void**)&ctx->ant_lmap, (void**)&ctx->ant_act};
   const size_t nb = (size_t)std::max(B, ctx->ant_B), np = (size_t)std::max(P, ctx->ant_P), nl = (size_t)std::max(lm, ctx->ant_lm);
   ctx->ant_B = ctx->ant_P = ctx->ant_lm = 0;            // a failed allocation below leaves "nothing reserved", not stale sizes
@@ -575,6 +591,7 @@ static int ensure_ant_scratch(ditree_ctx* ctx, int B, int P, int lm) {
   HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_hist, nb * 3 * ANT_S * sizeof(double)));
   HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_hist_n, nb * sizeof(int32_t)));
   HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_idx, nb * sizeof(int32_t)));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_nrow, nb * sizeof(int32_t)));
   HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_prev, nb * ANT_D * sizeof(double)));
   HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_hasprev, nb));
   HIP_TRY(ctx, hipMalloc((void**)&ctx->ant_cond, nb * 97 * sizeof(float)));
@@ -664,8 +681,9 @@ int32_t ditree_ant_chunk_sample(ditree_ctx* ctx, const ditree_tree* tree, const 
     HIP_TRY(ctx, hipGetLastError());
     return DITREE_OK;
   }
-  rc = denoise_run(ctx, p->noise + (size_t)j * P * ANT_D, (int64_t)nC * P * ANT_D, idx, ctx->ant_lmap, ctx->ant_cond, n_run, p->K,
-                   p->t0, p->dt, p->norm + 54, ctx->ant_act, nullptr, s);
+  rc = round_sampler(ctx, p->noise + (size_t)j * P * ANT_D, (int64_t)nC * P * ANT_D, idx, ctx->ant_lmap, ctx->ant_cond, n_run, p->K, p->t0,
+                     p->dt, p->ddpm_coef, p->step_noise ? p->step_noise + (size_t)j * p->K * P * ANT_D : nullptr,
+                     (int64_t)nC * p->K * P * ANT_D, (int64_t)P * ANT_D, p->norm + 54, ctx->ant_act, s);
   if (rc) return rc;
   launch_ant_copy_actions(ctx->ant_act, (int64_t)P * ANT_D, 1, idx, round->status, n_run, A, round->actions + (size_t)j * A * ANT_D,
                           ac_stride, s);
@@ -736,6 +754,60 @@ int32_t ditree_expand_round_ant(ditree_ctx* ctx, const ditree_tree* tree, const 
   rc = ditree_ant_round_begin(ctx, tree, round, p, stream);
   if (rc) return rc;
   const int nC = tree->n_chunks, A = tree->A;
+  if (p->early_exit && round->B > 0) {
+    // the pool-scheduled form of the car round's early exit (ditree_expand_round): calls packed to whole tile-waves (2048
+    // candidates for the ant network) from the ready list, rows of one launch at different chunks of their edges
+    if (p->cond_out) return set_err(ctx, DITREE_E_ARG, "expand_round_ant: cond_out is a test output of rounds without early_exit");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = round->B;
+    const int quantum = p->inject_actions ? 64 : denoise_wave_quantum(ctx);
+    AxisArg ax;
+    rc = fill_axis(ctx, p->axis, p->lm_n, &ax);
+    if (rc) return rc;
+    AntNormArg nm;
+    for (int i = 0; i < 27; ++i) { nm.obs_mean[i] = p->norm[i]; nm.obs_std[i] = p->norm[27 + i]; }
+    for (int i = 0; i < 8; ++i) { nm.act_mean[i] = p->norm[54 + i]; nm.act_std[i] = p->norm[62 + i]; }
+    const int64_t st_stride = (int64_t)nC * (A + 1) * ANT_S, ac_stride = (int64_t)nC * A * ANT_D;
+    const AntChunkStrides cs{(int64_t)(A + 1) * ANT_S, (int64_t)A * ANT_D, (int64_t)P * ANT_D, (int64_t)A * ANT_S};
+    int calls = 0, waves = 0;
+    for (;;) {
+      launch_compact_ready(round->status, round->chunks_run, nullptr, nC, B, ctx->ant_idx, ctx->ant_nrow, ctx->alive_cnt, s);
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->alive_cnt_host, ctx->alive_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      HIP_TRY(ctx, hipStreamSynchronize(s));
+      const int n_ready = *ctx->alive_cnt_host;
+      if (n_ready <= 0) break;
+      const int take = n_ready < quantum ? n_ready : (n_ready / quantum) * quantum;
+      if (++calls > nC * (B / quantum + 2) + 8) return set_err(ctx, DITREE_E_STATE, "expand_round_ant: early-exit scheduler did not drain");
+      waves += (take + quantum - 1) / quantum;
+      const double* acts;
+      int64_t act_stride;
+      int act_dense = 1;
+      if (p->inject_actions) {
+        acts = p->inject_actions;
+        act_stride = (int64_t)nC * P * ANT_D;
+        act_dense = 0;
+      } else {
+        launch_local_map(ctx->maze, ctx->rows, ctx->cols, round->end_state, round->status, ctx->ant_idx, take, p->lm_n, ax, p->s_global,
+                         1, ctx->ant_lmap, s, ANT_S);
+        launch_cond_vector_ant(ctx->ant_hist, 3, ctx->ant_hist_n, ctx->ant_prev, ctx->ant_hasprev, p->cond_goal, ctx->ant_idx, take, nm,
+                               p->lm_size, ctx->ant_cond, s);
+        rc = round_sampler(ctx, p->noise, (int64_t)P * ANT_D, ctx->ant_nrow, ctx->ant_lmap, ctx->ant_cond, take, p->K, p->t0, p->dt,
+                           p->ddpm_coef, p->step_noise, (int64_t)p->K * P * ANT_D, (int64_t)P * ANT_D, p->norm + 54, ctx->ant_act, s);
+        if (rc) return rc;
+        acts = ctx->ant_act;
+        act_stride = (int64_t)P * ANT_D;
+      }
+      launch_ant_rollout(ctx->maze, ctx->rows, ctx->cols, model, round->end_state, acts, act_stride, p->next_obs_tape,
+                         (int64_t)nC * A * ANT_S, round->status, take, A, p->desired_goal[0], p->desired_goal[1], p->goal_radius,
+                         p->ball_radius, p->s_global, round->states, ditree_strides{st_stride, ANT_S, 1}, round->actions,
+                         ditree_strides{ac_stride, ANT_D, 1}, round->chunk_steps, nC, round->chunks_run, ctx->ant_prev, ctx->ant_hasprev,
+                         ctx->ant_hist, ctx->ant_hist_n, ctx->ant_idx, act_dense, s, 1, cs);
+    }
+    ctx->ee_calls = calls;
+    ctx->ee_waves = waves;
+    HIP_TRY(ctx, hipGetLastError());
+    return DITREE_OK;
+  }
   for (int j = 0; j < nC; ++j) {
     rc = ditree_ant_chunk_sample(ctx, tree, round, p, j, stream);
     if (rc) return rc;
@@ -767,6 +839,15 @@ int32_t ditree_chunk_budget(ditree_ctx* ctx, const ditree_tree* tree, const doub
   return DITREE_OK;
 }
 
+int32_t ditree_round_stats(ditree_ctx* ctx, int32_t* stats4) {
+  if (!ctx || !stats4) return DITREE_E_ARG;
+  stats4[0] = ctx->ee_calls;
+  stats4[1] = ctx->ee_waves;
+  stats4[2] = denoise_wave_quantum(ctx);
+  stats4[3] = 0;
+  return DITREE_OK;
+}
+
 int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
                             const ditree_round_params* p, void* stream) {
   if (!ctx) return DITREE_E_ARG;
@@ -778,8 +859,10 @@ int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditr
   if (!p || !p->samples || !p->cond_goal || !p->norm || !p->goal_xy || !p->axis || p->n_nodes <= 0 ||
       p->n_nodes > tree->capacity || p->P < tree->A || (!p->noise && !p->inject_actions))
     return set_err(ctx, DITREE_E_ARG, "expand_round: bad parameters");
-  if (!p->inject_actions && (!p->t0 || !p->dt || p->K <= 0))
+  if (!p->inject_actions && (!p->t0 || (!p->dt && !p->ddpm_coef) || p->K <= 0))
     return set_err(ctx, DITREE_E_ARG, "expand_round: flow schedule missing");
+  if (!p->inject_actions && p->ddpm_coef && !p->step_noise && p->K > 1)
+    return set_err(ctx, DITREE_E_ARG, "expand_round: the DDPM branch needs step_noise (B, n_chunks, K, P, 2)");
   if (tree->state_dim != 6 || tree->action_dim != 2)
     return set_err(ctx, DITREE_E_ARG, "expand_round: the car round needs a tree with state_dim 6 / action_dim 2 (ant: ditree_expand_round_ant)");
   const int B = round->B, A = tree->A, nC = tree->n_chunks, P = p->P;
@@ -805,12 +888,60 @@ int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditr
   launch_nn_argmin(p->samples, 6, B, tree->xy, p->n_nodes, round->parent, tree->state, tree->last_action,
                    tree->has_prev, ctx->cur_state, ctx->prev_action, ctx->has_prev, s);
   const int64_t st_stride = (int64_t)nC * (A + 1) * 6, ac_stride = (int64_t)nC * A * 2;
-  // Early exit (p->early_exit): after every chunk the still-alive candidates are compacted into an index
-  // list and the next chunk's map / conditioning / denoiser / rollout run on those rows only -- what the
-  // reference does by abandoning a collided edge (planners/RRT.py:179-184).  Costs one 4-byte D2H per chunk.
-  int n_run = B;                              // rows processed in the current chunk
-  const int32_t* idx = nullptr;               // nullptr = identity (chunk 0, or early exit disabled)
-  for (int j = 0; j < nC && n_run > 0; ++j) {
+  // Early exit (p->early_exit): what the reference does by abandoning a collided edge (planners/RRT.py:179-184) -- a chunk runs
+  // only for candidates that are still alive.  A denoiser call costs whole WAVES of tiles (every layer has rows / quantum
+  // tile-waves on the 256 CUs, quantum = 512 candidates for the car network), so the calls are packed to whole waves from a
+  // POOL of ready (candidate, next chunk) items instead of one ragged call per chunk: after every call the ready list --
+  // ordered by chunks finished, the candidates furthest behind first -- is rebuilt on the device, and the next call takes the
+  // largest multiple of the quantum from its head (everything, once less than one quantum is left).  Rows of one launch may
+  // sit at different chunks of their edges (chunk index = the candidate's chunks_run counter).  All candidates of a round see
+  // the same tree snapshot and every kernel treats rows independently, so the results are bit-identical to the plain chunk
+  // loop (tests: traces, rounds, full-size rounds).  Costs one 4-byte D2H per call.
+  if (p->early_exit) {
+    const int quantum = p->inject_actions ? 64 : denoise_wave_quantum(ctx);
+    const ChunkStrides cs{(int64_t)(A + 1) * 6, (int64_t)A * 2, (int64_t)P * 2};
+    int calls = 0, waves = 0;
+    for (;;) {
+      launch_compact_ready(round->status, round->chunks_run, p->chunk_budget, nC, B, ctx->alive_idx, ctx->alive_nrow, ctx->alive_cnt, s);
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->alive_cnt_host, ctx->alive_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      HIP_TRY(ctx, hipStreamSynchronize(s));
+      const int n_ready = *ctx->alive_cnt_host;
+      if (n_ready <= 0) break;
+      const int take = n_ready < quantum ? n_ready : (n_ready / quantum) * quantum;
+      if (++calls > nC * (B / quantum + 2) + 8) return set_err(ctx, DITREE_E_STATE, "expand_round: early-exit scheduler did not drain");
+      waves += (take + quantum - 1) / quantum;
+      const int32_t* idx = ctx->alive_idx;
+      const double* acts;
+      int64_t act_stride;
+      int act_dense = 1;
+      if (p->inject_actions) {
+        acts = p->inject_actions;                 // (B, n_chunks, P, 2): the kernel adds the candidate's chunk offset
+        act_stride = (int64_t)nC * P * 2;
+        act_dense = 0;
+      } else {
+        launch_local_map(ctx->maze, ctx->rows, ctx->cols, ctx->cur_state, round->status, idx, take, p->lm_n, ax, p->s_global, 1,
+                         ctx->lmap, s);
+        launch_cond_vector(ctx->cur_state, ctx->prev_action, ctx->has_prev, p->cond_goal, idx, take, nm, p->lm_size, ctx->cond, s);
+        double an[4] = {p->norm[12], p->norm[13], p->norm[14], p->norm[15]};
+        // rows of the (B * n_chunks, ...) views: start noise (P, 2) and, for the DDPM branch, step noise (K, P, 2)
+        rc = round_sampler(ctx, p->noise, (int64_t)P * 2, ctx->alive_nrow, ctx->lmap, ctx->cond, take, p->K, p->t0, p->dt,
+                           p->ddpm_coef, p->step_noise, (int64_t)p->K * P * 2, (int64_t)P * 2, an, ctx->act64, s);
+        if (rc) return rc;
+        acts = ctx->act64;
+        act_stride = (int64_t)P * 2;
+      }
+      launch_car_rollout_ex(ctx->maze, ctx->rows, ctx->cols, ctx->cur_state, acts, act_stride, round->status, take, A,
+                            p->goal_xy[0], p->goal_xy[1], round->states, ditree_strides{st_stride, 6, 1}, round->actions,
+                            ditree_strides{ac_stride, 2, 1}, round->chunk_steps, nC, round->chunks_run, ctx->prev_action,
+                            ctx->has_prev, idx, act_dense, s, p->chunk_budget, -1, cs);
+    }
+    ctx->ee_calls = calls;
+    ctx->ee_waves = waves;
+    HIP_TRY(ctx, hipMemcpyAsync(round->end_state, ctx->cur_state, (size_t)B * 6 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(ctx, hipGetLastError());
+    return DITREE_OK;
+  }
+  for (int j = 0; j < nC; ++j) {
     const double* acts;
     int64_t act_stride;
     int act_dense = 1;
@@ -819,28 +950,22 @@ int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditr
       act_stride = (int64_t)nC * P * 2;
       act_dense = 0;                          // the tape is indexed by candidate
     } else {
-      launch_local_map(ctx->maze, ctx->rows, ctx->cols, ctx->cur_state, round->status, idx, n_run, p->lm_n, ax,
+      launch_local_map(ctx->maze, ctx->rows, ctx->cols, ctx->cur_state, round->status, nullptr, B, p->lm_n, ax,
                        p->s_global, 1, ctx->lmap, s);
-      launch_cond_vector(ctx->cur_state, ctx->prev_action, ctx->has_prev, p->cond_goal, idx, n_run, nm, p->lm_size,
+      launch_cond_vector(ctx->cur_state, ctx->prev_action, ctx->has_prev, p->cond_goal, nullptr, B, nm, p->lm_size,
                          ctx->cond, s);
       double an[4] = {p->norm[12], p->norm[13], p->norm[14], p->norm[15]};
-      rc = denoise_run(ctx, p->noise + (size_t)j * P * 2, (int64_t)nC * P * 2, idx, ctx->lmap, ctx->cond, n_run, p->K,
-                       p->t0, p->dt, an, ctx->act64, nullptr, s);
+      rc = round_sampler(ctx, p->noise + (size_t)j * P * 2, (int64_t)nC * P * 2, nullptr, ctx->lmap, ctx->cond, B, p->K, p->t0, p->dt,
+                         p->ddpm_coef, p->step_noise ? p->step_noise + (size_t)j * p->K * P * 2 : nullptr,
+                         (int64_t)nC * p->K * P * 2, (int64_t)P * 2, an, ctx->act64, s);
       if (rc) return rc;
       acts = ctx->act64;
       act_stride = (int64_t)P * 2;
     }
-    launch_car_rollout_ex(ctx->maze, ctx->rows, ctx->cols, ctx->cur_state, acts, act_stride, round->status, n_run, A,
+    launch_car_rollout_ex(ctx->maze, ctx->rows, ctx->cols, ctx->cur_state, acts, act_stride, round->status, B, A,
                           p->goal_xy[0], p->goal_xy[1], round->states + (size_t)j * (A + 1) * 6, ditree_strides{st_stride, 6, 1},
                           round->actions + (size_t)j * A * 2, ditree_strides{ac_stride, 2, 1}, round->chunk_steps + j, nC,
-                          round->chunks_run, ctx->prev_action, ctx->has_prev, idx, act_dense, s, p->chunk_budget, j);
-    if (p->early_exit && j + 1 < nC) {
-      launch_compact_alive(round->status, B, ctx->alive_idx, ctx->alive_cnt, s, p->chunk_budget, j + 1);
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->alive_cnt_host, ctx->alive_cnt, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-      HIP_TRY(ctx, hipStreamSynchronize(s));
-      n_run = *ctx->alive_cnt_host;
-      idx = ctx->alive_idx;
-    }
+                          round->chunks_run, ctx->prev_action, ctx->has_prev, nullptr, act_dense, s, p->chunk_budget, j);
   }
   HIP_TRY(ctx, hipMemcpyAsync(round->end_state, ctx->cur_state, (size_t)B * 6 * sizeof(double),
                               hipMemcpyDeviceToDevice, s));

@@ -41,7 +41,9 @@ struct ditree_ctx {
   double* act64 = nullptr;          // (B,P,2)
   int scratch_lm = 0, scratch_P = 0;
   int32_t* alive_idx = nullptr;     // (B,) compacted candidate indices (early-exit rounds)
+  int32_t* alive_nrow = nullptr;    // (B,) their rows of the (B * n_chunks, P, D) noise view
   int32_t* alive_cnt = nullptr;     // device scalar
+  int ee_calls = 0, ee_waves = 0;   // denoiser calls / tile-waves of the last early-exit round (ditree_round_stats)
   int32_t* alive_cnt_host = nullptr;  // pinned host copy
   double* path_dev = nullptr;       // reference path xy for the fallback selection
   int path_cap = 0;
@@ -50,6 +52,7 @@ struct ditree_ctx {
   double* ant_hist = nullptr;
   int32_t* ant_hist_n = nullptr;
   int32_t* ant_idx = nullptr;       // alive candidates of an early-exit round
+  int32_t* ant_nrow = nullptr;      // their rows of the (B * n_chunks, P, 8) noise view
   int ant_n_run = 0;                // rows the current chunk runs on (ditree_ant_chunk_sample -> _step)
   const int32_t* ant_run_idx = nullptr;
   double* ant_prev = nullptr;
@@ -94,6 +97,7 @@ void launch_path_after_obstacle(const float* path, int stride, int P, double cx,
                                 int rows, int cols, int32_t* out, hipStream_t s);
 // ant_kernels.hip
 struct AntModelArg;
+struct AntChunkStrides { int64_t states, actions_out, actions_in, tape; };
 void launch_ant_collision(const unsigned char* maze, int rows, int cols, const double* state, int stride, int B, double ball_radius,
                           double s_global, uint8_t* out, hipStream_t s);
 void launch_ant_gather_hist(const int32_t* parent, const double* node_hist, const int32_t* node_hist_n, int B, double* hist,
@@ -105,7 +109,13 @@ void launch_ant_rollout(const unsigned char* maze, int rows, int cols, const Ant
                         int A, double gx, double gy, double goal_radius, double ball_radius, double s_global, double* states_out,
                         ditree_strides sl, double* actions_out, ditree_strides al, int32_t* steps_out, int64_t steps_stride,
                         int32_t* chunks_run, double* prev_action_io, uint8_t* has_prev_io, double* hist_out, int32_t* hist_n,
-                        const int32_t* idx, int act_dense, hipStream_t s);
+                        const int32_t* idx, int act_dense, hipStream_t s, int chunk_from_counter = 0,
+                        AntChunkStrides cs = AntChunkStrides{0, 0, 0, 0});
+// per-chunk strides (doubles) of the round's row outputs / the injected action tape, for launches whose rows sit at different chunks
+struct ChunkStrides { int64_t states, actions_out, actions_in; };
+void launch_compact_ready(const int32_t* status, const int32_t* chunks_run, const int32_t* budget, int n_chunks, int B,
+                          int32_t* idx_out, int32_t* nrow_out, int32_t* count, hipStream_t s);
+int denoise_wave_quantum(ditree_ctx* ctx);
 void launch_compact_alive(const int32_t* status, int B, int32_t* idx_out, int32_t* count, hipStream_t s,
                           const int32_t* budget = nullptr, int next_chunk = 0);
 void launch_chunk_budget(const int32_t* parent, int B, const int32_t* num_visit, const int32_t* chunks, int n,

@@ -338,13 +338,22 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
                    double* __restrict__ actions_out, ditree_strides al, int32_t* __restrict__ steps_out,
                    int64_t steps_stride, int32_t* __restrict__ chunks_run, double* __restrict__ prev_action_io,
                    uint8_t* __restrict__ has_prev_io, const int32_t* __restrict__ idx, int act_dense,
-                   const int32_t* __restrict__ budget, int chunk_j) {
+                   const int32_t* __restrict__ budget, int chunk_j, ChunkStrides cs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   stage_maze(lds, maze, rows * cols);
   const int ob = (blockIdx.x * blockDim.x + threadIdx.x) / G, g = threadIdx.x & (G - 1);
   if (ob >= B) return;
   const int b = idx ? idx[ob] : ob;                 // compacted rounds: actions are dense (row ob), the rest per candidate
   if (status_io[b] != DITREE_ST_OK) return;
+  // chunk_j < 0 (pool-scheduled early-exit rounds: one launch holds candidates at DIFFERENT chunks of their edges): the chunk
+  // is the number of chunks this candidate has finished; the chunk-0 bases are offset by it
+  if (chunk_j < 0) {
+    chunk_j = chunks_run[b];
+    if (states_out) states_out += (size_t)chunk_j * cs.states;
+    if (actions_out) actions_out += (size_t)chunk_j * cs.actions_out;
+    if (steps_out) steps_out += chunk_j;
+    if (!act_dense) actions += (size_t)chunk_j * cs.actions_in;
+  }
   if (budget != nullptr && chunk_j >= budget[b]) return;      // this visit's edge is shorter (prop_duration schedule)
   double s[6];
 #pragma unroll
@@ -426,7 +435,7 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
                            double* states_out, ditree_strides states_stride, double* actions_out, ditree_strides actout_stride,
                            int32_t* steps_out, int64_t steps_stride, int32_t* chunks_run, double* prev_action_io,
                            uint8_t* has_prev_io, const int32_t* idx, int act_dense, hipStream_t s, const int32_t* budget,
-                           int chunk_j) {
+                           int chunk_j, ChunkStrides cs) {
   size_t lds = ((size_t)rows * cols + 15) & ~(size_t)15;
   // work-group size: one wave per group spreads a small batch over many CUs (1 024 candidates: 16 CUs instead of 4); once
   // every SIMD has a wave anyway, four waves per group share one staged maze
@@ -442,12 +451,12 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
     hipLaunchKernelGGL(car_rollout_kernel<2>, dim3((2 * B + blk - 1) / blk), dim3(blk), lds, s, maze, rows, cols, state_io,
                        actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out,
                        actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense,
-                       budget, chunk_j);
+                       budget, chunk_j, cs);
   else
     hipLaunchKernelGGL(car_rollout_kernel<1>, dim3((B + blk - 1) / blk), dim3(blk), lds, s, maze, rows, cols, state_io,
                        actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out,
                        actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense,
-                       budget, chunk_j);
+                       budget, chunk_j, cs);
 }
 void launch_car_rollout(const unsigned char* maze, int rows, int cols, double* state_io, const double* actions,
                         int64_t act_stride, int32_t* status_io, int B, int A, double gx, double gy,
@@ -455,7 +464,7 @@ void launch_car_rollout(const unsigned char* maze, int rows, int cols, double* s
                         int32_t* steps_out, double* prev_action_io, uint8_t* has_prev_io, hipStream_t s) {
   launch_car_rollout_ex(maze, rows, cols, state_io, actions, act_stride, status_io, B, A, gx, gy, states_out,
                         ditree_strides{states_stride, 6, 1}, actions_out, ditree_strides{actout_stride, 2, 1}, steps_out, 1,
-                        nullptr, prev_action_io, has_prev_io, nullptr, 1, s, nullptr, 0);
+                        nullptr, prev_action_io, has_prev_io, nullptr, 1, s, nullptr, 0, ChunkStrides{0, 0, 0});
 }
 
 // ------------------------------------------------------------------------- lidar
@@ -755,6 +764,49 @@ __global__ void __launch_bounds__(1024) compact_alive_kernel(const int32_t* __re
 void launch_compact_alive(const int32_t* status, int B, int32_t* idx_out, int32_t* count, hipStream_t s,
                           const int32_t* budget, int next_chunk) {
   hipLaunchKernelGGL(compact_alive_kernel, dim3(1), dim3(1024), 0, s, status, B, idx_out, count, budget, next_chunk);
+}
+
+// Ready list of a pool-scheduled early-exit round: the candidates that still have a chunk to run (status OK, chunks_run < their
+// budget), ordered by (chunks finished, candidate) -- the ones furthest behind first, so nobody starves at the end of the
+// list -- with, per entry, the row of the (B * n_chunks, ...) noise view its next denoiser call reads.  One workgroup; one
+// ordered prefix-sum pass per chunk index (n_chunks <= 64, B <= a few 10 000: microseconds).
+__global__ void __launch_bounds__(1024) compact_ready_kernel(const int32_t* __restrict__ status, const int32_t* __restrict__ chunks_run,
+                                                             const int32_t* __restrict__ budget, int n_chunks, int B,
+                                                             int32_t* __restrict__ idx_out, int32_t* __restrict__ nrow_out,
+                                                             int32_t* __restrict__ count) {
+  __shared__ int s_wave_sum[16];
+  const int tid = threadIdx.x;
+  int base = 0;
+  for (int j = 0; j < n_chunks; ++j) {
+    for (int start = 0; start < B; start += blockDim.x) {
+      const int b = start + tid;
+      const int rdy = (b < B && status[b] == DITREE_ST_OK && chunks_run[b] == j && j < (budget ? budget[b] : n_chunks)) ? 1 : 0;
+      int v = rdy;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(v, d);
+        if ((tid & 63) >= d) v += o;
+      }
+      if ((tid & 63) == 63) s_wave_sum[tid >> 6] = v;
+      __syncthreads();
+      int woff = 0, total = 0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+        if (w < (tid >> 6)) woff += s_wave_sum[w];
+        total += s_wave_sum[w];
+      }
+      if (rdy) {
+        idx_out[base + woff + v - 1] = b;
+        nrow_out[base + woff + v - 1] = b * n_chunks + j;
+      }
+      base += total;
+      __syncthreads();
+    }
+  }
+  if (tid == 0) *count = base;
+}
+void launch_compact_ready(const int32_t* status, const int32_t* chunks_run, const int32_t* budget, int n_chunks, int B,
+                          int32_t* idx_out, int32_t* nrow_out, int32_t* count, hipStream_t s) {
+  hipLaunchKernelGGL(compact_ready_kernel, dim3(1), dim3(1024), 0, s, status, chunks_run, budget, n_chunks, B, idx_out, nrow_out, count);
 }
 
 // planners/RRT.py:149-152 for a round: candidate b is visit number num_visit[parent] + (earlier candidates of the round with

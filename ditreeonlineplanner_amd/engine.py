@@ -184,10 +184,14 @@ _COALESCE_BROKEN = [False]
 
 
 def default_shard():
-    """(rank, world_size, process_group) of the default torch.distributed group when one is initialised (a script started
-    with `torch.distributed.run -m ditreeonlineplanner_amd.run script.py`), else (0, 1, None)."""
+    """(rank, world_size, process_group) a facade shards over when the caller names none.  Sharding over the default
+    torch.distributed group is OPT-IN -- DITREE_SHARD_DEFAULT_GROUP=1, which `python -m ditreeonlineplanner_amd.run` sets when
+    it joins the group for a driver script -- because it is only sound when every rank plans the SAME scenario with identical
+    RNG streams: a data-parallel harness whose ranks plan different scenarios would dead-lock or mix trees in the per-round
+    collectives.  Everything else gets (0, 1, None); explicit ``rank`` / ``world_size`` / ``process_group`` always win."""
+    import os
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
+    if os.environ.get("DITREE_SHARD_DEFAULT_GROUP", "0") == "1" and dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size(), None
     return 0, 1, None
 
@@ -218,6 +222,7 @@ class ExpansionEngine:
         self.early_exit = int(bool(early_exit))    # skip later chunks of collided / finished candidates
         self.norm = np.ascontiguousarray(CAR_NORM if norm is None else norm, dtype=np.float64)
         self.rank, self.world, self.pg = rank, world_size, process_group
+        self.ddpm = None                    # (timesteps (K,), coef (K, 5)): the sampler's DDPM branch instead of the flow steps
         self.force_allgather = False        # run the collective even with one rank (exercises the RCCL path on 1 GPU)
         self.exchange_events = None         # list -> one (start, end) event pair per round around pack + all-gather + unpack
         self.run_type = int(run_type)
@@ -287,19 +292,43 @@ class ExpansionEngine:
         dist.broadcast(t, src=src, group=self.pg)
         return bool(int(t.item()))
 
-    def sum_over_ranks(self, value: int) -> int:
+    def sum_over_ranks(self, value: int, op="sum") -> int:
         if self.world <= 1:
             return int(value)
         import torch.distributed as dist
         gloo = dist.get_backend(self.pg) == "gloo"
         t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if gloo else self.ctx.device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=self.pg)
         return int(t.item())
 
     # ------------------------------------------------------------------ one round
-    def expand_round(self, samples, cond_goal, noise=None, inject_actions=None, accept=True):
+    def _sampler_schedule(self, rp, keep, step_noise, lo, hi):
+        """t0 / dt of the flow steps, or -- self.ddpm set -- the DDPM timesteps, coefficient table and this round's step noise."""
+        if self.ddpm is None:
+            for name, arr in (("t0", self.t0), ("dt", self.dt)):
+                a, p = _flt(arr)
+                keep.append(a)
+                setattr(rp, name, p)
+            rp.K = self.k_steps
+            rp.ddpm_coef, rp.step_noise = None, None
+            return
+        ts, coef = self.ddpm
+        a, rp.t0 = _flt(ts)
+        b, rp.ddpm_coef = _flt(coef)
+        keep += [a, b, step_noise]
+        rp.dt = None
+        rp.K = len(a)
+        if step_noise is None:
+            raise ValueError("the DDPM branch needs step_noise (B, n_chunks, K, P, D) f32")
+        want = (self.n_chunks, rp.K, self.P, self.ACTION_DIM)
+        if tuple(step_noise.shape[1:]) != want or step_noise.dtype != torch.float32 or not step_noise.is_contiguous():
+            raise ValueError(f"step_noise must be a contiguous float32 (B, {want[0]}, {want[1]}, {want[2]}, {want[3]}) tensor")
+        rp.step_noise = step_noise[lo:hi].data_ptr() if hi > lo else None
+
+    def expand_round(self, samples, cond_goal, noise=None, inject_actions=None, accept=True, step_noise=None):
         """samples (B,6) f64, cond_goal (B,2) f64 [device tensors, all candidates of the round];
-        noise (B, n_chunks, P, 2) f32 or inject_actions (B, n_chunks, P, 2) f64 for this round."""
+        noise (B, n_chunks, P, 2) f32 or inject_actions (B, n_chunks, P, 2) f64 for this round; step_noise
+        (B, n_chunks, K, P, 2) f32 with ``self.ddpm`` set (the sampler's DDPM branch)."""
         B = samples.shape[0]
         if B > self.batch:
             raise ValueError(f"round of {B} candidates exceeds engine batch {self.batch}")
@@ -312,10 +341,13 @@ class ExpansionEngine:
         rp.cond_goal = cond_goal[lo:hi].data_ptr() if n else None
         rp.noise = noise[lo:hi].data_ptr() if (noise is not None and n) else None
         rp.inject_actions = inject_actions[lo:hi].data_ptr() if (inject_actions is not None and n) else None
-        rp.P, rp.K = self.P, self.k_steps
+        rp.P = self.P
         keep = []
-        for name, arr, conv in (("t0", self.t0, _flt), ("dt", self.dt, _flt), ("norm", self.norm, _dbl),
-                                ("goal_xy", self.env_goal, _dbl), ("axis", self.axis, _dbl)):
+        if self.ddpm is None or noise is None:
+            self._flow_only(rp, keep)
+        else:
+            self._sampler_schedule(rp, keep, step_noise, lo, hi)
+        for name, arr, conv in (("norm", self.norm, _dbl), ("goal_xy", self.env_goal, _dbl), ("axis", self.axis, _dbl)):
             a, p = conv(arr)
             keep.append(a)
             setattr(rp, name, p)
@@ -334,6 +366,14 @@ class ExpansionEngine:
             check(self.ctx._h, lib().ditree_expand_round(self.ctx._h, C.byref(self.tree.desc), C.byref(rd),
                                                           C.byref(rp), self.ctx.stream), "expand_round")
         return self._finish_round(B, per, noise is not None, accept)
+
+    def _flow_only(self, rp, keep):
+        """An action-tape round of an engine whose sampler is the DDPM branch: no sampler call, the schedule is irrelevant."""
+        saved, self.ddpm = self.ddpm, None
+        try:
+            self._sampler_schedule(rp, keep, None, 0, 0)
+        finally:
+            self.ddpm = saved
 
     def _finish_round(self, B, per, used_denoiser, accept):
         """The part of a round behind the expansion: the record exchange (sharded rounds) and the replicated accept."""
@@ -389,7 +429,16 @@ class ExpansionEngine:
                                                 self.ctx.stream), "accept")
         cnt = self.tree.read_counters()           # one small D2H per round: n_nodes / goal
         if getattr(self, "_used_denoiser", False):
-            self.ctx.check_range()                # f16 range guard: the stream is drained already, one more tiny D2H
+            # f16 range guard: the stream is drained already, one more tiny D2H.  Sharded: a rank whose shard saturated must
+            # not raise alone (the others would wait in the next collective until the launcher kills them) -- the ranks agree
+            # on the worst count first and then all raise.
+            layers = self.ctx.denoise_status(clear=True)
+            worst = self.sum_over_ranks(len(layers), op="max")
+            if worst:
+                if not layers:
+                    raise _lib.DitreeError(f"f16 range guard: another rank clamped activations in {worst} layer(s) of this round; "
+                                           "bind the checkpoint with precision=PREC_BF16X3 or PREC_F32")
+                self.ctx.raise_range_error(layers)
         return cnt
 
     # ------------------------------------------------------------------ results
@@ -520,7 +569,7 @@ class AntExpansionEngine(ExpansionEngine):
         gj = np.floor((self.goal_state[0] + W / 2 * sg) / sg)
         self.env_goal = np.array([(gj + 0.5) * sg - W / 2 * sg, H / 2 * sg - (gi + 0.5) * sg])
 
-    def _params(self, samples, cond_goal, noise, inject_actions, lo, hi, next_obs_tape=None, cond_out=None):
+    def _params(self, samples, cond_goal, noise, inject_actions, lo, hi, next_obs_tape=None, cond_out=None, step_noise=None):
         n = hi - lo
         rp = _lib.AntRoundParams()
         rp.n_nodes = self.tree.n_nodes_host
@@ -528,9 +577,13 @@ class AntExpansionEngine(ExpansionEngine):
         rp.cond_goal = cond_goal[lo:hi].data_ptr() if n else None
         rp.noise = noise[lo:hi].data_ptr() if (noise is not None and n) else None
         rp.inject_actions = inject_actions[lo:hi].data_ptr() if (inject_actions is not None and n) else None
-        rp.P, rp.K = self.P, self.k_steps
+        rp.P = self.P
         keep = [samples, cond_goal, noise, inject_actions, next_obs_tape, cond_out]
-        for name, arr, conv in (("t0", self.t0, _flt), ("dt", self.dt, _flt), ("norm", self.norm, _dbl),
+        if self.ddpm is None or noise is None:
+            self._flow_only(rp, keep)
+        else:
+            self._sampler_schedule(rp, keep, step_noise, lo, hi)
+        for name, arr, conv in (("norm", self.norm, _dbl),
                                 ("desired_goal", self.env_goal, _dbl), ("axis", self.axis, _dbl)):
             a, p = conv(arr)
             keep.append(a)
@@ -545,7 +598,7 @@ class AntExpansionEngine(ExpansionEngine):
         return rp, keep
 
     def expand_round(self, samples, cond_goal, noise=None, inject_actions=None, accept=True, next_obs_tape=None, step_fn=None,
-                     cond_out=None):
+                     cond_out=None, step_noise=None):
         """samples (B, 29) f64, cond_goal (B, 2) f64, noise (B, n_chunks, P, 8) f32 or inject_actions (B, n_chunks, P, 8) f64
         [device tensors, all candidates of the round]; next_obs_tape (B, n_chunks, A, 29) f64 for dynamics='tape'; step_fn for
         dynamics='host'; cond_out (B, n_chunks, 97) f32: receives every sampler call's conditioning vector (tests)."""
@@ -565,7 +618,7 @@ class AntExpansionEngine(ExpansionEngine):
         lo, hi, per = self.shard(B)
         n = hi - lo
         self.ensure_maze()
-        rp, keep = self._params(samples, cond_goal, noise, inject_actions, lo, hi, next_obs_tape, cond_out)
+        rp, keep = self._params(samples, cond_goal, noise, inject_actions, lo, hi, next_obs_tape, cond_out, step_noise)
         if n > 0:
             rd = self.rb.desc(lo, n)
             h, L, t = self.ctx._h, lib(), C.byref(self.tree.desc)

@@ -338,6 +338,11 @@ def _ctx_check_range(self):
     """Raise when the f16 range guard fired: the clamped activations make the returned actions wrong, not approximate."""
     layers = self.denoise_status(clear=True)
     if layers:
+        self.raise_range_error(layers)
+
+
+def _ctx_raise_range_error(self, layers):
+    if True:
         raise _lib.DitreeError(
             "f16 range guard: activations beyond +-65504 were clamped in " + ", ".join(layers[:6]) +
             (f" and {len(layers) - 6} more layers" if len(layers) > 6 else "") +
@@ -372,6 +377,31 @@ def _ctx_denoise(self, noise, local_map, cond, t0=None, dt=None, act_norm=None, 
     return actions if want_actions else xout
 
 
+def _ctx_denoise_ddpm(self, noise, step_noise, local_map, cond, timesteps, coef, act_norm=None, want_actions=True, check_range=True):
+    """The sampler's DDPM branch on the device (include/ditree.h ditree_denoise_ddpm): noise (B, P, D) f32 = x_K, step_noise
+    (B, K, P, D) f32 = the z of every reverse step, timesteps (K,) / coef (K, 5) from ``ddpm.ddpm_tables``."""
+    dev = self.device
+    for nm_, t in (("noise", noise), ("step_noise", step_noise), ("local_map", local_map), ("cond", cond)):
+        _chk(t, torch.float32, nm_, dev)
+    self._check_denoiser_shapes(noise, local_map, cond)
+    B, P, D = noise.shape
+    ts, tsp = _flt(timesteps)
+    cf, cfp = _flt(coef)
+    K = len(ts)
+    if cf.shape != (K, 5) or tuple(step_noise.shape) != (B, K, P, D):
+        raise ValueError(f"coef must be ({K}, 5), step_noise ({B}, {K}, {P}, {D})")
+    an, anp = _dbl(CAR_NORM[12:16] if act_norm is None else act_norm)
+    if an.size != 2 * D:
+        raise ValueError(f"act_norm: need mu[{D}], sigma[{D}]")
+    actions = torch.empty(noise.shape, dtype=torch.float64, device=dev) if want_actions else None
+    xout = None if want_actions else torch.empty_like(noise)
+    check(self._h, lib().ditree_denoise_ddpm(self._h, _ptr(noise), _ptr(step_noise), _ptr(local_map), _ptr(cond), B, K, tsp, cfp, anp,
+                                             _ptr(actions), _ptr(xout), self.stream), "denoise_ddpm")
+    if check_range:
+        self.check_range()
+    return actions if want_actions else xout
+
+
 def _ctx_denoise_eval(self, sample, local_map, cond, timestep, reuse_encoder=False, check_range=True):
     """One raw network evaluation net(sample, map, timestep, cond) -> (B,P,D) f32 (the DDPM branch's model call)."""
     dev = self.device
@@ -385,6 +415,13 @@ def _ctx_denoise_eval(self, sample, local_map, cond, timestep, reuse_encoder=Fal
     if check_range:
         self.check_range()
     return out
+
+
+def _ctx_round_stats(self):
+    """{calls, waves, quantum} of the last early-exit round on this ctx (include/ditree.h ditree_round_stats)."""
+    d = (C.c_int32 * 4)()
+    check(self._h, lib().ditree_round_stats(self._h, d), "round_stats")
+    return {"denoiser_calls": int(d[0]), "tile_waves": int(d[1]), "candidates_per_wave": int(d[2])}
 
 
 def _ctx_denoise_dims(self):
@@ -419,10 +456,13 @@ Context.load_weights = _ctx_load_weights
 Context.denoise_reserve = _ctx_denoise_reserve
 Context.denoise = _ctx_denoise
 Context.denoise_eval = _ctx_denoise_eval
+Context.denoise_ddpm = _ctx_denoise_ddpm
 Context.debug_read = _ctx_debug_read
 Context.denoise_dims = _ctx_denoise_dims
+Context.round_stats = _ctx_round_stats
 Context.denoise_status = _ctx_denoise_status
 Context.check_range = _ctx_check_range
+Context.raise_range_error = _ctx_raise_range_error
 Context._check_denoiser_shapes = _ctx_check_denoiser_shapes
 
 

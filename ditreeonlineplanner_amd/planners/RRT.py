@@ -38,12 +38,19 @@ class RRT_Planner(BasePlanner):
         self.goal_sample_rate = 0.15
         self.goal_conditioning_bias = kwargs.get("goal_conditioning_bias", 0.85)
         self.prop_duration_schedule = list(kwargs.get("prop_duration", [64]))
-        # plan() runs the fused flow-matching rounds (ditree_expand_round: K Euler steps inside the library).  A sampler
-        # built for policy='diffusion' needs its scheduler's step between network calls (fm_policy.py:164-182): that loop
-        # lives in DiffusionSampler.forward, not in the round kernel -- refuse instead of sampling with the wrong rule.
-        if getattr(sampler, "policy", "flow_matching") != "flow_matching":
-            raise NotImplementedError("RRT_Planner.plan expands with the flow-matching sampler; policy="
-                                      f"{getattr(sampler, 'policy', None)!r} is only available through DiffusionSampler.forward")
+        # plan() runs fused rounds (ditree_expand_round): K flow-matching Euler steps inside the library, or -- a sampler built
+        # with policy='diffusion' and a DDPM scheduler of the reference's configuration (run_scenarios.py:157-158) -- the K
+        # DDPM reverse steps (fm_policy.py:164-182; ditree_denoise_ddpm).  Any other scheduler object can only drive
+        # DiffusionSampler.forward itself: refuse instead of sampling with the wrong rule.
+        self._ddpm = None
+        if getattr(sampler, "policy", "flow_matching") == "diffusion":
+            self._ddpm = sampler.ddpm_tables() if hasattr(sampler, "ddpm_tables") else None
+            if self._ddpm is None:
+                raise NotImplementedError("RRT_Planner.plan with policy='diffusion' needs a DDPM scheduler with epsilon prediction, "
+                                          "clip_sample and fixed_small variance (the reference's configuration); other schedulers "
+                                          "are only available through DiffusionSampler.forward")
+        elif getattr(sampler, "policy", "flow_matching") != "flow_matching":
+            raise NotImplementedError(f"policy={getattr(sampler, 'policy', None)!r}")
         self.offline_time_budget = kwargs.get("offline_time_budget", 60)
         self.plan_count = 0
         self.init_main_path = None
@@ -71,6 +78,7 @@ class RRT_Planner(BasePlanner):
             run_type=self.run_type, goal_scale=getattr(sampler, "local_map_size", None),
             rank=self.rank, world_size=self.world_size, process_group=self.process_group)
         self._engine.env_goal = np.asarray(self.env.goal, dtype=np.float64)
+        self._engine.ddpm = self._ddpm
         from concurrent.futures import ThreadPoolExecutor
         self._draw_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ditree-draw")
 
@@ -115,6 +123,7 @@ class RRT_Planner(BasePlanner):
             early_exit=kwargs.get("early_exit", True), goal_scale=getattr(sampler, "local_map_size", None),
             dynamics=self.ant_dynamics, model=kwargs.get("ant_model"), rank=self.rank, world_size=self.world_size,
             process_group=self.process_group)
+        self._engine.ddpm = self._ddpm
         from concurrent.futures import ThreadPoolExecutor
         self._draw_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ditree-draw")
 
@@ -326,6 +335,8 @@ class RRT_Planner(BasePlanner):
             else:
                 noise, acts = None, self._host_actions(drawn, B)
             extra = {}
+            if network and eng.ddpm is not None:       # the z of every reverse step, drawn like the start noise (whole round, every rank)
+                extra["step_noise"] = torch.randn((B, eng.n_chunks, len(eng.ddpm[0]), eng.P, eng.ACTION_DIM), device=dev)
             if self.is_ant:
                 if self.ant_dynamics == "host":
                     extra["step_fn"] = self._ant_env_step

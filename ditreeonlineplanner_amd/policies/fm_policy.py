@@ -89,6 +89,16 @@ class DiffusionSampler(nn.Module):
     def to(self, *a, **k):
         return self
 
+    def ddpm_tables(self):
+        """(timesteps, coef) of the on-device DDPM loop when ``noise_scheduler`` is a DDPM scheduler of the configuration the
+        device step implements (epsilon prediction, clip_sample, fixed_small variance: run_scenarios.py:157-158), else None."""
+        if self.policy != "diffusion":
+            return None
+        if getattr(self, "_ddpm_tables", None) is None:
+            from ..ddpm import ddpm_tables
+            self._ddpm_tables = (ddpm_tables(self.noise_scheduler, self.num_diffusion_iters),)
+        return self._ddpm_tables[0]
+
     def ensure_bound(self, max_batch):
         net = self.noise_pred_net
         # what the tensor shapes do not tell the library: sequence length and map size come from the sampler
@@ -134,7 +144,14 @@ class DiffusionSampler(nn.Module):
         noise = torch.randn((B, self.pred_horizon, self.action_dim), device=dev)     # :158-159
         self.ensure_bound(B)
         if self.policy == "diffusion":
-            # fm_policy.py:164-182: the caller's scheduler (e.g. diffusers' DDPMScheduler) drives the loop; every
+            tables = self.ddpm_tables()
+            if tables is not None:
+                # fm_policy.py:164-182 with a DDPM scheduler of the reference's configuration: the whole reverse process on the
+                # device (ditree_denoise_ddpm); the step noise is drawn here in the order scheduler.step would draw it
+                K = len(tables[0])
+                z = torch.randn((K, B, self.pred_horizon, self.action_dim), device=dev).permute(1, 0, 2, 3).contiguous()
+                return ctx.denoise_ddpm(noise, z, lm, cond, tables[0], tables[1], act_norm=self.norm[12:16]).cpu().numpy()
+            # any other scheduler object drives the loop itself (fm_policy.py:164-182); every
             # model call is one raw network evaluation on the device, the map embedding is computed once
             self.noise_scheduler.set_timesteps(self.num_diffusion_iters)
             naction = noise
@@ -177,6 +194,12 @@ def _forward_ant(self, obs_seq, prev_actions, goal, local_map):
     noise = torch.randn((B, self.pred_horizon, self.action_dim), device=dev)
     self.ensure_bound(B)
     if self.policy == "diffusion":
+        tables = self.ddpm_tables()
+        if tables is not None:
+            K = len(tables[0])
+            z = torch.randn((K, B, self.pred_horizon, self.action_dim), device=dev).permute(1, 0, 2, 3).contiguous()
+            return ctx.denoise_ddpm(noise, z, lm, cond, tables[0], tables[1],
+                                    act_norm=np.concatenate([self.metadata["Actions_mean"], self.metadata["Actions_std"]])).cpu().numpy()
         self.noise_scheduler.set_timesteps(self.num_diffusion_iters)
         naction = noise
         for i, k in enumerate(self.noise_scheduler.timesteps):

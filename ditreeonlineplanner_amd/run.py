@@ -14,8 +14,8 @@ Several GPUs of one node: start one process per GPU,
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m ditreeonlineplanner_amd.run script.py
 
 The launcher then binds the process to GPU LOCAL_RANK and joins the RCCL process group before the script starts, and
-every `RRT_Planner` the script builds shards its rounds over the ranks (planners/RRT.py: `rank` / `world_size` default to
-the initialised group).  The scripts seed every RNG identically on all ranks (run_scenarios.py:86-90), so all ranks draw
+every `RRT_Planner` the script builds shards its rounds over the ranks (the launcher sets DITREE_SHARD_DEFAULT_GROUP=1:
+planners/RRT.py `rank` / `world_size` then default to the group; without it an initialised group is NOT adopted).  The scripts seed every RNG identically on all ranks (run_scenarios.py:86-90), so all ranks draw
 the same samples and return the same path."""
 import os
 import runpy
@@ -40,6 +40,8 @@ def join_process_group():
         dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=world)
     else:
         dist.init_process_group("nccl", rank=int(os.environ["RANK"]), world_size=world, device_id=torch.device("cuda", local))
+    # the planners of THIS script shard over the group (engine.default_shard): every rank runs the same script with the same seeds
+    os.environ["DITREE_SHARD_DEFAULT_GROUP"] = "1"
 
 
 def main(argv=None):

@@ -423,6 +423,23 @@ int32_t ditree_denoise(ditree_ctx* ctx, const float* noise, const float* local_m
                        const float* cond, int32_t B, int32_t K, const float* t0, const float* dt,
                        const double* act_norm, double* actions, float* x_out, void* stream);
 
+/* The sampler's policy = 'diffusion' branch (policies/fm_policy.py:164-182) with a DDPM scheduler as the reference configures it
+ * (run_scenarios.py:157-158: beta_schedule 'squaredcos_cap_v2', clip_sample True, prediction_type 'epsilon'; variance
+ * 'fixed_small'), K reverse steps inside the library:
+ *   eps = net(x, map, timesteps[k], cond)            (the embedding sees the scheduler's integer timestep, unscaled)
+ *   x0  = clip((x - sb_k eps) / sa_k, -1, 1);   x <- c0_k x0 + c1_k x + sigma_k z_k
+ * with, for timestep t and its predecessor (abar = cumulative product of 1 - beta, abar_prev = 1 behind the last step):
+ *   sb = sqrt(1 - abar_t), sa = sqrt(abar_t), c0 = sqrt(abar_prev) (1 - abar_t / abar_prev) / (1 - abar_t),
+ *   c1 = sqrt(abar_t / abar_prev) (1 - abar_prev) / (1 - abar_t), sigma = sqrt(max((1 - abar_prev) / (1 - abar_t) (1 - abar_t /
+ *   abar_prev), 1e-20)) for t > 0 and 0 at t = 0 -- all formed by the caller in float32 as the scheduler's tensors are.
+ * `diffusers` is not part of the reference repository: the arithmetic follows the published algorithm (Ho et al. 2020 as
+ * diffusers 0.x implements it) and is held to the build's numpy restatement -- PARITY UNPINNED.
+ *   noise [dev] (B, P, D) f32 x_K ~ N(0, I); step_noise [dev] (B, K, P, D) f32 z_k ~ N(0, I) (row k unused where sigma_k = 0);
+ *   timesteps [host] K floats; coef [host] (K, 5) floats sb, sa, c0, c1, sigma; other arguments as ditree_denoise. */
+int32_t ditree_denoise_ddpm(ditree_ctx* ctx, const float* noise, const float* step_noise, const float* local_map,
+                            const float* cond, int32_t B, int32_t K, const float* timesteps, const float* coef,
+                            const double* act_norm, double* actions, float* x_out, void* stream);
+
 /* One raw evaluation of the noise-prediction network, out = net(sample, map, timestep, cond)
  * (model/diffusion/conditional_unet1d.py:268-347 behind local_map_encoder.py:101-109): the building block of the
  * sampler's policy = 'diffusion' branch (policies/fm_policy.py:164-182), whose scheduler step stays with the caller.
@@ -467,7 +484,11 @@ typedef struct {
   int32_t lm_n;                  /* local_map_size */
   double lm_size;                /* the divisor of the goal conditioning (local_map_size) */
   double s_global;
-  int32_t early_exit;            /* != 0: compact the alive candidates after every chunk (RRT.py:179-184) */
+  int32_t early_exit;            /* != 0: chunks run for the candidates that are still alive only (RRT.py:179-184), the denoiser calls
+                                    packed to whole tile-waves from the pool of ready (candidate, chunk) items; same results */
+  const float* ddpm_coef;        /* [host] (K, 5) or NULL.  != NULL: the sampler's DDPM branch (ditree_denoise_ddpm) instead of the
+                                    flow steps; t0 then holds the K scheduler timesteps and dt is unused */
+  const float* step_noise;       /* [dev] (B, n_chunks, K, P, 2) f32 with ddpm_coef */
   const int32_t* chunk_budget;   /* [dev] (B,) chunks each candidate may run (ditree_chunk_budget), or NULL = all n_chunks */
 } ditree_round_params;
 
@@ -483,6 +504,13 @@ int32_t ditree_chunk_budget(ditree_ctx* ctx, const ditree_tree* tree, const doub
 
 int32_t ditree_expand_round(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,
                             const ditree_round_params* p, void* stream);
+
+/* Scheduling figures of the last ditree_expand_round with early_exit on this ctx: stats4 [host] = {denoiser calls, tile-waves
+ * they cost (sum over calls of ceil(rows / quantum)), the quantum = candidates per full wave of tiles on the 256 CUs for the
+ * loaded denoiser (512 for the car network), 0}.  An early-exit round packs its calls to whole waves from a pool of ready
+ * (candidate, next chunk) items (DESIGN.md "Early exit"); without early exit a round of B candidates and n chunks costs
+ * n * ceil(B / quantum) waves. */
+int32_t ditree_round_stats(ditree_ctx* ctx, int32_t* stats4);
 
 /* One expansion round of the ANT (BASELINE config 3; cfgs/antmaze.yaml + run_scenarios.py:123-132: action_horizon 2, edge
  * length 48 = 24 chunks, pred_horizon 16, obs_history 3, local map 16 x 16 @ 0.8, s_global 4) against a tree with state_dim
@@ -525,6 +553,8 @@ typedef struct {
   const double* next_obs_tape;   /* [dev] (B, n_chunks, A, 29) f64 for DITREE_ANT_DYN_TAPE */
   const ditree_ant_model* model; /* [host] for DITREE_ANT_DYN_MODEL */
   int32_t early_exit;            /* != 0: later chunks run on the still-alive candidates only (RRT.py:179-184) */
+  const float* ddpm_coef;        /* [host] (K, 5) or NULL: the DDPM branch, as ditree_round_params */
+  const float* step_noise;       /* [dev] (B, n_chunks, K, P, 8) f32 with ddpm_coef */
   float* cond_out;               /* [dev] (B, n_chunks, 97) f32 or NULL: the conditioning vector of every sampler call (tests) */
 } ditree_ant_round_params;
 int32_t ditree_expand_round_ant(ditree_ctx* ctx, const ditree_tree* tree, const ditree_round* round,

@@ -308,6 +308,40 @@ def test_raw_network_evaluation_and_diffusion_loop(ctx, oracle_net, inputs, prec
         DiffusionSampler(net, None, "carmaze", policy="diffusion", pred_horizon=64, action_dim=2)
 
 
+@pytest.mark.parametrize("prec", [1, 2])
+def test_ddpm_reverse_process_on_the_device(ctx, oracle_net, inputs, prec):
+    """ditree_denoise_ddpm (policies/fm_policy.py:164-182 with the reference's DDPMScheduler configuration, run_scenarios.py:
+    157-158): K = 5 reverse steps inside the library against the numpy restatement of the published algorithm (oracle/ddpm.py)
+    around the torch-CPU oracle network, on the same start and step noise.  diffusers itself is absent: PARITY UNPINNED."""
+    from oracle import ddpm as ODD
+    from ditreeonlineplanner_amd.ddpm import DDPMScheduler, ddpm_tables
+    noise, lm, cond = inputs
+    B, K = 6, 5
+    noise, lm, cond = noise[:B].contiguous(), lm[:B].contiguous(), cond[:B].contiguous()
+    z = torch.randn(B, K, 64, 2, generator=torch.Generator().manual_seed(9))
+    sch = DDPMScheduler(num_train_timesteps=K, beta_schedule="squaredcos_cap_v2", clip_sample=True, prediction_type="epsilon")
+    ts, coef = ddpm_tables(sch, K)
+    assert list(ts) == [4.0, 3.0, 2.0, 1.0, 0.0] and coef[-1, 4] == 0.0 and (coef[:-1, 4] > 0).all()
+
+    def eps_fn(x, t):
+        with torch.no_grad():
+            return oracle_net(sample=torch.as_tensor(x), local_map=lm, timestep=torch.full((B,), t), global_cond=cond).numpy()
+    ref = ODD.reverse_process(eps_fn, noise.numpy(), K, z.permute(1, 0, 2, 3).numpy())
+    _bind(ctx, oracle_net, prec, B)
+    got = ctx.denoise_ddpm(noise.cuda(), z.cuda(), lm.cuda(), cond.cuda(), ts, coef, want_actions=False).cpu().numpy()
+    assert np.abs(got).max() <= 1.0 + 1e-6                    # the last step returns the clipped x0
+    assert rel(got, ref) < 20 * TOL[prec]["l2"], rel(got, ref)
+    # un-normalised actions of the same call, and a sub-batch larger than nothing: rows independent
+    unit = np.array([0.5, -0.25, 2.0, 3.0])
+    a = ctx.denoise_ddpm(noise.cuda(), z.cuda(), lm.cuda(), cond.cuda(), ts, coef, act_norm=unit).cpu().numpy()
+    assert np.abs(a - (got.astype(np.float64) * unit[2:] + unit[:2])).max() < 1e-12
+    part = ctx.denoise_ddpm(noise[:2].cuda().contiguous(), z[:2].cuda().contiguous(), lm[:2].cuda().contiguous(),
+                            cond[:2].cuda().contiguous(), ts, coef, want_actions=False).cpu().numpy()
+    assert np.array_equal(part, got[:2])
+    with pytest.raises(ValueError):
+        ctx.denoise_ddpm(noise.cuda(), z[:, :3].cuda().contiguous(), lm.cuda(), cond.cuda(), ts, coef)
+
+
 _SIZE_CACHE = {}
 
 

@@ -1,5 +1,7 @@
 """GPU: the reference-shaped Python surface (CarEnv, Lidar2DSim, DiffusionSampler, RRT_Planner)
 driving the HIP engine; written like the tests the reference would have for these classes."""
+import random
+
 import numpy as np
 import pytest
 import torch
@@ -175,10 +177,12 @@ def test_rrt_planner_plan_runs_and_reports(net_pair):
     assert pl._engine.tree.n_nodes_host == 1
 
 
-def test_planner_refuses_a_diffusion_policy_sampler(net_pair):
-    """RRT_Planner.plan runs the fused flow-matching rounds; a sampler built for policy='diffusion' needs its scheduler
-    between network calls (fm_policy.py:164-182) and must not be sampled with the wrong rule."""
+def test_planner_with_a_diffusion_policy_sampler(net_pair):
+    """policy='diffusion' (policies/fm_policy.py:164-182): with a DDPM scheduler of the reference's configuration
+    (run_scenarios.py:157-158) the planner's rounds run the K reverse steps on the device; a scheduler object the device step
+    does not implement is refused instead of being sampled with the wrong rule."""
     from ditreeonlineplanner_amd.car_env import CarEnv
+    from ditreeonlineplanner_amd.ddpm import DDPMScheduler
     from ditreeonlineplanner_amd.planners.RRT import RRT_Planner
     from ditreeonlineplanner_amd.policies.fm_policy import DiffusionSampler
 
@@ -188,15 +192,34 @@ def test_planner_refuses_a_diffusion_policy_sampler(net_pair):
         def set_timesteps(self, n):
             pass
     _, net = net_pair
-    smp = DiffusionSampler(net, Sch(), "carmaze", policy="diffusion", pred_horizon=64, action_dim=2, prediction_type="actions",
-                           obs_history=1, action_history=1, goal_conditioned=True, num_diffusion_iters=3, local_map_size=20)
+    mk = lambda sch, k: DiffusionSampler(net, sch, "carmaze", policy="diffusion", pred_horizon=64, action_dim=2,      # noqa: E731
+                                         prediction_type="actions", obs_history=1, action_history=1, goal_conditioned=True,
+                                         num_diffusion_iters=k, local_map_size=20)
     maze = load_maze("boxes")
     env = CarEnv(maze_map=maze, collision_checking=False)
     start = np.array([*G.cell_rowcol_to_xy([17, 2], maze), 0.7, 0, 0, 0])
     goal = np.array([*G.cell_rowcol_to_xy([2, 17], maze), 0, 0, 0, 0])
-    with pytest.raises(NotImplementedError, match="flow-matching"):
-        RRT_Planner(start, goal, env_id="carmaze", environment=env, sampler=smp, action_horizon=8, local_map_size=20,
-                    local_map_scale=0.2, global_map_scale=1.0, prop_duration=[64], time_budget=1)
+    kw = dict(env_id="carmaze", environment=env, action_horizon=8, local_map_size=20, local_map_scale=0.2, global_map_scale=1.0,
+              prop_duration=[32])
+    with pytest.raises(NotImplementedError, match="DDPM scheduler"):
+        RRT_Planner(start, goal, sampler=mk(Sch(), 3), time_budget=1, **kw)
+    sch = DDPMScheduler(num_train_timesteps=4, beta_schedule="squaredcos_cap_v2", clip_sample=True, prediction_type="epsilon")
+    smp = mk(sch, 4)
+    pl = RRT_Planner(start, goal, sampler=smp, time_budget=600, batch=32, max_candidates=64, **kw)
+    assert pl._engine.ddpm is not None and pl._engine.ddpm[1].shape == (4, 5)
+    random.seed(3)
+    np.random.seed(3)
+    torch.manual_seed(3)
+    path, actions = pl.plan()
+    n = pl.results["number_of_nodes"]
+    assert pl.results["iterations"] > 0 and n >= 1
+    if path is not None:
+        assert path.dtype == np.float32 and path.shape[1] == 6 and np.isfinite(path).all()
+        # clip_sample: x0 in [-1, 1] -> the un-normalised actions of every edge stay within mean +- a few std
+        assert np.abs(actions).max() < 20
+    # the sampler's own forward takes the same on-device loop
+    a = smp(np.zeros((3, 1, 6)), prev_actions=None, goal=np.array([3.0, 4.0]), local_map=np.zeros((3, 20, 20), dtype=np.float32))
+    assert a.shape == (3, 64, 2) and np.isfinite(a).all()
 
 
 def test_planner_counts_collision_checks_and_defaults_to_f32_class_precision(net_pair):

@@ -195,6 +195,9 @@ def _gpu_planner_worker(rank, world, port, out_path):
     import random
     sys.path.insert(0, REPO)
     _init(rank, world, port)
+    from ditreeonlineplanner_amd.engine import default_shard
+    assert default_shard() == (0, 1, None)          # an initialised group alone is NOT adopted (opt-in, engine.default_shard)
+    os.environ["DITREE_SHARD_DEFAULT_GROUP"] = "1"   # what `python -m ditreeonlineplanner_amd.run` sets when it joins the group
     from ditreeonlineplanner_amd.car_env import CarEnv
     from ditreeonlineplanner_amd.planners.RRT import RRT_Planner
     from ditreeonlineplanner_amd.policies.fm_policy import DiffusionSampler
@@ -247,6 +250,7 @@ def _gpu_mppi_worker(rank, world, port, out_path):
     the noise hash), two tiny all-reduces per step (MIN of beta, SUM of 3 + 2T doubles), replicated update and env step."""
     sys.path.insert(0, REPO)
     _init(rank, world, port)
+    os.environ["DITREE_SHARD_DEFAULT_GROUP"] = "1"
     from ditreeonlineplanner_amd.mppi import MPPI
     from tests.test_gpu_mppi import l_path
     maze = load_maze("boxes")
