@@ -865,10 +865,16 @@ def run_ant_round(args):
     for _ in range(args.warmup):
         step()
     ctx.profile(1)
+    if world > 1 or force_dist:
+        eng.exchange_events = []
     elapsed = _timed(step, dataclass_replace(args, warmup=0), dist, world, dev, rehearse)
     prof = ctx.profile_read(prec)
     ctx.profile(0)
     ctx.check_range()
+    if eng.exchange_events:
+        comm["exchange"] = {"ms_per_round": float(np.mean([a.elapsed_time(b) for a, b in eng.exchange_events])),
+                            "bytes_per_rank": Bper * eng.tree.record_doubles * 8}
+    eng.exchange_events = None
     lo, hi, _ = eng.shard(Btot)
     st = eng.rb.status[lo:hi].cpu().numpy() & 0xFF
     run_chunks = eng.rb.chunks_run[lo:hi].cpu().numpy()

@@ -71,8 +71,10 @@ class NoisePredNet(nn.Module):
         """Upload the current parameters into ``ctx`` (repacked for MFMA inside the library)."""
         if precision is not None:
             self.precision = precision
+        # in-memory hand-over: no checksum line (it guards blobs that were stored or shipped -- weights.pack_state_dict's
+        # default -- and costs seconds on 0.7 GB in numpy)
         blob, manifest = pack_state_dict(self.state_dict(), pred_horizon=self.pred_horizon,
-                                         local_map_size=self.local_map_size)
+                                         local_map_size=self.local_map_size, checksum=False)
         ctx.load_weights(blob, manifest)
         ctx.weights_owner = self
         self._ctx = ctx

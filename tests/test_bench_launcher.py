@@ -120,3 +120,22 @@ def test_launcher_takes_its_ranks_down_when_it_is_terminated(tmp_path):
     time.sleep(0.5)
     for k in kids:
         assert not os.path.exists(f"/proc/{k}") or open(f"/proc/{k}/stat").read().split()[2] == "Z", k
+
+
+@pytest.mark.gpu
+def test_bench_ant_workloads_print_labelled_lines():
+    """`--workload ant-round` (BASELINE config 3 as a real round) with 2 ranks rehearsed on one GPU, and `--workload rollout
+    --model ant` (the higher-DoF rollout slot): one JSON line each, the stand-in dynamics named in metric / data / config."""
+    rc, lines, err = _run(["--workload", "ant-round", "--gpus", "2", "--batch", "128", "--steps", "1", "--warmup", "0",
+                           "--no-cpu-baseline", "--no-early-exit-line"], {"DITREE_REHEARSE_ONE_GPU": "1"}, timeout=900)
+    assert rc == 0, err[-3000:]
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["global_batch"] == 256 and out["value"] > 0
+    assert "NOT MuJoCo" in out["metric"] and "NOT MuJoCo" in out["data"] and out["config"]["ant_dynamics"] == "model"
+    assert out["roofline"]["bound"] == "mfma" and out["outcome"]["ok"] + out["outcome"]["goal"] + out["outcome"]["collided"] == 128
+    assert out["exchange"]["bytes_per_rank"] == 128 * 134 * 8
+    rc, lines, err = _run(["--workload", "rollout", "--model", "ant", "--batch", "8192", "--steps", "3", "--warmup", "1"], {}, timeout=600)
+    assert rc == 0, err[-3000:]
+    out = json.loads(lines[-1])
+    assert "NOT MuJoCo" in out["metric"] and out["roofline"]["bound"] == "hbm" and out["roofline"]["kernel"] == "ant_rollout_kernel<true>"
+    assert out["roofline"]["algorithmic_bytes_per_launch"] == 8192 * (232 + 64 * 16 + 232 * 16 + 8) and out["value"] > 0

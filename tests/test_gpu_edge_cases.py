@@ -336,6 +336,7 @@ def test_round3_kernels_at_their_smallest_and_odd_sizes(ctx):
         cnt = eng.expand_round(dev(np.zeros((1, 29))), dev(np.zeros((1, 2))), noise=torch.randn(1, 1, 16, 8, device="cuda"),
                                next_obs_tape=dev(obs) if dyn == "tape" else None)
         assert int(cnt[0]) == 2 and torch.isfinite(eng.rb.actions).all() and eng.rb.actions.shape == (1, 1, A, 8)
-        n = min(3, A + 1)
-        assert int(eng.tree.hist_n[1]) == n
-        assert torch.equal(eng.tree.hist[1, 3 - n:], eng.tree.edge_states[1, A + 1 - n: A + 1])
+        ns = int(eng.tree.edge_nstates[1])                     # rows kept (the goal == the start here: the edge may end at step 1)
+        n = min(3, ns)
+        assert 2 <= ns <= A + 1 and int(eng.tree.hist_n[1]) == n
+        assert torch.equal(eng.tree.hist[1, 3 - n:], eng.tree.edge_states[1, ns - n: ns])
