@@ -93,6 +93,13 @@ class MppiParams(C.Structure):
                 ("seed", C.c_uint64), ("window_back", C.c_int32), ("window_fwd", C.c_int32), ("lanes", C.c_int32), ("k_offset", C.c_int64)]
 
 
+class MppiAntParams(C.Structure):
+    _fields_ = [("T", C.c_int32), ("K", C.c_int32), ("lam", C.c_double), ("sigma", C.c_double * 8), ("w_track", C.c_double),
+                ("w_progress", C.c_double), ("w_collision", C.c_double), ("w_goal", C.c_double), ("seed", C.c_uint64),
+                ("window_back", C.c_int32), ("window_fwd", C.c_int32), ("k_offset", C.c_int64), ("goal_radius", C.c_double),
+                ("ball_radius", C.c_double), ("s_global", C.c_double), ("model", AntModel)]
+
+
 MPPI_ROLLOUTS, MPPI_MIN, MPPI_SUMS, MPPI_APPLY, MPPI_EXECUTE, MPPI_ALL = 1, 2, 4, 8, 16, 31
 
 
@@ -133,6 +140,7 @@ SIGNATURES = {
     "ditree_allgather_nodes": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "ditree_comm_destroy": (_i32, [_vp]),
     "ditree_mppi_step": (_i32, [_vp, C.POINTER(MppiParams), _vp, _vp, _vp, _i32, _pd, _vp, C.c_uint64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ditree_mppi_step_ant": (_i32, [_vp, C.POINTER(MppiAntParams), _vp, _vp, _vp, _i32, _pd, _vp, C.c_uint64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ditree_load_weights": (_i32, [_vp, _vp, _i64, C.c_char_p, _vp]),
     "ditree_denoise_reserve": (_i32, [_vp, _i32, _i32]),
     "ditree_denoise": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _pf, _pf, _pd, _vp, _vp, _vp]),

@@ -29,6 +29,7 @@ UNITS = [
     ("geom_kernels.hip", ["-ffp-contract=off"]),
     ("mppi_kernels.hip", ["-ffp-contract=off"]),
     ("ant_kernels.hip", ["-ffp-contract=off"]),
+    ("mppi_ant_kernels.hip", ["-ffp-contract=off"]),
     ("ditree_api.hip", []),
     ("denoise_kernels.hip", []),
     ("denoise_host.hip", []),

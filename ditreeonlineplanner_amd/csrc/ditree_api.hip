@@ -81,6 +81,7 @@ void ditree_ctx_destroy(ditree_ctx* ctx) {
   if (ctx->alive_cnt_host) hipHostFree(ctx->alive_cnt_host);
   if (ctx->path_dev) hipFree(ctx->path_dev);
   if (ctx->mppi_partial) hipFree(ctx->mppi_partial);
+  if (ctx->mppi_ant_partial) hipFree(ctx->mppi_ant_partial);
   if (ctx->mppi_minkey) hipFree(ctx->mppi_minkey);
   void* ant[] = {ctx->ant_hist, ctx->ant_hist_n, ctx->ant_idx, ctx->ant_nrow, ctx->ant_prev, ctx->ant_hasprev, ctx->ant_cond, ctx->ant_lmap, ctx->ant_act};
   for (void* q : ant) if (q) hipFree(q);

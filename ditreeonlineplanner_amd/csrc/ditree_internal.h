@@ -62,6 +62,7 @@ struct ditree_ctx {
   double* ant_act = nullptr;
   int ant_P = 0, ant_lm = 0;
   double* mppi_partial = nullptr;   // partial sums of the MPPI update (ditree_mppi_step)
+  double* mppi_ant_partial = nullptr;   // the same for ditree_mppi_step_ant (3 + 8 T per slice)
   unsigned long long* mppi_minkey = nullptr;   // running minimum of the rollout costs (order-preserving integer image)
   DenoiserState* dn = nullptr;
   // optional RCCL communicator (ditree_comm_*): librccl opened at run time

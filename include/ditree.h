@@ -375,6 +375,31 @@ int32_t ditree_mppi_step(ditree_ctx* ctx, const ditree_mppi_params* p, double* s
                          int32_t P, const double* goal_xy, const double* noise, uint64_t counter, int32_t stages,
                          double* costs, double* weights, int32_t* flags, double* sums, double* result, void* stream);
 
+/* The same controller on the higher-DoF rollout slot -- BASELINE config 5 as written ("MPPI antmaze, 65 536 rollouts"): 29-d
+ * state, 8-d controls U (T, 8) with noise eps ~ N(0, diag(sigma^2)), every rollout step one env step of the build's STAND-IN
+ * model (ditree_ant_model; NOT MuJoCo), the reference's ant collision test (ditree_ant_collision) and goal radius, the same
+ * cost, soft-min update, executed step and stages as ditree_mppi_step.  The reference ships neither an MPPI module nor the
+ * ant's physics: PARITY UNPINNED BY CONSTRUCTION (the build's numpy restatement: oracle/mppi.py).
+ *   state_io [dev] 29 f64; U_io [dev] (T, 8); path_xy [dev] (P, 2); noise [dev] (K, T, 8) or NULL (counter hash, four
+ *   Box-Muller pairs per (GLOBAL rollout, step)); costs / weights / flags as ditree_mppi_step; sums [dev] 3 + 8 T;
+ *   result [dev] 64 f64: [2] status, [3] beta, [4] eta, [5] nearest path index of the input state, [6] collided rollouts,
+ *   [7] effective sample size, [16..24) the executed action, [24..53) the state after EXECUTE. */
+typedef struct {
+  int32_t T, K;
+  double lambda;
+  double sigma[8];
+  double w_track, w_progress, w_collision, w_goal;
+  uint64_t seed;
+  int32_t window_back, window_fwd;
+  int64_t k_offset;
+  double goal_radius, ball_radius, s_global;     /* 0.45 * s_global, 1.2, 4 (planners/base_planner.py:155,297) */
+  ditree_ant_model model;
+} ditree_mppi_ant_params;
+int32_t ditree_mppi_step_ant(ditree_ctx* ctx, const ditree_mppi_ant_params* p, double* state_io, double* U_io,
+                             const double* path_xy, int32_t P, const double* desired_goal_xy /*[host] 2*/, const double* noise,
+                             uint64_t counter, int32_t stages, double* costs, double* weights, int32_t* flags, double* sums,
+                             double* result, void* stream);
+
 /* ------------------------------------------------------------------ denoiser */
 
 /* Upload the denoiser weights (reference: run_scenarios.py:157-185, state-dict keys

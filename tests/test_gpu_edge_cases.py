@@ -224,7 +224,7 @@ def test_round3_entry_points_argument_and_call_order_errors(ctx):
     with pytest.raises(ValueError):
         MPPI(maze_data=maze, T=65, K=8, ctx=ctx)
     with pytest.raises(NotImplementedError):
-        MPPI(maze_data=maze, T=8, K=8, nx=29, nu=8, ctx=ctx)
+        MPPI(maze_data=maze, T=8, K=8, nx=10, nu=4, ctx=ctx)
     m = MPPI(maze_data=maze, T=8, K=16, ctx=ctx)
     with pytest.raises(DitreeError, match="set_ref_path"):
         m.step(np.zeros(6))

@@ -288,3 +288,79 @@ def test_controller_step_at_config5_size(ctx):
     assert np.abs(m._U.cpu().numpy() - Un).max() < 1e-9
     wg = w.cpu().numpy()
     assert abs(wg.sum() - 1.0) < 1e-10 and np.abs(wg - wn).max() < 1e-9
+
+
+# ------------------------------------------------------------------------------------------ config 5 as written: MPPI on the ant slot
+def make_ant(ctx, K, T=16, **kw):
+    """MPPI(maze, T, K, nx=29, nu=8): the stand-in crawler model (NOT MuJoCo) behind the same controller; boxes.csv scaled by 4."""
+    from ditreeonlineplanner_amd.mppi import MPPI
+    from oracle import ant as OA
+    maze = load_maze("boxes")
+    path1, goal_xy = l_path(maze, ds=0.02)
+    path = path1 * 4.0                                       # the ant's maze is the car's scaled by s_global = 4
+    m = MPPI(maze_data=maze, T=T, K=K, nx=29, nu=8, ctx=ctx, **kw)
+    start = np.zeros(29)
+    start[:2] = path[0]
+    start[2], start[3] = 0.75, 1.0
+    start[7:15] = np.tile([0.0, OA.AntModel.ank_rest], 4)
+    goal = np.zeros(29)
+    goal[:2] = goal_xy * 4.0
+    m.reset(start_state=start, goal_state=goal)
+    m.set_ref_path(path)
+    return m, maze, path, start
+
+
+def kw_ant(m):
+    p = m.params
+    return dict(lam=p.lam, sigma=[p.sigma[d] for d in range(8)], w_track=p.w_track, w_progress=p.w_progress, w_collision=p.w_collision,
+                w_goal=p.w_goal, window_back=p.window_back, window_fwd=p.window_fwd)
+
+
+def test_ant_mppi_matches_the_numpy_restatement(ctx):
+    """ditree_mppi_step_ant at K = 4096, T = 16 on the on-device noise: costs / beta / eta / controls 1e-9 against oracle/mppi.py
+    (rollout_costs_ant on the mirrored counter hash), collided / goal flags exact; K = 1 reduces to the nominal sequence and the
+    executed step is the model step of its first control."""
+    from ditreeonlineplanner_amd.mppi import AntMPPI
+    K, T = 4096, 16
+    m, maze, path, start = make_ant(ctx, K, T, seed=77)
+    assert isinstance(m, AntMPPI)
+    state = start.copy()
+    state[:2] = path[400] + np.array([0.0, -1.6])            # close to the bottom wall (ball radius 1.2, cell 4): a share collides
+    state[15:18] = [0.8, -0.6, 0.0]
+    rng = np.random.default_rng(2)
+    U = rng.uniform(-0.5, 0.5, (T, 8))
+    m.counter = 5
+    m._state.copy_(torch.as_tensor(state))
+    m._U.copy_(torch.as_tensor(U))
+    w = torch.zeros(K, dtype=torch.float64, device=ctx.device)
+    m.launch(UPD, weights=w)
+    kw = kw_ant(m)
+    eps = OM.device_noise_ant(77, 5, 0, K, T, kw["sigma"])
+    assert abs(eps[1:].std() - 0.5) < 0.01
+    rc, rf, i0 = OM.rollout_costs_ant(maze, state, U, path, m.env.goal, eps, **kw)
+    Un, wn, beta, eta, ess = OM.update_ant(U, rc, eps, kw["lam"])
+    res = m._result.cpu().numpy()
+    assert int(res[5]) == i0
+    flags = m._flags.cpu().numpy()
+    assert np.array_equal(flags, rf), (np.bincount(flags, minlength=3), np.bincount(rf, minlength=3))
+    assert 50 < int((rf == 2).sum()) < K - 50 and int(res[6]) == int((rf == 2).sum())
+    assert np.abs(m._costs.cpu().numpy() - rc).max() < 1e-9 * max(1.0, np.abs(rc).max())
+    assert abs(res[3] - beta) < 1e-9 * max(1.0, abs(beta)) and abs(res[4] - eta) < 1e-9 * eta and abs(res[7] - ess) < 1e-7 * ess
+    assert np.abs(m._U.cpu().numpy() - Un).max() < 1e-9
+    wg = w.cpu().numpy()
+    assert abs(wg.sum() - 1.0) < 1e-10 and np.abs(wg - wn).max() < 1e-9
+    # K = 1: the nominal sequence alone; the executed step = one model step of the (clipped) first control
+    m1, _, _, _ = make_ant(ctx, 1, T)
+    U1 = rng.uniform(-1.4, 1.4, (T, 8))
+    m1._U.copy_(torch.as_tensor(U1))
+    nxt, action, done = m1.step(start)
+    x_ref, a_ref, status, U_ref = OM.execute_ant(maze, start, U1, m1.env.goal)
+    assert done is False and status == 0 and np.array_equal(action, a_ref) and np.abs(action).max() == 1.0
+    assert np.abs(nxt - x_ref).max() < 1e-9 and np.array_equal(m1._U.cpu().numpy(), U_ref)
+    # closed loop for a few steps: finite, no collision from the corridor centre, the state the facade hands back is the device's
+    m2, _, _, _ = make_ant(ctx, 2048, T, seed=3)
+    st = start.copy()
+    for _ in range(20):
+        st, a, done = m2.step(st)
+        assert done is False and np.isfinite(st).all() and np.abs(a).max() <= 1.0
+    assert m2.last["effective_samples"] > 1.0
