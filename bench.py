@@ -16,7 +16,8 @@ Other workloads of BASELINE.json's config list (each prints its own one-line JSO
     --workload rollout       config 5: 65 536 car rollouts x T = 16 steps, the rollout kernel alone (no denoiser);
                              --model ant: the higher-DoF rollout slot on the build's stand-in 29-state / 8-action model (NOT MuJoCo)
     --workload mppi          config 5: 65 536 MPPI rollouts (the build's own controller: costs, soft-min update, executed step),
-                             sharded over --gpus N with two tiny all-reduces per controller step
+                             sharded over --gpus N with two tiny all-reduces per controller step; --model ant: the same on the
+                             stand-in 29-state / 8-action model (config 5 "antmaze" as written; NOT MuJoCo)
     --workload lidar-round   config 4: a round of 8 192 candidates + one 181-ray lidar scan per candidate end pose
     --workload ant-round     config 3: a round of 4 096 ant candidates x H = 48 (24 chunks): ant-sized denoiser + glue + the reference's
                              ant collision / goal tests + accept into the 29-d tree; the env step (MuJoCo in the reference, no oracle) is
@@ -477,9 +478,23 @@ def run_mppi(args):
     seg1 = a_ + (b_ - a_) * np.linspace(0, 1, 850)[:, None]
     seg2 = b_ + (c_ - b_) * np.linspace(0, 1, 850)[1:, None]
     path = np.concatenate([seg1, seg2])
-    m = MPPI(maze_data=maze, T=T, K=K, nx=6, nu=2, seed=20260104, ctx=ctx, rank=rank, world_size=world, lanes=args.mppi_lanes)
-    start = np.array([path[0, 0], path[0, 1], 0.0, 0.0, 0.0, 0.0])
-    m.reset(start_state=start, goal_state=np.array([c_[0], c_[1], 0, 0, 0, 0.0]))
+    ant = args.model == "ant"
+    if ant:
+        # config 5 as written ("MPPI antmaze"): the same controller on the higher-DoF slot -- the build's stand-in crawler model
+        # (NOT MuJoCo), the reference's ant collision / goal tests, boxes.csv scaled by s_global = 4
+        path = path * 4.0
+        m = MPPI(maze_data=maze, T=T, K=K, nx=29, nu=8, seed=20260104, ctx=ctx, rank=rank, world_size=world)
+        start = np.zeros(29)
+        start[:2] = path[0]
+        start[2], start[3] = 0.75, 1.0
+        start[7:15] = np.tile([0.0, 0.87], 4)
+        goal_s = np.zeros(29)
+        goal_s[:2] = c_ * 4.0
+        m.reset(start_state=start, goal_state=goal_s)
+    else:
+        m = MPPI(maze_data=maze, T=T, K=K, nx=6, nu=2, seed=20260104, ctx=ctx, rank=rank, world_size=world, lanes=args.mppi_lanes)
+        start = np.array([path[0, 0], path[0, 1], 0.0, 0.0, 0.0, 0.0])
+        m.reset(start_state=start, goal_state=np.array([c_[0], c_[1], 0, 0, 0, 0.0]))
     m.set_ref_path(path)
     m._state.copy_(torch.as_tensor(start))              # the state then stays on the device (the step writes it back)
     state = [start]
@@ -512,7 +527,7 @@ def run_mppi(args):
             m.launch(_lib.MPPI_MIN | _lib.MPPI_SUMS | _lib.MPPI_APPLY | _lib.MPPI_EXECUTE)
         m.counter += 1
         res = m._result.cpu().numpy()              # one D2H + sync per step: action, status, statistics, the new state
-        state[0] = res[8:14].copy()
+        state[0] = res[24:53].copy() if ant else res[8:14].copy()
         it[0] += 1
 
     elapsed = _timed(step, args, dist, world, dev, rehearse)
@@ -520,25 +535,33 @@ def run_mppi(args):
     if rank == 0:
         k_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
         Kloc = m.K_local
-        alg = Kloc * 12 + 48 + 32 * T + len(path) * 16
+        alg = Kloc * 12 + (232 + 64 * T if ant else 48 + 32 * T) + len(path) * 16
         ach = alg / (k_ms * 1e-3) / 1e9
-        # FP64 work of a rollout step (counted from the kernel source, fma = 2): dynamics ~60 + 3 sin/cos pairs + tanh (~40 each)
-        # + two-ball collision ~2 x 60 + goal 6 + path window 64 points x 7 + noise hash / Box-Muller ~120  ->  ~900 flop
-        flop = Kloc * T * 900.0
-        res = {"metric": "MPPI rollouts/sec (controller step: K x T=16 car rollouts with collision / goal / path-tracking cost, soft-min update, one executed step)",
+        # FP64 work of a rollout step (counted from the kernel source, fma = 2), an UPPER BOUND on the executed work: rollouts that
+        # hit a wall or the goal stop early (`controller.collided_rollouts_last_step`).  car: dynamics ~60 + 3 sin/cos pairs + tanh
+        # (~40 each) + two-ball collision ~2 x 60 + goal 6 + path window 64 points x 7 + noise hash / Box-Muller ~120 -> ~900 flop;
+        # ant stand-in: 5 sub-steps x (4 legs x ~40 + tanh x 4 + atan2 + sin / cos + quaternion ~60 = ~420) + collision ~70 +
+        # path window 64 x 7 + 4 noise pairs ~480 -> ~3100 flop
+        fps = 3100.0 if ant else 900.0
+        flop = Kloc * T * fps
+        kname = "mppi_ant_rollout_kernel" if ant else f"mppi_rollout_kernel<{args.mppi_lanes or 2}>"
+        what = ("ant-slot rollouts: the build's stand-in 29-state / 8-action crawler model, NOT MuJoCo" if ant else "car rollouts")
+        res = {"metric": f"MPPI rollouts/sec (controller step: K x T=16 {what} with collision / goal / path-tracking cost, soft-min update, one executed step)",
                "value": K * args.steps / elapsed, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
                "dtype": "f64", "data": _data(rehearse),
-               "config": {"workload": f"BASELINE config 5: {K} MPPI rollouts (global) x T={T}, car model on boxes.csv, L-shaped reference path of "
-                                      f"{len(path)} points, on-device noise; the build's own controller (the reference ships no MPPI module: parity unpinned)",
+               "config": {"workload": f"BASELINE config 5: {K} MPPI rollouts (global) x T={T}, " +
+                                      ("the stand-in ant model (NOT MuJoCo; parity unpinned) on boxes.csv x 4" if ant else "car model on boxes.csv") +
+                                      f", L-shaped reference path of {len(path)} points, on-device noise; the build's own controller (the reference ships no MPPI module: parity unpinned)",
                           "rollouts_global": K, "rollouts_per_gpu": Kloc, "horizon": T,
                           "parallelism": f"rollouts sharded x{world}; all-reduce MIN (1 double) + SUM ({3 + 2 * T} doubles) per step"},
                "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                            **recorded_traffic("mppi", kernel="mppi_rollout_kernel"), "kernel": f"mppi_rollout_kernel<{args.mppi_lanes or 2}>",
+                            **recorded_traffic("mppi_ant" if ant else "mppi", kernel="mppi_ant_rollout_kernel" if ant else "mppi_rollout_kernel"), "kernel": kname,
                             "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": alg, "kernel_time_share": k_ms * 1e-3 * args.steps / elapsed,
                             "fp64": {"achieved_tflops": flop / (k_ms * 1e-3) / 1e12, "peak_tflops": 78.6,
-                                     "frac": flop / (k_ms * 1e-3) / 1e12 / 78.6, "flop_per_rollout_step": 900,
-                                     "note": "the governing unit: a sequential FP64 chain per rollout (2 lanes share one rollout by default); flop count from the source, fma = 2"},
+                                     "frac": flop / (k_ms * 1e-3) / 1e12 / 78.6, "flop_per_rollout_step": fps,
+                                     "note": "the governing unit: a sequential FP64 chain per rollout" + ("" if ant else f" ({args.mppi_lanes or 2} lanes share one rollout)") +
+                                             "; flop count from the source, fma = 2; UPPER BOUND on executed work (no early termination assumed)"},
                             "note": "noise is generated on the device: the kernel writes 12 B per rollout and reads ~30 KB of shared inputs per work-group out of L2"},
                "controller": {"state_xy": [float(state[0][0]), float(state[0][1])], **m.last}, **comm}
         res["controller"].update({"collided_rollouts_last_step": int(m._result[6].item()), "effective_samples_last_step": float(m._result[7].item())})

@@ -36,7 +36,7 @@ def short(name):
     for k in ("conv3_halo16x3_kernel", "conv3_halo16_kernel", "gemm16_kernel", "conv2d_small_kernel", "conv_gemm_kernel", "gn2d_kernel", "gn1d_kernel",
               "final_proj_flow_kernel", "car_rollout_kernel", "lidar_scan_kernel", "nn_argmin_kernel", "local_map_kernel",
               "im2col2d_kernel", "maxpool2d_kernel", "encoder_stem_kernel", "mppi_rollout_kernel", "mppi_partial_kernel",
-              "mppi_finish_kernel", "mppi_min_kernel", "gn1d_short_kernel", "cond_vector_ant_kernel", "ant_rollout_kernel",
+              "mppi_ant_rollout_kernel", "mppi_ant_partial_kernel", "mppi_ant_finish_kernel", "mppi_ant_min_kernel", "mppi_finish_kernel", "mppi_min_kernel", "gn1d_short_kernel", "cond_vector_ant_kernel", "ant_rollout_kernel",
               "ant_collision_kernel", "ant_gather_hist_kernel", "ant_copy_actions_kernel", "accept_commit_kernel", "accept_scan_kernel"):
         if k in name:
             return k

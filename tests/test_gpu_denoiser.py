@@ -137,7 +137,21 @@ LAYERS = [  # (engine buffer, oracle module path)
 ]
 
 
+_ORACLE_MEMO = {}
+
+
+def memo(key, fn):
+    """The oracle side of a test does not depend on the instantiation under test: computed once per module run."""
+    if key not in _ORACLE_MEMO:
+        _ORACLE_MEMO[key] = fn()
+    return _ORACLE_MEMO[key]
+
+
 def _oracle_with_taps(net, noise, lm, cond):
+    return memo(("taps", id(net), tuple(noise.shape)), lambda: _oracle_with_taps_compute(net, noise, lm, cond))
+
+
+def _oracle_with_taps_compute(net, noise, lm, cond):
     taps = {}
     hooks = []
     mods = dict(net.named_modules())
@@ -229,7 +243,7 @@ def test_actions_and_multi_step(ctx, oracle_net, inputs, prec):
     B = noise.shape[0]
     _bind(ctx, oracle_net, prec, B)
     t0, dt = OS.get_timesteps("exp", 4, 4.0)
-    xk_ref = OS.flow_sample(oracle_net, noise, lm, cond, k_steps=4)
+    xk_ref = memo(("k4", id(oracle_net)), lambda: OS.flow_sample(oracle_net, noise, lm, cond, k_steps=4))
     a_ref = OS.unnormalize_actions(xk_ref)
     a = ctx.denoise(noise.cuda(), lm.cuda(), cond.cuda(), t0=t0.numpy(), dt=dt.numpy(), want_actions=True)
     assert a.dtype == torch.float64
@@ -275,16 +289,20 @@ def test_raw_network_evaluation_and_diffusion_loop(ctx, oracle_net, inputs, prec
     _bind(ctx, oracle_net, prec, B)
     with torch.no_grad():
         for i, t in enumerate((0.0, 7.0, 63.0)):
-            ref = oracle_net(sample=noise, local_map=lm, timestep=torch.full((B,), t), global_cond=cond).numpy()
+            ref = memo(("raw", id(oracle_net), t), lambda: oracle_net(sample=noise, local_map=lm, timestep=torch.full((B,), t),
+                                                                        global_cond=cond).numpy())
             got = ctx.denoise_eval(noise.cuda(), lm.cuda(), cond.cuda(), t, reuse_encoder=i > 0).cpu().numpy()
             assert rel(got, ref) < tol, (t, rel(got, ref))
         # the facade loop
-        sch = _ToyScheduler()
-        sch.set_timesteps(3)
-        x = noise.clone()
-        for k in sch.timesteps:
-            eps = oracle_net(sample=x, local_map=lm, timestep=torch.full((B,), float(k)), global_cond=cond)
-            x = sch.step(eps, k, x).prev_sample
+        def toy_loop():
+            sch = _ToyScheduler()
+            sch.set_timesteps(3)
+            x = noise.clone()
+            for k in sch.timesteps:
+                eps = oracle_net(sample=x, local_map=lm, timestep=torch.full((B,), float(k)), global_cond=cond)
+                x = sch.step(eps, k, x).prev_sample
+            return x
+        x = memo(("toy", id(oracle_net)), toy_loop)
     from ditreeonlineplanner_amd.policies.fm_policy import DiffusionSampler
     from ditreeonlineplanner_amd.model import NoisePredNet
     net = NoisePredNet()
@@ -390,11 +408,11 @@ def test_f16_range_guard_reports_a_clamped_layer(ctx, oracle_net, inputs):
     B = noise.shape[0]
     dev = ctx.device
     args = (noise.to(dev), lm.to(dev), cond.to(dev))
-    # healthy network: the guard stays silent in every instantiation
-    for prec in (2, 4):
-        _bind(ctx, oracle_net, prec, B)
-        ctx.denoise(*args, want_actions=False)
-        assert ctx.denoise_status() == []
+    # healthy network: the guard stays silent (the other f16 instantiation is covered by every other test of this module:
+    # Context.denoise raises when it fires)
+    _bind(ctx, oracle_net, 2, B)
+    ctx.denoise(*args, want_actions=False)
+    assert ctx.denoise_status() == []
     big = copy.deepcopy(oracle_net)
     key = "unet.mid_modules.0.cond_encoder.1"
     with torch.no_grad():

@@ -156,7 +156,8 @@ def cases():
             n = 6
             live = _oracle_planner(onet, maze, nodes, goal, noise).expand_round(samples[:n], cond[:n])
             assert np.array_equal(live["status"], refs[0]["status"][:n]) and np.array_equal(live["parent"], refs[0]["parent"][:n])
-            assert np.abs(live["states"] - refs[0]["states"][:n]).max() < 1e-6, "tests/golden/oracle_cache is stale: re-run make_oracle_cache.py"
+            # (torch-CPU convolutions differ by ~1e-6 between host CPUs: the probe catches a stale cache, not rounding)
+            assert np.abs(live["states"] - refs[0]["states"][:n]).max() < 2e-5, "tests/golden/oracle_cache is stale: re-run make_oracle_cache.py"
         out[name] = dict(maze=maze, nodes=nodes, goal=goal, samples=samples, cond=cond, noise=noise, refs=refs, B=Bc, rounds=rounds)
     return onet, out
 

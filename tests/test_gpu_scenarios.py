@@ -107,7 +107,8 @@ def test_plan_with_the_denoiser_matches_the_oracle_plan(net_and_ctx, tag, H):
     if cached:                     # live probe: the plan's first round re-computed now
         live = oracle_plan(onet, tag, H, budget=BATCH)
         n = len(live["parents"])
-        assert np.array_equal(live["parents"], op["parents"][:n]) and np.abs(live["states"] - op["states"][:n]).max() < 1e-6, \
+        # (torch-CPU convolutions differ by ~1e-6 between host CPUs: the probe catches a stale cache, not rounding)
+        assert np.array_equal(live["parents"], op["parents"][:n]) and np.abs(live["states"] - op["states"][:n]).max() < 2e-5, \
             "tests/golden/oracle_cache is stale: re-run make_oracle_cache.py"
     reached, path, actions = bool(op["reached"]), op["path"], op["actions"]
 
