@@ -117,23 +117,35 @@ ant_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, A
 #pragma unroll
     for (int k = 0; k < ANT_S; ++k) ho[(size_t)(0 - first_kept) * ANT_S + k] = s[k];
   }
-  int status = DITREE_ST_OK, steps = 0, i = 0;
-  double a[ANT_D];
-  for (; i < A; ++i) {
+  int status = DITREE_ST_OK, steps = 0;
+  double a[ANT_D], la[ANT_D];
+#pragma unroll
+  for (int k = 0; k < ANT_D; ++k) la[k] = 0.0;
+  // Rows are stored in LOCKSTEP (every lane stores row i + 1 in the same instruction: its state while the edge runs, the zero
+  // row of base_planner.py:282 afterwards), so candidate-minor storage writes whole 512-byte runs (see car_rollout_kernel).
+  bool alive = true;
+  for (int i = 0; i < A; ++i) {
 #pragma unroll
     for (int k = 0; k < ANT_D; ++k) a[k] = act[(size_t)i * ANT_D + k];
-    if constexpr (MODEL) {
-      ant_model_step(s, a, m);
-    } else {
+    if (alive) {
+      if constexpr (MODEL) {
+        ant_model_step(s, a, m);
+      } else {
 #pragma unroll
-      for (int k = 0; k < ANT_S; ++k) s[k] = tp[(size_t)i * ANT_S + k];
+        for (int k = 0; k < ANT_S; ++k) s[k] = tp[(size_t)i * ANT_S + k];
+      }
+      steps = i + 1;
+#pragma unroll
+      for (int k = 0; k < ANT_D; ++k) la[k] = a[k];
+    } else if (status == DITREE_ST_GOAL) {
+#pragma unroll
+      for (int k = 0; k < ANT_D; ++k) a[k] = 0.0;          // remaining actions zeroed on the goal branch only (:315)
     }
-    steps = i + 1;
     if (so) {
 #pragma unroll
-      for (int k = 0; k < ANT_S; ++k) so[(size_t)(i + 1) * sl.row + k * sl.comp] = s[k];
+      for (int k = 0; k < ANT_S; ++k) so[(size_t)(i + 1) * sl.row + k * sl.comp] = alive ? s[k] : 0.0;
     }
-    if (ho && i + 1 - first_kept >= 0) {
+    if (ho && alive && i + 1 - first_kept >= 0) {
 #pragma unroll
       for (int k = 0; k < ANT_S; ++k) ho[(size_t)(i + 1 - first_kept) * ANT_S + k] = s[k];
     }
@@ -141,22 +153,14 @@ ant_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, A
 #pragma unroll
       for (int k = 0; k < ANT_D; ++k) ao[(size_t)i * al.row + k * al.comp] = a[k];
     }
-    const double ex = s[0] - gx, ey = s[1] - gy;
-    const bool done = sqrt(fma(ey, ey, ex * ex)) < goal_radius;      // np.linalg.norm (ddot = one fma), base_planner.py:296-297
-    const bool coll = ant_collides(s, lds, rows, cols, s_global, ball_radius);   // :306 before :314
-    if (coll) { status = DITREE_ST_COLLIDED; ++i; break; }
-    if (done) { status = DITREE_ST_GOAL; ++i; break; }
-  }
-  for (int r = i; r < A; ++r) {                           // rows after the last executed step: states stay zero (:282), actions
-    if (so) {                                             // are zeroed only on the goal branch (:315)
-#pragma unroll
-      for (int k = 0; k < ANT_S; ++k) so[(size_t)(r + 1) * sl.row + k * sl.comp] = 0.0;
+    if (alive) {
+      const double ex = s[0] - gx, ey = s[1] - gy;
+      const bool done = sqrt(fma(ey, ey, ex * ex)) < goal_radius;      // np.linalg.norm (ddot = one fma), base_planner.py:296-297
+      const bool coll = ant_collides(s, lds, rows, cols, s_global, ball_radius);   // :306 before :314
+      if (coll) { status = DITREE_ST_COLLIDED; alive = false; }
+      else if (done) { status = DITREE_ST_GOAL; alive = false; }
     }
-    if (ao) {
-      const bool z = (status == DITREE_ST_GOAL);
-#pragma unroll
-      for (int k = 0; k < ANT_D; ++k) ao[(size_t)r * al.row + k * al.comp] = z ? 0.0 : act[(size_t)r * ANT_D + k];
-    }
+    if (states_out == nullptr && actions_out == nullptr && !__any(alive)) break;
   }
 #pragma unroll
   for (int k = 0; k < ANT_S; ++k) state_io[(size_t)b * ANT_S + k] = s[k];
@@ -166,7 +170,7 @@ ant_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, A
   if (status == DITREE_ST_OK) {
     if (prev_action_io) {                                 // RRT.py:188 prev_actions = curr_action_seq (its last row conditions)
 #pragma unroll
-      for (int k = 0; k < ANT_D; ++k) prev_action_io[(size_t)b * ANT_D + k] = a[k];
+      for (int k = 0; k < ANT_D; ++k) prev_action_io[(size_t)b * ANT_D + k] = la[k];
       if (has_prev_io) has_prev_io[b] = 1;
     }
     if (hist_n) hist_n[b] = A + 1 < 3 ? A + 1 : 3;

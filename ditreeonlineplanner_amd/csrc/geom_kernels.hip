@@ -372,51 +372,60 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
   int steps = 0;
   double la0 = 0.0, la1 = 0.0;
   int i = 0;
-  for (; i < A; ++i) {
-    const double a0r = act[2 * i], a1r = act[2 * i + 1];
-    car_euler_step(s, a0r, a1r);
-    steps = i + 1;
+  // Software pipelining of the two dependent chains of a step: the dynamics of step i + 1 need only the state after step i,
+  // not the outcome of its goal / collision tests -- so they are evaluated speculatively in the same basic block as those
+  // tests (independent instruction streams for a SIMD that holds a single wave of this kernel at 65 536 candidates) and
+  // thrown away when step i ends the edge.  Same arithmetic on the same operands: results are bit-identical.
+  double sn[6];
+  double a0r = act[0], a1r = act[1];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) sn[k] = s[k];
+  car_euler_step(sn, a0r, a1r);
+  // Rows are stored in LOCKSTEP: every lane of the wave stores row i + 1 in the same instruction -- the state while its edge is
+  // running, the zero row (base_planner.py:282) once it has ended -- so with candidate-minor storage every store is a whole
+  // 512-byte run (a lane that zero-filled its tail later, on its own, wrote partial sectors that the memory system first had
+  // to fetch: 1.7 x the algorithmic bytes, profiles/r04_rollout_pmc_traffic.json "before").
+  bool alive = true;
+  for (i = 0; i < A; ++i) {
+    double c0r = act[2 * i], c1r = act[2 * i + 1];
+    if (alive) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s[k] = sn[k];                                  // the state after step i
+      if (i + 1 < A) car_euler_step(sn, act[2 * (i + 1)], act[2 * (i + 1) + 1]);   // speculative: step i + 1
+      steps = i + 1;
+      la0 = c0r; la1 = c1r;
+    } else if (status == DITREE_ST_GOAL) {
+      c0r = 0.0; c1r = 0.0;                                                       // :314-317; a collided edge's tail is copied through
+    }
     if (so) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) so[(size_t)(i + 1) * sl.row + k * sl.comp] = s[k];
+      for (int k = 0; k < 6; ++k) so[(size_t)(i + 1) * sl.row + k * sl.comp] = alive ? s[k] : 0.0;
     }
-    if (ao) { ao[(size_t)i * al.row] = a0r; ao[(size_t)i * al.row + al.comp] = a1r; }
-    la0 = a0r; la1 = a1r;
-    double ex = s[0] - gx, ey = s[1] - gy;
-    bool done = sqrt(fma(ey, ey, ex * ex)) < 0.5;   // np.linalg.norm (ddot rounds as one fma), car_env.py:346-351
-    bool coll;                                                                   // base_planner.py:306
-    if constexpr (G == 2) {
-      const double off = 0.15 * 0.5, sgn = g ? -1.0 : 1.0;                       // common/map_utils.py:103-115: lane g, ball g
-      const double ox = off * cos(s[2]), oy = off * sin(s[2]);
-      const int mine = ball_collides(s[0] + sgn * ox, s[1] + sgn * oy, lds, rows, cols) ? 1 : 0;
+    if (ao) { ao[(size_t)i * al.row] = c0r; ao[(size_t)i * al.row + al.comp] = c1r; }
+    bool coll = false, done = false;
+    if (alive) {
+      const double ex = s[0] - gx, ey = s[1] - gy;
+      done = sqrt(fma(ey, ey, ex * ex)) < 0.5;      // np.linalg.norm (ddot rounds as one fma), car_env.py:346-351
+    }
+    if constexpr (G == 2) {                         // both lanes of a pair stay in step (the exchange below is pair-wide)
+      int mine = 0;
+      if (alive) {
+        const double off = 0.15 * 0.5, sgn = g ? -1.0 : 1.0;                     // common/map_utils.py:103-115: lane g, ball g
+        const double ox = off * cos(s[2]), oy = off * sin(s[2]);
+        mine = ball_collides(s[0] + sgn * ox, s[1] + sgn * oy, lds, rows, cols) ? 1 : 0;
+      }
       coll = (mine | __shfl_xor(mine, 1)) != 0;
-    } else {
-      coll = car_collides(s[0], s[1], s[2], lds, rows, cols);
+    } else if (alive) {
+      coll = car_collides(s[0], s[1], s[2], lds, rows, cols);                     // base_planner.py:306
     }
-    if (coll) {
+    if (alive && coll) {
       status = DITREE_ST_COLLIDED | (done ? DITREE_ST_FLAG_GOAL_AT_COLLISION : 0);
-      ++i;
-      break;
-    }
-    if (done) {                                                                   // :314-317
+      alive = false;
+    } else if (alive && done) {                                                   // :314-317
       status = DITREE_ST_GOAL;
-      ++i;
-      break;
+      alive = false;
     }
-  }
-  // rows after the last executed step stay zero (states :282; actions zeroed :315)
-  for (int r = i; r < A; ++r) {
-    if (so) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) so[(size_t)(r + 1) * sl.row + k * sl.comp] = 0.0;
-    }
-    if (ao) {
-      // only the goal branch zeroes the remaining actions (:314-317); a collided edge is discarded
-      // by the caller, its untouched tail is copied through like the reference's array
-      const bool z = (status == DITREE_ST_GOAL);
-      ao[(size_t)r * al.row] = z ? 0.0 : act[2 * r];
-      ao[(size_t)r * al.row + al.comp] = z ? 0.0 : act[2 * r + 1];
-    }
+    if (states_out == nullptr && actions_out == nullptr && !__any(alive)) break;  // nothing left to run or to write in this wave
   }
   if (G == 2 && g != 0) return;                       // per-candidate results: lane 0
 #pragma unroll
