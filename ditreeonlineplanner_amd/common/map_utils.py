@@ -4,9 +4,9 @@
   run_scenarios_with_lidar_DiTree.py:409,463; incremented by the reference in ``is_colliding_car``,
   common/map_utils.py:103-105).  ``RRT_Planner.plan`` adds the number of env steps its rounds executed on the GPU
   (one two-ball test per step, as the reference: base_planner.py:290-312).
-* ``is_colliding_car`` / ``create_local_map`` -- same signatures, evaluated by the HIP kernels (bit-exact flags / maps,
-  tests/test_gpu_geometry.py).
-Anything else of the reference module (forest / PNG helpers, ant / drone collision) is resolved lazily from the
+* ``is_colliding_car`` / ``create_local_map`` / ``is_colliding_ant`` / ``is_colliding_maze`` -- same signatures, evaluated by
+  the HIP kernels (bit-exact flags / maps, tests/test_gpu_geometry.py, tests/test_gpu_ant_round.py).
+Anything else of the reference module (forest / PNG helpers, drone collision) is resolved lazily from the
 reference checkout when one is on the path (PEP 562 ``__getattr__``)."""
 from __future__ import annotations
 
@@ -68,6 +68,27 @@ def create_local_map(global_map, x, y, theta, map_size, scale, s_global, map_cen
     st[:, 0], st[:, 1], st[:, 2] = x, y, theta
     out = ctx.local_map(torch.as_tensor(st, device=ctx.device), n=N, scale=float(scale), s_global=float(s_global))
     return out.cpu().numpy().astype(gm.dtype if gm.dtype.kind == "f" else np.float32)
+
+
+def is_colliding_maze(state, maze_grid, maze_size_scaling=1, ball_radius=0.1):
+    """common/map_utils.py:139-219 (one ball; the point-maze / ant collision test) on the device: `ant_collision` with an
+    upright torso."""
+    import torch
+    ctx = _ctx()
+    ctx.upload_maze(np.asarray(maze_grid, dtype=np.float32), owner=None)
+    st = np.zeros((1, 7))
+    st[0, :2] = np.asarray(state, dtype=np.float64)[:2]
+    st[0, 3] = 1.0
+    return bool(ctx.ant_collision(torch.as_tensor(st, device=ctx.device), float(ball_radius), float(maze_size_scaling))[0].item())
+
+
+def is_colliding_ant(state, maze_map, ant_radius=1, map_scale=1):
+    """common/map_utils.py:126-136: upside down (body z axis below the horizon) or the single-ball maze test, on the device."""
+    import torch
+    ctx = _ctx()
+    ctx.upload_maze(np.asarray(maze_map, dtype=np.float32), owner=None)
+    st = np.asarray(state, dtype=np.float64).reshape(1, -1)
+    return bool(ctx.ant_collision(torch.as_tensor(np.ascontiguousarray(st), device=ctx.device), float(ant_radius), float(map_scale))[0].item())
 
 
 _REF = None

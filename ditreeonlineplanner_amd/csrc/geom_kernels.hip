@@ -330,7 +330,7 @@ void launch_path_after_obstacle(const float* path, int stride, int P, double cx,
 // G lanes per candidate (1 or 2).  G = 2: both lanes of a pair integrate the (identical) dynamics, lane g tests ball g and the
 // pair ORs by one lane exchange, lane 0 stores the state rows and lane 1 the action rows -- twice the waves for the same batch
 // (two per SIMD at 65 536 candidates), each with a shorter chain per step.  Same arithmetic, same results.
-template <int G>
+template <int G, bool LOCKSTEP>
 __global__ void __launch_bounds__(256)
 car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, double* __restrict__ state_io,
                    const double* __restrict__ actions, int64_t act_stride, int32_t* __restrict__ status_io, int B,
@@ -372,60 +372,98 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
   int steps = 0;
   double la0 = 0.0, la1 = 0.0;
   int i = 0;
-  // Software pipelining of the two dependent chains of a step: the dynamics of step i + 1 need only the state after step i,
-  // not the outcome of its goal / collision tests -- so they are evaluated speculatively in the same basic block as those
-  // tests (independent instruction streams for a SIMD that holds a single wave of this kernel at 65 536 candidates) and
-  // thrown away when step i ends the edge.  Same arithmetic on the same operands: results are bit-identical.
-  double sn[6];
-  double a0r = act[0], a1r = act[1];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) sn[k] = s[k];
-  car_euler_step(sn, a0r, a1r);
-  // Rows are stored in LOCKSTEP: every lane of the wave stores row i + 1 in the same instruction -- the state while its edge is
-  // running, the zero row (base_planner.py:282) once it has ended -- so with candidate-minor storage every store is a whole
-  // 512-byte run (a lane that zero-filled its tail later, on its own, wrote partial sectors that the memory system first had
-  // to fetch: 1.7 x the algorithmic bytes, profiles/r04_rollout_pmc_traffic.json "before").
-  bool alive = true;
-  for (i = 0; i < A; ++i) {
-    double c0r = act[2 * i], c1r = act[2 * i + 1];
-    if (alive) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) s[k] = sn[k];                                  // the state after step i
-      if (i + 1 < A) car_euler_step(sn, act[2 * (i + 1)], act[2 * (i + 1) + 1]);   // speculative: step i + 1
-      steps = i + 1;
-      la0 = c0r; la1 = c1r;
-    } else if (status == DITREE_ST_GOAL) {
-      c0r = 0.0; c1r = 0.0;                                                       // :314-317; a collided edge's tail is copied through
-    }
-    if (so) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) so[(size_t)(i + 1) * sl.row + k * sl.comp] = alive ? s[k] : 0.0;
-    }
-    if (ao) { ao[(size_t)i * al.row] = c0r; ao[(size_t)i * al.row + al.comp] = c1r; }
-    bool coll = false, done = false;
-    if (alive) {
-      const double ex = s[0] - gx, ey = s[1] - gy;
-      done = sqrt(fma(ey, ey, ex * ex)) < 0.5;      // np.linalg.norm (ddot rounds as one fma), car_env.py:346-351
-    }
-    if constexpr (G == 2) {                         // both lanes of a pair stay in step (the exchange below is pair-wide)
-      int mine = 0;
+  if constexpr (LOCKSTEP) {
+    // Candidate-minor rows (sl.cand == 1) are stored in LOCKSTEP: every lane of the wave stores row i + 1 in the same
+    // instruction -- its state while its edge is running, the zero row (base_planner.py:282) once it has ended -- so every store
+    // is a whole 512-byte run.  (A lane that zero-filled its tail later, on its own, wrote partial sectors that the memory
+    // system first had to fetch: 162 MB per launch for 94 MB of algorithmic bytes at 65 536 x 16, 111 MB in lockstep --
+    // profiles/r04_rollout_*pmc_traffic.json.)
+    bool alive = true;
+    for (i = 0; i < A; ++i) {
+      double c0r = act[2 * i], c1r = act[2 * i + 1];
       if (alive) {
-        const double off = 0.15 * 0.5, sgn = g ? -1.0 : 1.0;                     // common/map_utils.py:103-115: lane g, ball g
-        const double ox = off * cos(s[2]), oy = off * sin(s[2]);
-        mine = ball_collides(s[0] + sgn * ox, s[1] + sgn * oy, lds, rows, cols) ? 1 : 0;
+        car_euler_step(s, c0r, c1r);
+        steps = i + 1;
+        la0 = c0r; la1 = c1r;
+      } else if (status == DITREE_ST_GOAL) {
+        c0r = 0.0; c1r = 0.0;                                                     // :314-317; a collided edge's tail is copied through
       }
-      coll = (mine | __shfl_xor(mine, 1)) != 0;
-    } else if (alive) {
-      coll = car_collides(s[0], s[1], s[2], lds, rows, cols);                     // base_planner.py:306
+      if (so) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) so[(size_t)(i + 1) * sl.row + k * sl.comp] = alive ? s[k] : 0.0;
+      }
+      if (ao) { ao[(size_t)i * al.row] = c0r; ao[(size_t)i * al.row + al.comp] = c1r; }
+      bool coll = false, done = false;
+      if (alive) {
+        const double ex = s[0] - gx, ey = s[1] - gy;
+        done = sqrt(fma(ey, ey, ex * ex)) < 0.5;    // np.linalg.norm (ddot rounds as one fma), car_env.py:346-351
+      }
+      if constexpr (G == 2) {                       // both lanes of a pair stay in step (the exchange below is pair-wide)
+        int mine = 0;
+        if (alive) {
+          const double off = 0.15 * 0.5, sgn = g ? -1.0 : 1.0;                   // common/map_utils.py:103-115: lane g, ball g
+          const double ox = off * cos(s[2]), oy = off * sin(s[2]);
+          mine = ball_collides(s[0] + sgn * ox, s[1] + sgn * oy, lds, rows, cols) ? 1 : 0;
+        }
+        coll = (mine | __shfl_xor(mine, 1)) != 0;
+      } else if (alive) {
+        coll = car_collides(s[0], s[1], s[2], lds, rows, cols);                   // base_planner.py:306
+      }
+      if (alive && coll) {
+        status = DITREE_ST_COLLIDED | (done ? DITREE_ST_FLAG_GOAL_AT_COLLISION : 0);
+        alive = false;
+      } else if (alive && done) {                                                 // :314-317
+        status = DITREE_ST_GOAL;
+        alive = false;
+      }
     }
-    if (alive && coll) {
-      status = DITREE_ST_COLLIDED | (done ? DITREE_ST_FLAG_GOAL_AT_COLLISION : 0);
-      alive = false;
-    } else if (alive && done) {                                                   // :314-317
-      status = DITREE_ST_GOAL;
-      alive = false;
+  } else {
+    for (; i < A; ++i) {
+      const double a0r = act[2 * i], a1r = act[2 * i + 1];
+      car_euler_step(s, a0r, a1r);
+      steps = i + 1;
+      if (so) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) so[(size_t)(i + 1) * sl.row + k * sl.comp] = s[k];
+      }
+      if (ao) { ao[(size_t)i * al.row] = a0r; ao[(size_t)i * al.row + al.comp] = a1r; }
+      la0 = a0r; la1 = a1r;
+      double ex = s[0] - gx, ey = s[1] - gy;
+      bool done = sqrt(fma(ey, ey, ex * ex)) < 0.5;   // np.linalg.norm (ddot rounds as one fma), car_env.py:346-351
+      bool coll;                                                                   // base_planner.py:306
+      if constexpr (G == 2) {
+        const double off = 0.15 * 0.5, sgn = g ? -1.0 : 1.0;                       // common/map_utils.py:103-115: lane g, ball g
+        const double ox = off * cos(s[2]), oy = off * sin(s[2]);
+        const int mine = ball_collides(s[0] + sgn * ox, s[1] + sgn * oy, lds, rows, cols) ? 1 : 0;
+        coll = (mine | __shfl_xor(mine, 1)) != 0;
+      } else {
+        coll = car_collides(s[0], s[1], s[2], lds, rows, cols);
+      }
+      if (coll) {
+        status = DITREE_ST_COLLIDED | (done ? DITREE_ST_FLAG_GOAL_AT_COLLISION : 0);
+        ++i;
+        break;
+      }
+      if (done) {                                                                   // :314-317
+        status = DITREE_ST_GOAL;
+        ++i;
+        break;
+      }
     }
-    if (states_out == nullptr && actions_out == nullptr && !__any(alive)) break;  // nothing left to run or to write in this wave
+    // rows after the last executed step stay zero (states :282; actions zeroed :315)
+    for (int r = i; r < A; ++r) {
+      if (so) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) so[(size_t)(r + 1) * sl.row + k * sl.comp] = 0.0;
+      }
+      if (ao) {
+        // only the goal branch zeroes the remaining actions (:314-317); a collided edge is discarded
+        // by the caller, its untouched tail is copied through like the reference's array
+        const bool z = (status == DITREE_ST_GOAL);
+        ao[(size_t)r * al.row] = z ? 0.0 : act[2 * r];
+        ao[(size_t)r * al.row + al.comp] = z ? 0.0 : act[2 * r + 1];
+      }
+    }
   }
   if (G == 2 && g != 0) return;                       // per-candidate results: lane 0
 #pragma unroll
@@ -456,16 +494,16 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
   static int lanes_env = -1;
   if (lanes_env < 0) { const char* e = getenv("DITREE_ROLLOUT_LANES"); lanes_env = e ? atoi(e) : 0; }
   const int G = lanes_env == 1 ? 1 : (lanes_env == 2 ? 2 : (B <= 32768 ? 2 : 1));
-  if (G == 2)
-    hipLaunchKernelGGL(car_rollout_kernel<2>, dim3((2 * B + blk - 1) / blk), dim3(blk), lds, s, maze, rows, cols, state_io,
-                       actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out,
-                       actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense,
-                       budget, chunk_j, cs);
-  else
-    hipLaunchKernelGGL(car_rollout_kernel<1>, dim3((B + blk - 1) / blk), dim3(blk), lds, s, maze, rows, cols, state_io,
-                       actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out,
-                       actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense,
-                       budget, chunk_j, cs);
+  // lockstep row stores pay with candidate-minor rows (whole 512-byte runs); with rows packed per candidate they cost 27 %
+  // (dead lanes keep storing zero rows step by step: profiles/r04_rollout_layout_probe.json) -- chosen by the layout
+  const int pipe_env = ((states_out && states_stride.cand == 1) || (!states_out && actions_out && actout_stride.cand == 1)) ? 1 : 0;
+#define CAR_ROLLOUT_LAUNCH(GG, PP)                                                                                          \
+  hipLaunchKernelGGL((car_rollout_kernel<GG, PP>), dim3((GG * B + blk - 1) / blk), dim3(blk), lds, s, maze, rows, cols, state_io, \
+                     actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out, actout_stride,      \
+                     steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense, budget, chunk_j, cs)
+  if (G == 2) { if (pipe_env) CAR_ROLLOUT_LAUNCH(2, true); else CAR_ROLLOUT_LAUNCH(2, false); }
+  else { if (pipe_env) CAR_ROLLOUT_LAUNCH(1, true); else CAR_ROLLOUT_LAUNCH(1, false); }
+#undef CAR_ROLLOUT_LAUNCH
 }
 void launch_car_rollout(const unsigned char* maze, int rows, int cols, double* state_io, const double* actions,
                         int64_t act_stride, int32_t* status_io, int B, int A, double gx, double gy,

@@ -171,13 +171,16 @@ class Context:
         return out
 
     # ------------------------------------------------------------------ rollout
-    def car_rollout(self, state, actions, goal_xy, A=8, status=None, prev_action=None, has_prev=None, out=None, layout=None):
+    def car_rollout(self, state, actions, goal_xy, A=8, status=None, prev_action=None, has_prev=None, out=None, layout=None,
+                    want_actions=True):
         """state (B,6) f64 [updated in place], actions (B, n>=A, 2) f64.
         Returns (status, states (B,A+1,6), actions_out (B,A,2), steps).  ``out``: a previous return value whose
         buffers are reused (the kernel writes every row, so no clearing is needed).
         ``layout``: "rows" = rows packed per candidate (the reference's arrays), "soa" = step-major / component-major /
         candidate-minor storage (every store of a wavefront is one contiguous 512-byte run; the returned tensors are
-        permuted VIEWS of it with the same (B, A+1, 6) / (B, A, 2) shapes).  Default: "soa" from 4096 candidates up."""
+        permuted VIEWS of it with the same (B, A+1, 6) / (B, A, 2) shapes).  Default: "soa" from 4096 candidates up.
+        ``want_actions=False``: the (A, 2) copy of the executed actions (the reference returns it, base_planner.py:318-320) is
+        not written -- consumers that hold the actions already (an MPPI-style sweep) save 16 A bytes per rollout."""
         dev = self.device
         _chk(state, torch.float64, "state", dev)
         _chk(actions, torch.float64, "actions", dev)
@@ -199,11 +202,15 @@ class Context:
             aout = torch.zeros(B, A, 2, dtype=torch.float64, device=dev)
             steps = torch.zeros(B, dtype=torch.int32, device=dev)
         g, gp = _dbl(goal_xy)
-        sl, al = _lib.Strides(*states.stride()), _lib.Strides(*aout.stride())
+        if want_actions and aout is None:
+            aout = (torch.zeros(A, 2, B, dtype=torch.float64, device=dev).permute(2, 0, 1) if layout == "soa"
+                    else torch.zeros(B, A, 2, dtype=torch.float64, device=dev))
+        sl = _lib.Strides(*states.stride())
+        al = _lib.Strides(*aout.stride()) if aout is not None else _lib.Strides(2 * A, 2, 1)
         check(self._h, lib().ditree_car_rollout_ld(self._h, _ptr(state), _ptr(actions), actions.shape[1] * 2, _ptr(status), B, A,
-                                                    gp, _ptr(states), C.byref(sl), _ptr(aout), C.byref(al), _ptr(steps),
-                                                    _ptr(prev_action), _ptr(has_prev), self.stream), "car_rollout")
-        return status, states, aout, steps
+                                                    gp, _ptr(states), C.byref(sl), _ptr(aout) if want_actions else None, C.byref(al),
+                                                    _ptr(steps), _ptr(prev_action), _ptr(has_prev), self.stream), "car_rollout")
+        return status, states, (aout if want_actions else None), steps
 
     # ------------------------------------------------------------------ ant: collision glue + the higher-DoF rollout slot
     def ant_collision(self, state, ball_radius=1.2, s_global=4.0):

@@ -105,6 +105,8 @@ for name, (so, ao) in avariants.items():
     res["ant_model"][name]["algorithmic_MB"] = (K * (232 + 64 * T) + (K * 232 * (T + 1) if so is not None else 0) + (K * 64 * T if ao is not None else 0) + K * 240) / 1e6
     res["ant_model"][name]["collided"] = int((status == 2).sum().item())
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-with open(os.path.join(REPO, "gpurun_out", "rollout_layout_probe.json"), "w") as f:
+res["car_kernel_variant"] = "software-pipelined steps (DITREE_ROLLOUT_PIPELINE=1)" if os.environ.get("DITREE_ROLLOUT_PIPELINE") == "1" else "default"
+name = sys.argv[1] if len(sys.argv) > 1 else "rollout_layout_probe"
+with open(os.path.join(REPO, "gpurun_out", name + ".json"), "w") as f:
     json.dump(res, f, indent=1)
 print(json.dumps(res, indent=1))

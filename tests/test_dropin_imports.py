@@ -123,3 +123,34 @@ def test_launcher_puts_dropin_first(tmp_path):
     assert out["OTHER"] == "from the checkout"
     assert os.path.realpath(out["CWD"]) == os.path.realpath(str(root))
     assert out["ARGV"] == "['--flag', '3']"
+
+
+def test_engine_names_win_over_a_reference_checkout_on_the_path(tmp_path, monkeypatch):
+    """common.map_utils falls through to the USER's reference checkout for names the engine does not provide (forest / PNG
+    helpers) -- it must never let the checkout shadow a hot-path name: is_colliding_car / create_local_map / is_colliding_ant /
+    is_colliding_maze / cc_calls stay the engine's even when a checkout that defines them is first on the path."""
+    import importlib
+    ck = tmp_path / "checkout" / "common"
+    ck.mkdir(parents=True)
+    (ck / "map_utils.py").write_text(
+        "cc_calls = -7\n"
+        "def is_colliding_car(*a, **k): return 'REFERENCE'\n"
+        "def create_local_map(*a, **k): return 'REFERENCE'\n"
+        "def is_colliding_ant(*a, **k): return 'REFERENCE'\n"
+        "def is_colliding_maze(*a, **k): return 'REFERENCE'\n"
+        "def load_forest_png(path): return ('from the checkout', path)\n")
+    monkeypatch.setenv("DITREE_REFERENCE_ROOT", str(tmp_path / "checkout"))
+    monkeypatch.syspath_prepend(str(tmp_path / "checkout"))
+    from ditreeonlineplanner_amd.common import map_utils as mu
+    importlib.reload(mu)
+    try:
+        for name in ("is_colliding_car", "create_local_map", "is_colliding_ant", "is_colliding_maze", "add_cc_calls"):
+            fn = getattr(mu, name)
+            assert fn.__module__ == "ditreeonlineplanner_amd.common.map_utils", name       # the engine's, not the checkout's
+        assert mu.cc_calls == 0
+        assert mu.load_forest_png("x.png") == ("from the checkout", "x.png")              # fall-through for everything else
+        with pytest.raises(AttributeError):
+            mu.no_such_name
+    finally:
+        monkeypatch.delenv("DITREE_REFERENCE_ROOT")
+        importlib.reload(mu)

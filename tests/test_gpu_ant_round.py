@@ -54,6 +54,14 @@ def test_ant_collision_bit_exact_against_reference_goldens(ctx):
     assert np.array_equal(ctx.ant_collision(dev(st), 1.2, 4.0).cpu().numpy().astype(bool), g["antcol_boxes_expected"][:512])
     with pytest.raises(ValueError):
         ctx.ant_collision(dev(np.zeros((4, 6))))
+    # the reference-named functions of common.map_utils (what a driver script imports) are the same kernels
+    from ditreeonlineplanner_amd.common import map_utils as mu
+    maze = load_maze("boxes")
+    st, exp = g["antcol_boxes_states"], g["antcol_boxes_expected"]
+    for i in range(0, 4096, 173):
+        assert mu.is_colliding_ant(st[i], maze, 1.2, 4.0) == bool(exp[i])
+        if OA.body_z_up(st[i, 3:7]) >= 0 and np.isfinite(st[i, :2]).all():
+            assert mu.is_colliding_maze(st[i, :3], maze, 4.0, 1.2) == bool(exp[i])
 
 
 # ------------------------------------------------------------------------------------------ the rollout slot
