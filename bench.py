@@ -309,8 +309,9 @@ def run_rollout(args):
     """BASELINE config 5 -- "65 536 MPPI rollouts" -- as SURVEY.md section 8(d) defines it: the car rollout kernel alone
     (propagate_action_sequence_env + CarEnv.step + is_colliding_car fused), K rollouts of T = 16 steps per launch per GPU,
     every rank its own K (the path shards by rollout, no collective).  Algorithmic bytes per rollout: 48 (state) + 16 T
-    (actions, f64) + 48 T (states) + 8 (flags) = 56 + 64 T.  State rows are stored step-major / candidate-minor in lockstep (whole
-    512-byte runs per wave store); the copy of the executed actions is not requested (the caller holds them)."""
+    (actions, f64) + 48 T (states) + 8 (flags) = 56 + 64 T (the kernel's contract also returns the start row and the (T, 2) copy of
+    the executed actions, as the reference does: 1 432 B per rollout).  Rows are stored step-major / candidate-minor in lockstep
+    (whole 512-byte runs per wave store)."""
     rank, world, local, dist, rehearse = _dist_setup(args)
     from ditreeonlineplanner_amd.ops import Context
     K = args.batch if args.batch_set else 65536
@@ -343,7 +344,7 @@ def run_rollout(args):
         timed = it[0] >= args.warmup
         if timed:
             ev[it[0] - args.warmup][0].record()
-        out["r"] = ctx.car_rollout(state, a, goal, A=T, status=status, out=out.get("r"), want_actions=False)
+        out["r"] = ctx.car_rollout(state, a, goal, A=T, status=status, out=out.get("r"))
         if timed:
             ev[it[0] - args.warmup][1].record()
         it[0] += 1

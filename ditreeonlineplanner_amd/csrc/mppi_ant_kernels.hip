@@ -222,16 +222,16 @@ mppi_ant_finish_kernel(const unsigned char* __restrict__ maze, int rows, int col
                        double* __restrict__ sums, double* __restrict__ result, int do_sums, int do_apply, int do_execute) {
   const int nacc = 3 + AM_NU * a.T;
   if (do_sums) {
-    __shared__ double wsum[4];
-    for (int j = 0; j < nacc; ++j) {
-      double v = (int)threadIdx.x < slices ? partial[(size_t)threadIdx.x * nacc + j] : 0.0;
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-      if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
-      __syncthreads();
-      if (threadIdx.x == 0) sums[j] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-      __syncthreads();
+    // thread j adds value j of the slices in slice order (one fixed order: reproducible); 3 + 8 T values, <= 256 slices --
+    // the loads of a value are independent, only the adds chain (a per-value block reduction with two barriers each took
+    // 98 us for the 131 values of T = 16: profiles/r04_mppi_ant_bench_kernel_stats.csv)
+    for (int j = threadIdx.x; j < nacc; j += 256) {
+      double acc = 0.0;
+      for (int sl = 0; sl < slices; ++sl) acc += partial[(size_t)sl * nacc + j];
+      sums[j] = acc;
     }
+    __threadfence_block();
+    __syncthreads();
   }
   if (do_apply) {
     const double eta = sums[0];
