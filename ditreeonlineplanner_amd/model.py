@@ -34,7 +34,9 @@ def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
 
 class NoisePredNet(nn.Module):
     def __init__(self, input_dim=2, embedding_dim=400, additional_global_cond_dim=7,
-                 down_dims=(512, 1024, 2048), pred_horizon=64, local_map_size=20, seed=None):
+                 down_dims=(512, 1024, 2048), pred_horizon=64, local_map_size=20, seed=None, init=True):
+        """``init=False``: parameters are allocated but not initialised -- for a net that is filled by ``load_state_dict`` right
+        away (initialising 184 M parameters takes longer than loading them)."""
         super().__init__()
         self.input_dim, self.embedding_dim = input_dim, embedding_dim
         self.down_dims = tuple(int(d) for d in down_dims)
@@ -43,7 +45,8 @@ class NoisePredNet(nn.Module):
         gen = torch.Generator().manual_seed(0 if seed is None else seed)
         for name, shape in noise_pred_net_param_shapes(input_dim, embedding_dim, additional_global_cond_dim,
                                                         down_dims).items():
-            _attach(self, name, nn.Parameter(self._init(name, shape, gen), requires_grad=False))
+            value = self._init(name, shape, gen) if init else torch.empty(shape)
+            _attach(self, name, nn.Parameter(value, requires_grad=False))
         self._ctx = None
         self.precision = _lib.PREC_BF16
         self._reserved = 0

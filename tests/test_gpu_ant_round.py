@@ -292,7 +292,7 @@ def ant_net():
 
 def _bind(ctx, ant_net, prec, B):
     from ditreeonlineplanner_amd.model import NoisePredNet
-    net = NoisePredNet(input_dim=8, additional_global_cond_dim=97, pred_horizon=16, local_map_size=16)
+    net = NoisePredNet(input_dim=8, additional_global_cond_dim=97, pred_horizon=16, local_map_size=16, init=False)
     net.load_state_dict(ant_net.state_dict())
     net.bind(ctx, precision=prec, max_batch=B)
     return net

@@ -35,7 +35,7 @@ def test_config4_round_with_denoiser_in_the_loop_then_lidar():
     nodes, goal, samples, cond, noise = bench.synth_inputs(maze, B, seed=20260404)
     torch.manual_seed(0)
     onet = OD.init_noise_pred_net().eval()
-    net = NoisePredNet()
+    net = NoisePredNet(init=False)
     net.load_state_dict(onet.state_dict())
     net.bind(ctx, precision=_lib.PREC_F16X3, max_batch=B)
     eng = ExpansionEngine(ctx, maze, nodes[0], goal, edge_length=H, action_horizon=A, pred_horizon=P, batch=B,

@@ -116,7 +116,7 @@ def ctx():
 
 def _bind(ctx, oracle_net, prec, B):
     from ditreeonlineplanner_amd.model import NoisePredNet
-    net = NoisePredNet()
+    net = NoisePredNet(init=False)
     net.load_state_dict(oracle_net.state_dict())
     net.bind(ctx, precision=prec, max_batch=B)
     return net
@@ -305,7 +305,7 @@ def test_raw_network_evaluation_and_diffusion_loop(ctx, oracle_net, inputs, prec
         x = memo(("toy", id(oracle_net)), toy_loop)
     from ditreeonlineplanner_amd.policies.fm_policy import DiffusionSampler
     from ditreeonlineplanner_amd.model import NoisePredNet
-    net = NoisePredNet()
+    net = NoisePredNet(init=False)
     net.load_state_dict(oracle_net.state_dict())
     smp = DiffusionSampler(net, _ToyScheduler(), "carmaze", policy="diffusion", pred_horizon=64, action_dim=2,
                            prediction_type="actions", obs_history=1, action_history=1, goal_conditioned=True,
@@ -384,7 +384,7 @@ def test_other_denoiser_sizes(ctx, inputs, size, dims, prec):
         _SIZE_CACHE.clear()                           # keep one size at a time (memory)
         _SIZE_CACHE[size] = (onet, OS.flow_sample(onet, noise[:B], lm[:B], cond[:B], k_steps=1))
     onet, x_ref = _SIZE_CACHE[size]
-    net = NoisePredNet(down_dims=dims)
+    net = NoisePredNet(down_dims=dims, init=False)
     net.load_state_dict(onet.state_dict())
     if prec == 2 and size == "small":
         # the split instantiations only exist on the 256-channel tiles: a clean error, not a fallback

@@ -174,7 +174,7 @@ def run_engine(ctx, onet, st, prec):
     from ditreeonlineplanner_amd.engine import CNT_GOAL, CNT_LATCH, CNT_NODES, ExpansionEngine
     from ditreeonlineplanner_amd.model import NoisePredNet
     Bc, rounds = st["B"], st["rounds"]
-    net = NoisePredNet()
+    net = NoisePredNet(init=False)
     net.load_state_dict(onet.state_dict())
     net.bind(ctx, precision=prec, max_batch=Bc)
     eng = ExpansionEngine(ctx, st["maze"], st["nodes"][0], st["goal"], edge_length=H, action_horizon=A, pred_horizon=P,

@@ -87,7 +87,7 @@ def net_and_ctx():
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     onet = make_onet()
     ctx = Context(0)
-    net = NoisePredNet()
+    net = NoisePredNet(init=False)
     net.load_state_dict(onet.state_dict())
     net.bind(ctx, precision=_lib.PREC_F16X3, max_batch=BATCH)
     yield onet, ctx
