@@ -338,7 +338,7 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
                    double* __restrict__ actions_out, ditree_strides al, int32_t* __restrict__ steps_out,
                    int64_t steps_stride, int32_t* __restrict__ chunks_run, double* __restrict__ prev_action_io,
                    uint8_t* __restrict__ has_prev_io, const int32_t* __restrict__ idx, int act_dense,
-                   const int32_t* __restrict__ budget, int chunk_j, ChunkStrides cs) {
+                   const int32_t* __restrict__ budget, int chunk_j, ChunkStrides cs, int stage) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   stage_maze(lds, maze, rows * cols);
   const int ob = (blockIdx.x * blockDim.x + threadIdx.x) / G, g = threadIdx.x & (G - 1);
@@ -359,6 +359,24 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
 #pragma unroll
   for (int k = 0; k < 6; ++k) s[k] = state_io[(size_t)b * 6 + k];
   const double* act = actions + (size_t)(act_dense ? ob : b) * act_stride;
+  // stage != 0: a lane copies eight steps of ITS actions (one 128-byte line) into its LDS slots in one burst of loads and reads
+  // them back step by step -- no barrier (a lane only reads what it wrote); slot q of lane t at (q * blockDim + t) * 16: no
+  // bank conflicts.  Without it every step's 16-byte load touches the line again, up to 4 us after it was fetched.
+  double2* abuf = stage ? reinterpret_cast<double2*>(lds + (((size_t)rows * cols + 15) & ~(size_t)15)) + threadIdx.x : nullptr;
+  const int bd = blockDim.x;
+  auto action_at = [&](int i, double& a0, double& a1) {
+    if (abuf) {
+      if ((i & 7) == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (i + q < A) abuf[q * bd] = *reinterpret_cast<const double2*>(act + 2 * (i + q));
+      }
+      const double2 v = abuf[(i & 7) * bd];
+      a0 = v.x; a1 = v.y;
+    } else {
+      a0 = act[2 * i]; a1 = act[2 * i + 1];
+    }
+  };
   // G = 2: lane 0 owns the state rows, lane 1 the action rows
   // row i, component k of a candidate's block: base + i * row + k * comp (packed rows: {6, 1}; step-major SoA: {6 B, B} --
   // then the 64 lanes of a wave store 512 contiguous bytes)
@@ -380,7 +398,8 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
     // profiles/r04_rollout_*pmc_traffic.json.)
     bool alive = true;
     for (i = 0; i < A; ++i) {
-      double c0r = act[2 * i], c1r = act[2 * i + 1];
+      double c0r, c1r;
+      action_at(i, c0r, c1r);
       if (alive) {
         car_euler_step(s, c0r, c1r);
         steps = i + 1;
@@ -419,7 +438,8 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
     }
   } else {
     for (; i < A; ++i) {
-      const double a0r = act[2 * i], a1r = act[2 * i + 1];
+      double a0r, a1r;
+      action_at(i, a0r, a1r);
       car_euler_step(s, a0r, a1r);
       steps = i + 1;
       if (so) {
@@ -484,6 +504,12 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
                            uint8_t* has_prev_io, const int32_t* idx, int act_dense, hipStream_t s, const int32_t* budget,
                            int chunk_j, ChunkStrides cs) {
   size_t lds = ((size_t)rows * cols + 15) & ~(size_t)15;
+  // lane-private LDS staging of the action rows (DITREE_ROLLOUT_STAGE=0 turns it off): 65 536 x 16, candidate-minor rows:
+  // 114 -> 20.4 MB fetched per launch (total 188 -> 94.3 MB = 1.005 x the algorithmic 93.8 MB), same 70 us -- the FP64 chain
+  // bounds the kernel, not its bytes (profiles/r04_rollout_stage_* vs r04_rollout_nostage_*)
+  static int stage_env = -1;
+  if (stage_env < 0) { const char* e = getenv("DITREE_ROLLOUT_STAGE"); stage_env = e ? atoi(e) : 1; }
+  const int stage = stage_env && (act_stride % 2 == 0) && (cs.actions_in % 2 == 0) && ((uintptr_t)actions % 16 == 0) ? 1 : 0;
   // work-group size: one wave per group spreads a small batch over many CUs (1 024 candidates: 16 CUs instead of 4); once
   // every SIMD has a wave anyway, four waves per group share one staged maze
   const int blk = B >= 16384 ? 256 : 64;
@@ -498,9 +524,9 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
   // (dead lanes keep storing zero rows step by step: profiles/r04_rollout_layout_probe.json) -- chosen by the layout
   const int pipe_env = ((states_out && states_stride.cand == 1) || (!states_out && actions_out && actout_stride.cand == 1)) ? 1 : 0;
 #define CAR_ROLLOUT_LAUNCH(GG, PP)                                                                                          \
-  hipLaunchKernelGGL((car_rollout_kernel<GG, PP>), dim3((GG * B + blk - 1) / blk), dim3(blk), lds, s, maze, rows, cols, state_io, \
+  hipLaunchKernelGGL((car_rollout_kernel<GG, PP>), dim3((GG * B + blk - 1) / blk), dim3(blk), lds + (stage ? (size_t)blk * 128 : 0), s, maze, rows, cols, state_io, \
                      actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out, actout_stride,      \
-                     steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense, budget, chunk_j, cs)
+                     steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense, budget, chunk_j, cs, stage)
   if (G == 2) { if (pipe_env) CAR_ROLLOUT_LAUNCH(2, true); else CAR_ROLLOUT_LAUNCH(2, false); }
   else { if (pipe_env) CAR_ROLLOUT_LAUNCH(1, true); else CAR_ROLLOUT_LAUNCH(1, false); }
 #undef CAR_ROLLOUT_LAUNCH
