@@ -27,6 +27,18 @@ __device__ __forceinline__ bool ant_ball_collides(double x, double y, const unsi
   coll |= (x - r < x_min) && (col - 1 < 0 || mz[row * W + col - 1] == 1);          // left   :181-185
   coll |= (y + r > y_max) && (row - 1 < 0 || mz[(row - 1) * W + col] == 1);        // top    :188-192
   coll |= (y - r < y_min) && (row + 1 >= H || mz[(row + 1) * W + col] == 1);       // bottom :195-199
+  if (r < 0.9 * half) {
+    // :202-216 tests four corners; only the distance to the NEAREST one can be below r when r is well under half a cell (the ball
+    // sits in its cell up to rounding, every other corner is half a cell away along at least one axis): one sqrt, same value
+    const bool right = x >= cell_x, up = y >= cell_y;
+    const int ci = up ? row - 1 : row + 1, cj = right ? col + 1 : col - 1;
+    const double dx = (right ? x_max : x_min) - x, dy = (up ? y_max : y_min) - y;
+    const double dist = sqrt(dx * dx + dy * dy);                                    // :210
+    const bool inside = ci >= 0 && ci < H && cj >= 0 && cj < W;                      // :213
+    const int i2 = min(max(ci, 0), H - 1), j2 = min(max(cj, 0), W - 1);
+    coll |= (dist < r) && inside && (mz[i2 * W + j2] == 1);
+    return coll;
+  }
   const int ci[4] = {row - 1, row - 1, row + 1, row + 1};                           // :202-207
   const int cj[4] = {col + 1, col - 1, col + 1, col - 1};
   const double kx[4] = {x_max, x_min, x_max, x_min};
@@ -97,7 +109,8 @@ __device__ __forceinline__ void ant_model_step(double* s, const double* a_raw, c
       ty = ty - cph[l] * (m.k_lift * lift);
     }
     const double yaw = atan2(2.0 * (qw * qz + qx * qy), 1.0 - 2.0 * (qy * qy + qz * qz));
-    const double cy = cos(yaw), sy = sin(yaw);
+    double cy, sy;
+    sincos(yaw, &sy, &cy);
     const double axw = m.k_push * (cy * fxb - sy * fyb) - m.c_lin * vx;
     const double ayw = m.k_push * (sy * fxb + cy * fyb) - m.c_lin * vy;
     vx = vx + h * axw;

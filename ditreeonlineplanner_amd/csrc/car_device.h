@@ -23,26 +23,27 @@ __device__ __forceinline__ bool ball_collides(double x, double y, const unsigned
   coll |= (x - r < x_min) && (mz[row * W + cl] == 1);                            // left   :294-298
   coll |= (y + r > y_max) && (mz[rt * W + col] == 1);                            // top    :300-304
   coll |= (y - r < y_min) && (mz[rb * W + col] == 1);                            // bottom :306-310
-  // corners :315-327; invalid neighbour => collision; column clipped with map_length (sic, :326)
-  const int ci[4] = {row - 1, row - 1, row + 1, row + 1};
-  const int cj[4] = {col + 1, col - 1, col + 1, col - 1};
-  const double kx[4] = {x_max, x_min, x_max, x_min};
-  const double ky[4] = {y_max, y_max, y_min, y_min};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    bool invalid = ci[k] < 0 || ci[k] >= H || cj[k] < 0 || cj[k] >= W;
-    int i2 = min(max(ci[k], 0), H - 1);
-    int j2 = min(min(max(cj[k], 0), H - 1), W - 1);
-    double dist = hypot(kx[k] - x, ky[k] - y);
-    coll |= invalid || ((dist < r) && (mz[i2 * W + j2] == 1));
-  }
+  // corners :315-327; invalid neighbour => collision; column clipped with map_length (sic, :326).
+  // The reference tests all four corners: `invalid or (hypot(corner - p) < r and occupied)`.  Any invalid corner <=> the cell is on the
+  // map's border.  Of the four distances only the one to the NEAREST corner can be below r: the ball sits in its cell (up to
+  // rounding), every other corner is half a cell (0.5 >> r = 0.1) away along at least one axis and hypot >= max(|dx|, |dy|).
+  // One hypot instead of four, same value.
+  coll |= row == 0 || row == H - 1 || col == 0 || col == W - 1;
+  const bool right = x >= cell_x, up = y >= cell_y;
+  const int ci = up ? row - 1 : row + 1, cj = right ? col + 1 : col - 1;
+  const int i2 = min(max(ci, 0), H - 1);
+  const int j2 = min(min(max(cj, 0), H - 1), W - 1);
+  const double dist = hypot((right ? x_max : x_min) - x, (up ? y_max : y_min) - y);
+  coll |= (dist < r) && (mz[i2 * W + j2] == 1);
   return coll;
 }
 
 // common/map_utils.py:103-115: two balls +-0.075 m along the heading.
 __device__ __forceinline__ bool car_collides(double x, double y, double psi, const unsigned char* mz, int H, int W) {
   const double off = 0.15 * 0.5;
-  double ox = off * cos(psi), oy = off * sin(psi);
+  double sps, cps;
+  sincos(psi, &sps, &cps);       // one range reduction for the pair; ocml's sin / cos evaluate the same kernels (identical values)
+  double ox = off * cps, oy = off * sps;
   bool f = ball_collides(x + ox, y + oy, mz, H, W);
   bool b = ball_collides(x - ox, y - oy, mz, H, W);
   return f || b;
@@ -58,7 +59,9 @@ __device__ __forceinline__ void car_euler_step(double* s, double a0r, double a1r
   const double psi = s[2], v = s[3], D = s[4], dl = s[5];
   double Fxd = (Cm1 - Cm2 * v) * D - Cr2 * (v * v) - Cr0 * tanh(5.0 * v);     // :380
   double ang = psi + C1 * dl;
-  double d0 = v * cos(ang), d1 = v * sin(ang), d2 = v * C2 * dl, d3 = (Fxd / m) * cos(C1 * dl);
+  double sang, cang;
+  sincos(ang, &sang, &cang);
+  double d0 = v * cang, d1 = v * sang, d2 = v * C2 * dl, d3 = (Fxd / m) * cos(C1 * dl);
   s[0] = s[0] + dt * d0;
   s[1] = s[1] + dt * d1;
   s[2] = s[2] + dt * d2;

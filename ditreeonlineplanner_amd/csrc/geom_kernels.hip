@@ -117,7 +117,8 @@ local_map_kernel(const unsigned char* __restrict__ maze, int rows, int cols, con
   // RRT.py:158-166 passes curr_state[0], curr_state[1], curr_state[2] for every env (for the ant, element 2 is the torso
   // height, not a heading -- the reference's own behaviour, kept)
   const double x = state[(size_t)b * state_stride + 0], y = state[(size_t)b * state_stride + 1], th = state[(size_t)b * state_stride + 2];
-  const double c = cos(th), sn = sin(th);
+  double c, sn;
+  sincos(th, &sn, &c);          // one range reduction; ocml's sin / cos evaluate the same kernels (identical values)
   // base_planner.py:88-89,100-101,113-114: centre = (W/2, H/2) * maze_size_scaling (car: 1, ant: s_global = 4); RRT.py:166
   const double cx = (double)cols / 2.0 * s_global, cy = (double)rows / 2.0 * s_global;
   for (int cell = threadIdx.x; cell < n * n; cell += blockDim.x) {
@@ -421,7 +422,9 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
         int mine = 0;
         if (alive) {
           const double off = 0.15 * 0.5, sgn = g ? -1.0 : 1.0;                   // common/map_utils.py:103-115: lane g, ball g
-          const double ox = off * cos(s[2]), oy = off * sin(s[2]);
+          double sps, cps;
+          sincos(s[2], &sps, &cps);
+          const double ox = off * cps, oy = off * sps;
           mine = ball_collides(s[0] + sgn * ox, s[1] + sgn * oy, lds, rows, cols) ? 1 : 0;
         }
         coll = (mine | __shfl_xor(mine, 1)) != 0;
@@ -453,7 +456,9 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
       bool coll;                                                                   // base_planner.py:306
       if constexpr (G == 2) {
         const double off = 0.15 * 0.5, sgn = g ? -1.0 : 1.0;                       // common/map_utils.py:103-115: lane g, ball g
-        const double ox = off * cos(s[2]), oy = off * sin(s[2]);
+        double sps, cps;
+        sincos(s[2], &sps, &cps);
+        const double ox = off * cps, oy = off * sps;
         const int mine = ball_collides(s[0] + sgn * ox, s[1] + sgn * oy, lds, rows, cols) ? 1 : 0;
         coll = (mine | __shfl_xor(mine, 1)) != 0;
       } else {
@@ -575,7 +580,8 @@ __device__ __forceinline__ void lidar_ray(double x0, double y0, double yaw, int 
   const double mw = (double)rows, mh = (double)cols;
   const double angle = -180.0 + 2.0 * (double)ray;                 // np.arange(-180, 182, 2)
   const double ang = (yaw + angle) * (M_PI / 180.0);               // np.deg2rad(yaw + angle) (:53-54)
-  const double rx = cos(ang), ry = sin(ang);
+  double rx, ry;
+  sincos(ang, &ry, &rx);
   // borders Left, Right, Bottom, Top (:57-62): origin b0, direction d
   const double bx[4] = {0.0, mw, 0.0, 0.0}, by[4] = {0.0, 0.0, 0.0, mh};
   const double dxs[4] = {0.0, 0.0, mw, mw}, dys[4] = {mh, mh, 0.0, 0.0};
@@ -924,7 +930,8 @@ void launch_gather_rows_f32(const float* src, int64_t src_stride, const int32_t*
 __device__ __forceinline__ bool obstacle_ahead_dev(double x, double y, double psi, const unsigned char* mz, int H, int W,
                                                    const AheadArg& ts) {
   const double row = ((double)H / 2.0 - y) / 1.0, col = (x + (double)W / 2.0) / 1.0;     // car_env.py:196-201
-  const double c = cos(-psi), sn = sin(-psi);
+  double c, sn;
+  sincos(-psi, &sn, &c);
   bool any = false;
 #pragma unroll 1
   for (int i = 0; i < 30; ++i) {

@@ -52,8 +52,10 @@ __device__ __forceinline__ void am_noise(const AntMppiArgs& a, long long k, int 
     const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);
     const double r = sqrt(-2.0 * log(u1));
     const double ang = 6.283185307179586 * u2;
-    e[2 * p] = a.sigma[2 * p] * (r * cos(ang));
-    e[2 * p + 1] = a.sigma[2 * p + 1] * (r * sin(ang));
+    double sa, ca;
+    sincos(ang, &sa, &ca);
+    e[2 * p] = a.sigma[2 * p] * (r * ca);
+    e[2 * p + 1] = a.sigma[2 * p + 1] * (r * sa);
   }
 }
 

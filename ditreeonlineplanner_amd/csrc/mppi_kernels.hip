@@ -48,8 +48,10 @@ __device__ __forceinline__ void mppi_noise(unsigned long long seed, unsigned lon
   const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);             // [0, 1)
   const double r = sqrt(-2.0 * log(u1));
   const double a = 6.283185307179586 * u2;
-  e0 = s0 * (r * cos(a));
-  e1 = s1 * (r * sin(a));
+  double sa, ca;
+  sincos(a, &sa, &ca);
+  e0 = s0 * (r * ca);
+  e1 = s1 * (r * sa);
 }
 
 // order-preserving map double -> unsigned 64-bit (and back): negative values flip all bits, the others the sign bit
@@ -174,7 +176,9 @@ mppi_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, 
     if constexpr (G >= 2) {
       const double off = 0.15 * 0.5;
       const double sgn = (g & 1) ? -1.0 : 1.0;
-      const double ox = off * cos(s[2]), oy = off * sin(s[2]);
+      double sps, cps;
+      sincos(s[2], &sps, &cps);
+      const double ox = off * cps, oy = off * sps;
       coll = quad_or<G>(ball_collides(s[0] + sgn * ox, s[1] + sgn * oy, s_maze, rows, cols));
     } else {
       coll = car_collides(s[0], s[1], s[2], s_maze, rows, cols);
