@@ -363,32 +363,35 @@ struct DenoiserState {
   void emit_block(std::vector<std::function<void(int, int, hipStream_t)>>& ops, const ConvGemmParams& p, const Act& out, int L) {
     const int Cout = p.N, mode = p.mode, uf = ufmt;
     const int gch = Cout / 8;
-    // ... and whole 16-row blocks inside a sample (the ant config runs L = 8 and 4: unfused)
-    const bool fused = mode < MODE_GN_MISH || ((Cout & 255) == 0 && (gch == 64 || gch == 128 || gch == 256) && (L & 15) == 0);
-    if (!fused) {
-      ConvGemmParams q = p;
-      q.mode = MODE_BIAS;
-      const float* film_p = p.film;
-      const int film_ld_ = p.film_ld, film_off_ = p.film_off, ldres = p.ldres, res_Lp = p.res_Lp, res_off = p.res_off;
-      const void* resp = p.Res;
-      const float *ga = p.gamma, *be = p.beta;
-      void* xo = (void*)out.p;
-      const int ld = out.ld, oLp = out.Lp(), ocoff = out.coff;
-      const long long xpl = out.plane, rpl = p.res_plane;
-      int* gsat = p.sat;                 // the normalisation pass reports under the layer's name as well
-      ops.push_back([=, this](int, int Bp, hipStream_t s) mutable {
-        q.M = Bp * L;
-        run_gemm(q, uf, s);
-        note_other();
-        launch_gn1d(xo, ld, oLp, 1, ocoff, L, Cout, ga, be, 1e-5f, mode, film_p, film_ld_, film_off_, resp, ldres, res_Lp,
-                    res_off, Bp, uf, xpl, rpl, s, gsat);
-      });
-      return;
-    }
-    ConvGemmParams q = p;
-    ops.push_back([this, q, L, uf](int, int Bp, hipStream_t s) mutable {
+    // ... and a lane's four accumulator rows inside one sample: 16 | L, or L = 8 / 4 on the 16-bit tiles (the ant config's lower
+    // levels; DITREE_GN_SHORT_UNFUSED=1 keeps the round-3 two-launch form for A/B runs)
+    static const bool short_unfused = [] { const char* e = getenv("DITREE_GN_SHORT_UNFUSED"); return e && atoi(e) != 0; }();
+    const bool short_fusable = (L == 8 || L == 4) && fmt_st(uf) != ST_F32 && !short_unfused;
+    const bool fused = mode < MODE_GN_MISH ||
+                       ((Cout & 255) == 0 && (gch == 64 || gch == 128 || gch == 256) && ((L & 15) == 0 || short_fusable));
+    // short levels fuse on the gemm16 tile only: whole 256-row tiles (always so for the split formats, batch by batch otherwise)
+    const bool fused_needs_tiles = fused && mode >= MODE_GN_MISH && (L & 15) != 0;
+    ConvGemmParams qf = p, q = p;
+    q.mode = MODE_BIAS;
+    const float* film_p = p.film;
+    const int film_ld_ = p.film_ld, film_off_ = p.film_off, ldres = p.ldres, res_Lp = p.res_Lp, res_off = p.res_off;
+    const void* resp = p.Res;
+    const float *ga = p.gamma, *be = p.beta;
+    void* xo = (void*)out.p;
+    const int ld = out.ld, oLp = out.Lp(), ocoff = out.coff;
+    const long long xpl = out.plane, rpl = p.res_plane;
+    int* gsat = p.sat;                 // the normalisation pass reports under the layer's name as well
+    ops.push_back([=, this](int, int Bp, hipStream_t s) mutable {
+      if (fused && (!fused_needs_tiles || ((Bp * L) & 255) == 0)) {
+        qf.M = Bp * L;
+        run_gemm(qf, uf, s);
+        return;
+      }
       q.M = Bp * L;
       run_gemm(q, uf, s);
+      note_other();
+      launch_gn1d(xo, ld, oLp, 1, ocoff, L, Cout, ga, be, 1e-5f, mode, film_p, film_ld_, film_off_, resp, ldres, res_Lp,
+                  res_off, Bp, uf, xpl, rpl, s, gsat);
     });
   }
   // Conv1d(k = 1) residual projection.
@@ -492,9 +495,11 @@ void DenoiserState::build(int prec_, int Bmax_) {
   const int C0 = dims[0], C1 = dims[1], C2 = dims[2];
   const int L0 = P, L1 = P / 2, L2 = P / 4;
   if (P % 16 != 0 || P < 16 || P > 256 || (256 % P) != 0) throw std::runtime_error("pred_horizon must be 16, 32, 64, 128 or 256");
-  // rows of a batch are padded to whole work units: 16 samples, or -- the split formats exist on the 256-row halo / gemm16
-  // tiles only -- as many as fill a tile at the shortest level (P / 4 rows per sample: 64 samples at P = 16)
-  bgran = fmt_split(ufmt) ? std::max(16, 1024 / P) : 16;
+  // rows of a batch are padded to whole work units: 16 samples (f32), or -- the 16-bit formats run every level on the 256-row
+  // halo / gemm16 tiles (the split formats exist there only; the fused GroupNorm epilogue of the short levels needs whole
+  // tiles, and a sample's result must not depend on the batch it is part of) -- as many as fill a tile at the shortest level
+  // (P / 4 rows per sample: 64 samples at P = 16)
+  bgran = fmt_st(ufmt) != ST_F32 ? std::max(16, 1024 / P) : 16;
   Buser = Bmax_;
   Bmax = (Bmax_ + bgran - 1) / bgran * bgran;
   {

@@ -639,7 +639,7 @@ __global__ void __launch_bounds__(512, 2) conv_gemm_kernel(ConvGemmParams p) {
 //   A fragments are double-buffered per 32-deep sub-step, B fragments per half (64 fragment VGPRs in all);
 //   phase n reads what phase n+1 needs; the barrier sits before the last phase, which carries the LDS-DMA issue.
 // =================================================================================================
-template <int ET, bool SPLIT>
+template <int ET, bool SPLIT, bool SHORT = false>
 __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t (&acc)[4][8], char* smem, int tm, int tn,
                                                 int tid, int lane, int r4, int h4, int wm, int wn) {
   const int c_l = wn * 128 + 8 * r4;                          // lane's 8 consecutive channels in the tile
@@ -660,7 +660,13 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
         for (int j = 0; j < 4; ++j) { acc[mb][j] += b0[j]; acc[mb][4 + j] += b1[j]; }
     }
   }
-  // 16-row block mb of this wave: tile rows wm*64 + mb*16 .. +15 (inside one sample: 16 | L)
+  // 16-row block mb of this wave: tile rows wm*64 + mb*16 .. +15.  16 | L: the block lies inside one sample.  L = 8, 4 (the ant
+  // config's lower levels): the block holds 2 / 4 samples, but the four rows 4*h4 .. 4*h4 + 3 a LANE owns are consecutive
+  // positions of ONE sample (4 | L): sample blk_b + lane_b, first position blk_l + 4*h4 + lane_l with the per-lane offsets below
+  // (L | 16, so they do not depend on the block).  SHORT is its own instantiation (gemm16_kernel only): the 16 | L kernels
+  // have no registers to spare for it.
+  constexpr bool short_l = SHORT;
+  const int lane_b = short_l ? (4 * h4) / p.L : 0, lane_l = -lane_b * p.L;
   int blk_b[4], blk_l[4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
@@ -700,23 +706,17 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
   };
   // first row of 16-row block mb of this lane (row 4*h4 of the block), and the byte step to the next row
   auto out_ptr = [&](int mb, int esize) {
-    const long long orow = (long long)blk_b[mb] * p.out_Lp + (long long)(blk_l[mb] + 4 * h4) * p.out_stride + p.out_off;
+    const long long orow = (long long)(blk_b[mb] + lane_b) * p.out_Lp + (long long)(blk_l[mb] + 4 * h4 + lane_l) * p.out_stride + p.out_off;
     return (char*)p.Out + (orow * p.ldc + p.out_coff + n0) * esize;
   };
   if (p.mode < MODE_GN_MISH) {                                // plain store: 16-bit activations, or f32 (the FiLM table)
     const int esize = p.out_f32 ? 4 : 2;
     const long long ostep = (long long)p.out_stride * p.ldc * esize;
-    const bool short_l = (p.L & 15) != 0;                     // L = 8, 4: the rows of a 16-row block belong to several samples
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       char* ob = out_ptr(mb, esize);
 #pragma unroll
       for (int i = 0; i < 4; ++i, ob += ostep) {
-        if (short_l) {
-          const int m = tm * 256 + wm * 64 + mb * 16 + 4 * h4 + i;
-          const int b = m / p.L, l = m - b * p.L;
-          ob = (char*)p.Out + (((long long)b * p.out_Lp + (long long)l * p.out_stride + p.out_off) * p.ldc + p.out_coff + n0) * esize;
-        }
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = acc[mb][j][i];
@@ -733,16 +733,20 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
   // LDS (free after the K loop): GroupNorm sums, then the tile's per-channel and per-sample operands.  They are read
   // back block by block (16 transient registers instead of 48 resident ones: the accumulators fill the register file),
   // and an LDS read does not queue behind the row stores the way a global load does (see below).
-  float* s_sum = (float*)smem;                                // [16 slots][4 groups]
-  float* s_sq = s_sum + 64;
-  float* s_gb = s_sum + 128;                                  // gamma[256] | beta[256] of the tile's channels
-  float* s_film = s_gb + 512;                                 // FiLM rows of the tile's samples: [slot][scale 256 | bias 256]
   const bool has_film = p.mode == MODE_GN_MISH_FILM, has_res = p.mode == MODE_GN_MISH_RES;
-  const int spt = 256 / p.L;
-  if (tid < 128) s_sum[tid] = 0.0f;
+  const int spt = 256 / p.L;                                  // samples per tile: 4 .. 16, 32 (L = 8), 64 (L = 4)
+  const int ns = spt > 16 ? spt * 4 : 64;                     // statistics cells: [sample of the tile][4 groups]
+  float* s_sum = (float*)smem;
+  float* s_sq = s_sum + ns;
+  float* s_gb = s_sq + ns;                                    // gamma[256] | beta[256] of the tile's channels
+  float* s_film = s_gb + 512;                                 // FiLM rows of the tile's samples: [slot][scale 256 | bias 256]
+  // short samples: 64 FiLM rows would not fit the LDS -- a lane reads its sample's 2 x 8 values from the table itself, one
+  // block ahead (below)
+  const bool film_direct = has_film && short_l;
+  const int b_last = p.M / p.L - 1;
+  for (int i = tid; i < 2 * ns; i += 512) s_sum[i] = 0.0f;
   s_gb[tid] = tid < 256 ? p.gamma[tn * 256 + tid] : p.beta[tn * 256 + tid - 256];
-  if (has_film) {
-    const int b_last = p.M / p.L - 1;
+  if (has_film && !film_direct) {
     for (int idx = tid; idx < spt * 128; idx += 512) {
       const int sm = idx >> 7, c4 = idx & 127;
       const int b = min(tm * spt + sm, b_last);
@@ -753,10 +757,16 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
   // The memory counter (vmcnt) retires in issue order and counts stores too: a load that is waited for behind a row's
   // stores pays their round trip.  The residual rows therefore run in a ring of two tile rows (8 channels: hi [, lo]
   // per row), refilled as soon as a pair has been read -- before the stores of that pair are issued.
-  f32x4_t rh[2], rl[2];
+  f32x4_t rh[2], rl[2];                                       // (film_direct: the same registers hold the next block's FiLM values)
   const long long rstep = (long long)p.ldres * 2;
+  auto fetch_film = [&](int mb) {
+    const float* fr = p.film + (long long)min(blk_b[mb] + lane_b, b_last) * p.film_ld + p.film_off + n0;
+    rh[0] = *(const f32x4_t*)fr; rh[1] = *(const f32x4_t*)(fr + 4);
+    rl[0] = *(const f32x4_t*)(fr + p.N); rl[1] = *(const f32x4_t*)(fr + p.N + 4);
+  };
+  if (film_direct) fetch_film(0);
   auto fetch_res = [&](int r) {
-    const long long rrow = (long long)blk_b[r >> 2] * p.res_Lp + blk_l[r >> 2] + 4 * h4 + p.res_off;
+    const long long rrow = (long long)(blk_b[r >> 2] + lane_b) * p.res_Lp + blk_l[r >> 2] + 4 * h4 + lane_l + p.res_off;
     const char* rp = (const char*)p.Res + (rrow * p.ldres + n0) * 2 + (r & 3) * rstep;
     rh[r & 1] = *(const f32x4_t*)rp;
     if constexpr (SPLIT) rl[r & 1] = *(const f32x4_t*)(rp + p.res_plane);
@@ -768,13 +778,15 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
   const float inv_cnt = 1.0f / (float)(p.group_ch * p.L);
   int slot[4];
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) slot[mb] = (blk_b[mb] - tm * spt) * 4 + gi;
+  for (int mb = 0; mb < 4; ++mb) slot[mb] = (blk_b[mb] + lane_b - tm * spt) * 4 + gi;
   // group reduction of the per-lane partials of the four row blocks: the 16 lanes r4 of a row hold 8 channels each ->
   // DPP adds inside the row of 16 lanes (xor 1, 2, 4: 64 channels; the mirror of 16 when the group is 128+ wide), the
   // four rows h4 by two lane exchanges, and one lane per group adds into the sample's LDS cell.  For L <= 64 a cell is
   // fed by one wave (in program order) or by the two wn waves of a 256-wide group with one add each, so the sum does not
   // depend on the order the adds land in: results are reproducible bit for bit, whatever batch a sample is part of.
-  const bool adder = lane == 0 || (!wide && lane == 8);
+  // rows h4 of one sample: all four (16 | L), pairs (L = 8), each its own (L = 4)
+  const int hsame = short_l ? (p.L == 8 ? 2 : 1) : 4;
+  const bool adder = (r4 == 0 || (!wide && r4 == 8)) && (h4 & (hsame - 1)) == 0;
   auto block_sums = [&](float (&s)[4], float* cell) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) s[mb] = dpp_add<0xB1>(s[mb]);           // quad_perm [1,0,3,2]
@@ -786,10 +798,14 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) s[mb] = dpp_add<0x140>(s[mb]);        // row_mirror
     }
+    if (hsame >= 2) {
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) s[mb] += __shfl_xor(s[mb], 16);
+      for (int mb = 0; mb < 4; ++mb) s[mb] += __shfl_xor(s[mb], 16);
+    }
+    if (hsame == 4) {
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) s[mb] += __shfl_xor(s[mb], 32);
+      for (int mb = 0; mb < 4; ++mb) s[mb] += __shfl_xor(s[mb], 32);
+    }
     if (adder) {
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) atomicAdd(&cell[slot[mb]], s[mb]);
@@ -877,7 +893,11 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
         else { be[j] = bet0[j] - mean * ga[j]; be[4 + j] = bet1[j] - mean * ga[4 + j]; }
       }
     }
-    if (has_film) {
+    if (film_direct) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { fs[j] = rh[0][j]; fs[4 + j] = rh[1][j]; fb[j] = rl[0][j]; fb[4 + j] = rl[1][j]; }
+      if (mb + 1 < 4) fetch_film(mb + 1);                     // issued before this block's stores (vmcnt retires in order)
+    } else if (has_film) {
       const float* fr = s_film + (blk_b[mb] - tm * spt) * 512 + c_l;
       const f32x4_t f0 = *(const f32x4_t*)fr, f1 = *(const f32x4_t*)(fr + 4);
       const f32x4_t f2 = *(const f32x4_t*)(fr + 256), f3 = *(const f32x4_t*)(fr + 260);
@@ -1624,10 +1644,10 @@ __global__ void __launch_bounds__(256) conv2d_small_kernel(ConvGemmParams p) {
 // double-buffered), two K-steps in flight, one barrier per K-step with a plain vmcnt(0).
 //   Activation row of tile row m = (b, l):  b*in_Lp + l*in_stride + in_off + tap.  An 8-row staging piece covers whole
 //   samples or lies inside one (L = 4, or 8 | L), so its source offset is wave-uniform + 8 lane-dependent rows: two lane
-//   offsets (the XOR swizzle depends on the piece parity) + scalar offsets, as for the weights.  L = 8 and 4 (the ant
-//   config's lower levels) are served for plain stores only (GroupNorm etc. then run in gn1d_kernel).
+//   offsets (the XOR swizzle depends on the piece parity) + scalar offsets, as for the weights.  L = 8 and 4 are the ant
+//   config's lower levels.
 // =================================================================================================
-template <int ET, bool SPLIT>
+template <int ET, bool SPLIT, bool SHORT = false>
 __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BUF = 32768, W_BASE = 2 * BUF;
@@ -1869,13 +1889,13 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
   if (nk >= 2) step(Tt{}, Ff{}, nk - 2);
   step(Ff{}, Ff{}, nk - 1);
   __syncthreads();
-  gemm_epilogue16<ET, SPLIT>(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
+  gemm_epilogue16<ET, SPLIT, SHORT>(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
 }
 // fmt = storage type | split << 2 (denoise.h).  The 16-bit tiles (halo, gemm16, small Conv2d) exist for bf16 and f16;
 // the hi/lo split forms only on the halo / gemm16 pipeline; f32 runs everything on conv_gemm_kernel<1>.
 static bool gemm16_eligible(const ConvGemmParams& p, int fmt) {
-  // L = 8 and 4 (the ant config's lower levels): plain stores only -- a 16-row block of the epilogue spans 2 or 4 samples
-  const bool short_ok = (p.L == 8 || p.L == 4) && p.mode == MODE_BIAS;
+  // L = 8 and 4 (the ant config's lower levels): a 16-row block of the epilogue spans 2 or 4 samples (per-lane sample indices)
+  const bool short_ok = p.L == 8 || p.L == 4;
   return fmt_st(fmt) != ST_F32 && !p.c2d && (!p.out_f32 || p.mode == MODE_BIAS) && p.taps >= 1 && p.taps <= 3 && (p.M & 255) == 0 &&
          (p.N & 255) == 0 && (p.Cin & 63) == 0 && ((p.L & 15) == 0 || short_ok) && p.M > 0 &&
          (p.mode == MODE_BIAS || (256 % p.L) == 0);
@@ -1913,6 +1933,10 @@ static void ensure_lds_attrs() {
   hipFuncSetAttribute((const void*)gemm16_kernel<1, false>, at, 131072);
   hipFuncSetAttribute((const void*)gemm16_kernel<0, true>, at, 131072);
   hipFuncSetAttribute((const void*)gemm16_kernel<1, true>, at, 131072);
+  hipFuncSetAttribute((const void*)gemm16_kernel<0, false, true>, at, 131072);
+  hipFuncSetAttribute((const void*)gemm16_kernel<1, false, true>, at, 131072);
+  hipFuncSetAttribute((const void*)gemm16_kernel<0, true, true>, at, 131072);
+  hipFuncSetAttribute((const void*)gemm16_kernel<1, true, true>, at, 131072);
 }
 
 void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
@@ -1931,6 +1955,16 @@ void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
     }
     return;
   }
+  if (gemm16_eligible(p, fmt) && (p.L & 15) != 0) {          // L = 8, 4: per-lane sample indices in the epilogue
+    if (split) {
+      if (f16) DN_LAUNCH((gemm16_kernel<1, true, true>), grid, block, 131072, s, p);
+      else DN_LAUNCH((gemm16_kernel<0, true, true>), grid, block, 131072, s, p);
+    } else {
+      if (f16) DN_LAUNCH((gemm16_kernel<1, false, true>), grid, block, 131072, s, p);
+      else DN_LAUNCH((gemm16_kernel<0, false, true>), grid, block, 131072, s, p);
+    }
+    return;
+  }
   if (gemm16_eligible(p, fmt)) {
     if (split) {
       if (f16) DN_LAUNCH((gemm16_kernel<1, true>), grid, block, 131072, s, p);
@@ -1941,6 +1975,8 @@ void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
     }
     return;
   }
+  if (p.mode >= MODE_GN_MISH && (p.L & 15) != 0)
+    throw std::runtime_error("conv_gemm: a fused GroupNorm epilogue at L = 8 / 4 exists on the gemm16 tile only (whole 256-row tiles)");
   if (p.c2d && conv2d_small_eligible(fmt) && (p.N & 63) == 0 && (p.Cin & 63) == 0 && p.out_f32 && p.mode == MODE_BIAS) {
     const dim3 g2(((p.M + 63) >> 6) * (p.N >> 6), p.splitk > 1 ? p.splitk : 1);
     if (split) {
