@@ -167,17 +167,21 @@ __global__ void mppi_ant_min_kernel(const unsigned long long* __restrict__ minke
   result[3] = am_unkey(*minkey);
 }
 
+// Grid (slices, T): block (sl, t) reduces step t of slice sl's rollouts (block t = 0 also the three scalar sums and the weights).
+// One block per slice walked all T steps before: 1 024 waves on 1 024 SIMDs, each regenerating 64 Box-Muller pairs per rollout
+// with nothing to hide their latency (78 us at K = 65 536, T = 16).  Same sums in the same order.
 __global__ void __launch_bounds__(256)
 mppi_ant_partial_kernel(const double* __restrict__ costs, const double* __restrict__ noise, AntMppiArgs a, const double* __restrict__ result,
                         double* __restrict__ partial /*[slices][3 + 8T]*/, double* __restrict__ weights, const int32_t* __restrict__ flags) {
-  __shared__ double red[4][3 + AM_NU * AM_MAX_T];
+  __shared__ double red[4][3 + AM_NU];
+  const int t = blockIdx.y;
   const int per = (a.K + gridDim.x - 1) / gridDim.x;
   const int lo = blockIdx.x * per, hi = min(lo + per, a.K);
   const double beta = result[3];
   const int nacc = 3 + AM_NU * a.T;
   const int wv = threadIdx.x >> 6;
   const bool lane0 = (threadIdx.x & 63) == 0;
-  for (int j = threadIdx.x; j < 4 * (3 + AM_NU * AM_MAX_T); j += 256) (&red[0][0])[j] = 0.0;
+  if (threadIdx.x < 4 * (3 + AM_NU)) (&red[0][0])[threadIdx.x] = 0.0;
   __syncthreads();
   auto wave_sum = [](double v) {
 #pragma unroll
@@ -188,32 +192,41 @@ mppi_ant_partial_kernel(const double* __restrict__ costs, const double* __restri
     const int k = kb + (int)threadIdx.x;
     const bool valid = k < hi;
     const double w = valid ? exp(-(costs[k] - beta) / a.lambda) : 0.0;
-    if (valid && weights != nullptr) weights[k] = w;
-    const double sw = wave_sum(w), sw2 = wave_sum(w * w);
-    const double sc = wave_sum((valid && flags != nullptr && flags[k] == 2) ? 1.0 : 0.0);
-    if (lane0) { red[wv][0] += sw; red[wv][1] += sw2; red[wv][2] += sc; }
-    for (int t = 0; t < a.T; ++t) {
-      double e[AM_NU];
+    if (t == 0) {
+      if (valid && weights != nullptr) weights[k] = w;          // un-normalised; mppi_ant_weights_kernel divides by eta
+      const double sw = wave_sum(w), sw2 = wave_sum(w * w);
+      const double sc = wave_sum((valid && flags != nullptr && flags[k] == 2) ? 1.0 : 0.0);
+      if (lane0) { red[wv][0] += sw; red[wv][1] += sw2; red[wv][2] += sc; }
+    }
+    double e[AM_NU];
 #pragma unroll
-      for (int d = 0; d < AM_NU; ++d) e[d] = 0.0;
-      if (valid && a.k0 + k > 0) {
-        if (noise != nullptr) {
+    for (int d = 0; d < AM_NU; ++d) e[d] = 0.0;
+    if (valid && a.k0 + k > 0) {
+      if (noise != nullptr) {
 #pragma unroll
-          for (int d = 0; d < AM_NU; ++d) e[d] = noise[((size_t)k * a.T + t) * AM_NU + d];
-        } else {
-          am_noise(a, a.k0 + k, t, e);
-        }
+        for (int d = 0; d < AM_NU; ++d) e[d] = noise[((size_t)k * a.T + t) * AM_NU + d];
+      } else {
+        am_noise(a, a.k0 + k, t, e);
       }
+    }
 #pragma unroll
-      for (int d = 0; d < AM_NU; ++d) {
-        const double v = wave_sum(w * e[d]);
-        if (lane0) red[wv][3 + AM_NU * t + d] += v;
-      }
+    for (int d = 0; d < AM_NU; ++d) {
+      const double v = wave_sum(w * e[d]);
+      if (lane0) red[wv][3 + d] += v;
     }
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < nacc; j += 256)
-    partial[(size_t)blockIdx.x * nacc + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+  if (t == 0 && threadIdx.x < 3)
+    partial[(size_t)blockIdx.x * nacc + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < AM_NU) {
+    const int j = 3 + threadIdx.x;
+    partial[(size_t)blockIdx.x * nacc + 3 + AM_NU * t + threadIdx.x] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+  }
+}
+
+__global__ void __launch_bounds__(256) mppi_ant_weights_kernel(double* __restrict__ weights, const double* __restrict__ sums, int K) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < K) weights[k] = weights[k] / sums[0];
 }
 
 // result [64]: executed action 0..7 at [16..24), status [2], beta [3], eta [4], nearest path index [5], collided [6], effective
@@ -229,7 +242,13 @@ mppi_ant_finish_kernel(const unsigned char* __restrict__ maze, int rows, int col
     // 98 us for the 131 values of T = 16: profiles/r04_mppi_ant_bench_kernel_stats.csv)
     for (int j = threadIdx.x; j < nacc; j += 256) {
       double acc = 0.0;
-      for (int sl = 0; sl < slices; ++sl) acc += partial[(size_t)sl * nacc + j];
+      for (int s0 = 0; s0 < slices; s0 += 16) {                 // 16 loads in flight, then their adds in slice order
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = s0 + u < slices ? partial[(size_t)(s0 + u) * nacc + j] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+      }
       sums[j] = acc;
     }
     __threadfence_block();
@@ -238,9 +257,7 @@ mppi_ant_finish_kernel(const unsigned char* __restrict__ maze, int rows, int col
   if (do_apply) {
     const double eta = sums[0];
     for (int j = threadIdx.x; j < AM_NU * a.T; j += 256) U[j] = U[j] + sums[3 + j] / eta;
-    if (weights != nullptr)
-      for (int k = threadIdx.x; k < a.K; k += 256) weights[k] = weights[k] / eta;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {                                   // (the weights are normalised by mppi_ant_weights_kernel)
       result[4] = eta;
       result[6] = sums[2];
       result[7] = (eta * eta) / sums[1];
@@ -325,11 +342,13 @@ extern "C" int32_t ditree_mppi_step_ant(ditree_ctx* ctx, const ditree_mppi_ant_p
   }
   if (stages & DITREE_MPPI_MIN) hipLaunchKernelGGL(mppi_ant_min_kernel, dim3(1), dim3(1), 0, s, ctx->mppi_minkey, result);
   if (stages & DITREE_MPPI_SUMS)
-    hipLaunchKernelGGL(mppi_ant_partial_kernel, dim3(slices), dim3(256), 0, s, costs, noise, a, result, ctx->mppi_ant_partial, weights, flags);
+    hipLaunchKernelGGL(mppi_ant_partial_kernel, dim3(slices, a.T), dim3(256), 0, s, costs, noise, a, result, ctx->mppi_ant_partial, weights, flags);
   if (stages & (DITREE_MPPI_SUMS | DITREE_MPPI_APPLY | DITREE_MPPI_EXECUTE))
     hipLaunchKernelGGL(mppi_ant_finish_kernel, dim3(1), dim3(256), 0, s, ctx->maze, ctx->rows, ctx->cols, m, ctx->mppi_ant_partial, slices,
                        a, state_io, U_io, weights, sums, result, (stages & DITREE_MPPI_SUMS) ? 1 : 0,
                        (stages & DITREE_MPPI_APPLY) ? 1 : 0, (stages & DITREE_MPPI_EXECUTE) ? 1 : 0);
+  if ((stages & DITREE_MPPI_APPLY) && weights != nullptr)
+    hipLaunchKernelGGL(mppi_ant_weights_kernel, dim3((a.K + 255) / 256), dim3(256), 0, s, weights, sums, a.K);
   HIP_TRY(ctx, hipGetLastError());
   return DITREE_OK;
 }

@@ -212,22 +212,24 @@ __global__ void mppi_min_kernel(const unsigned long long* __restrict__ minkey, d
   result[3] = mppi_unkey(*minkey);                    // the rollout kernel's atomicMin, decoded
 }
 
-// slice s owns rollouts [s * per, (s + 1) * per).  A thread takes rollout lo + tid (+ 256, ...): per rollout and step the
-// products w eps are reduced over the wave by a fixed butterfly and lane 0 adds them to its wave's LDS row in loop order, the
-// four rows are added in a fixed tree: every sum has one order, results are reproducible.  (Per-thread accumulators indexed
-// by t would live in scratch: T is a run-time value.)
+// Grid (slices, T): slice s owns rollouts [s * per, (s + 1) * per), block (s, t) reduces step t of them (block t = 0 also the
+// three scalar sums and the weights).  A thread takes rollout lo + tid (+ 256, ...): the products w eps are reduced over the
+// wave by a fixed butterfly and lane 0 adds them to its wave's LDS row in loop order, the four rows are added in a fixed tree:
+// every sum has one order, results are reproducible.  (One block per slice walked all T steps before: one wave per SIMD with
+// nothing to hide the latency of the regenerated Box-Muller noise.)
 __global__ void __launch_bounds__(256)
 mppi_partial_kernel(const double* __restrict__ costs, const double* __restrict__ noise, MppiArgs a, const double* __restrict__ result,
                     double* __restrict__ partial /*[slices][3 + 2T]: eta, sum w^2, collided, sum w eps*/, double* __restrict__ weights,
                     const int32_t* __restrict__ flags) {
-  __shared__ double red[4][3 + 2 * MPPI_MAX_T];
+  __shared__ double red[4][5];
+  const int t = blockIdx.y;
   const int per = (a.K + gridDim.x - 1) / gridDim.x;
   const int lo = blockIdx.x * per, hi = min(lo + per, a.K);
   const double beta = result[3];
   const int nacc = 3 + 2 * a.T;
   const int wv = threadIdx.x >> 6;
   const bool lane0 = (threadIdx.x & 63) == 0;
-  for (int j = threadIdx.x; j < 4 * (3 + 2 * MPPI_MAX_T); j += 256) (&red[0][0])[j] = 0.0;
+  if (threadIdx.x < 20) (&red[0][0])[threadIdx.x] = 0.0;
   __syncthreads();
   auto wave_sum = [](double v) {
 #pragma unroll
@@ -238,23 +240,32 @@ mppi_partial_kernel(const double* __restrict__ costs, const double* __restrict__
     const int k = kb + (int)threadIdx.x;
     const bool valid = k < hi;
     const double w = valid ? exp(-(costs[k] - beta) / a.lambda) : 0.0;
-    if (valid && weights != nullptr) weights[k] = w;            // un-normalised; the finish kernel divides by eta
-    const double sw = wave_sum(w), sw2 = wave_sum(w * w);
-    const double sc = wave_sum((valid && flags != nullptr && flags[k] == 2) ? 1.0 : 0.0);      // collided rollouts (exact: integers)
-    if (lane0) { red[wv][0] += sw; red[wv][1] += sw2; red[wv][2] += sc; }
-    for (int t = 0; t < a.T; ++t) {
-      double e0 = 0.0, e1 = 0.0;
-      if (valid && a.k0 + k > 0) {
-        if (noise != nullptr) { e0 = noise[((size_t)k * a.T + t) * 2]; e1 = noise[((size_t)k * a.T + t) * 2 + 1]; }
-        else mppi_noise(a.seed, a.counter, a.k0 + k, t, a.s0, a.s1, e0, e1);
-      }
-      const double v0 = wave_sum(w * e0), v1 = wave_sum(w * e1);
-      if (lane0) { red[wv][3 + 2 * t] += v0; red[wv][4 + 2 * t] += v1; }
+    if (t == 0) {
+      if (valid && weights != nullptr) weights[k] = w;            // un-normalised; mppi_weights_kernel divides by eta
+      const double sw = wave_sum(w), sw2 = wave_sum(w * w);
+      const double sc = wave_sum((valid && flags != nullptr && flags[k] == 2) ? 1.0 : 0.0);      // collided rollouts (exact: integers)
+      if (lane0) { red[wv][0] += sw; red[wv][1] += sw2; red[wv][2] += sc; }
     }
+    double e0 = 0.0, e1 = 0.0;
+    if (valid && a.k0 + k > 0) {
+      if (noise != nullptr) { e0 = noise[((size_t)k * a.T + t) * 2]; e1 = noise[((size_t)k * a.T + t) * 2 + 1]; }
+      else mppi_noise(a.seed, a.counter, a.k0 + k, t, a.s0, a.s1, e0, e1);
+    }
+    const double v0 = wave_sum(w * e0), v1 = wave_sum(w * e1);
+    if (lane0) { red[wv][3] += v0; red[wv][4] += v1; }
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < nacc; j += 256)
-    partial[(size_t)blockIdx.x * nacc + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+  if (t == 0 && threadIdx.x < 3)
+    partial[(size_t)blockIdx.x * nacc + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x < 2) {
+    const int j = 3 + threadIdx.x;
+    partial[(size_t)blockIdx.x * nacc + 3 + 2 * t + threadIdx.x] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+  }
+}
+
+__global__ void __launch_bounds__(256) mppi_weights_kernel(double* __restrict__ weights, const double* __restrict__ sums, int K) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < K) weights[k] = weights[k] / sums[0];
 }
 
 // sums [3 + 2T] = {eta = sum w, sum w^2, collided rollouts, sum_k w_k eps[k, t, d]}: the quantities a sharded controller
@@ -266,23 +277,24 @@ mppi_finish_kernel(const unsigned char* __restrict__ maze, int rows, int cols, c
                    double* __restrict__ sums, double* __restrict__ result, int do_sums, int do_apply, int do_execute) {
   const int nacc = 3 + 2 * a.T;
   if (do_sums) {
-    // thread t takes slice t (<= 256 slices); per value a fixed butterfly + a fixed order over the four waves
-    __shared__ double wsum[4];
-    for (int j = 0; j < nacc; ++j) {
-      double v = (int)threadIdx.x < slices ? partial[(size_t)threadIdx.x * nacc + j] : 0.0;
+    // thread j adds value j of the slices in slice order (one fixed order: reproducible); 3 + 2 T values, <= 256 slices
+    for (int j = threadIdx.x; j < nacc; j += 256) {
+      double acc = 0.0;
+      for (int s0 = 0; s0 < slices; s0 += 16) {                 // 16 loads in flight, then their adds in slice order
+        double v[16];
 #pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-      if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
-      __syncthreads();
-      if (threadIdx.x == 0) sums[j] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-      __syncthreads();
+        for (int u = 0; u < 16; ++u) v[u] = s0 + u < slices ? partial[(size_t)(s0 + u) * nacc + j] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+      }
+      sums[j] = acc;
     }
+    __threadfence_block();
+    __syncthreads();
   }
   if (do_apply) {
     const double eta = sums[0];
     for (int j = threadIdx.x; j < 2 * a.T; j += 256) U[j] = U[j] + sums[3 + j] / eta;
-    if (weights != nullptr)
-      for (int k = threadIdx.x; k < a.K; k += 256) weights[k] = weights[k] / eta;
     if (threadIdx.x == 0) {
       result[4] = eta;
       result[6] = sums[2];
@@ -368,11 +380,13 @@ extern "C" int32_t ditree_mppi_step(ditree_ctx* ctx, const ditree_mppi_params* p
   }
   if (stages & DITREE_MPPI_MIN) hipLaunchKernelGGL(mppi_min_kernel, dim3(1), dim3(1), 0, s, ctx->mppi_minkey, result);
   if (stages & DITREE_MPPI_SUMS)
-    hipLaunchKernelGGL(mppi_partial_kernel, dim3(slices), dim3(256), 0, s, costs, noise, a, result, ctx->mppi_partial, weights, flags);
+    hipLaunchKernelGGL(mppi_partial_kernel, dim3(slices, a.T), dim3(256), 0, s, costs, noise, a, result, ctx->mppi_partial, weights, flags);
   if (stages & (DITREE_MPPI_SUMS | DITREE_MPPI_APPLY | DITREE_MPPI_EXECUTE))
     hipLaunchKernelGGL(mppi_finish_kernel, dim3(1), dim3(256), 0, s, ctx->maze, ctx->rows, ctx->cols, ctx->mppi_partial, slices,
                        a, state_io, U_io, weights, sums, result, (stages & DITREE_MPPI_SUMS) ? 1 : 0,
                        (stages & DITREE_MPPI_APPLY) ? 1 : 0, (stages & DITREE_MPPI_EXECUTE) ? 1 : 0);
+  if ((stages & DITREE_MPPI_APPLY) && weights != nullptr)
+    hipLaunchKernelGGL(mppi_weights_kernel, dim3((a.K + 255) / 256), dim3(256), 0, s, weights, sums, a.K);
   HIP_TRY(ctx, hipGetLastError());
   return DITREE_OK;
 }
