@@ -367,7 +367,7 @@ def run_rollout(args):
                "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
                             **recorded_traffic("rollout", kernel="car_rollout_kernel"), "kernel": "car_rollout_kernel", "avg_launch_ms": avg_ms,
                             "algorithmic_bytes_per_launch": alg,
-                            "note": "FP64 transcendental-bound in practice (3 sincos + tanh + 9 sqrt/hypot per step): see DESIGN.md"},
+                            "note": "bound by its sequential FP64 chain at one wave per SIMD (2 sincos + cos + tanh + 2 hypot + sqrt per step), not by HBM: the launch without row stores takes 80 % of this one (DESIGN.md section 5)"},
                "outcome": {"ok": int((st == 0).sum()), "goal": int((st == 1).sum()), "collided": int((st == 2).sum())}, **comm}
         print(json.dumps(res), flush=True)
     if dist is not None:

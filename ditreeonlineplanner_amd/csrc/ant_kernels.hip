@@ -76,8 +76,8 @@ void launch_ant_copy_actions(const double* act, int64_t act_stride, int act_dens
 // contiguous bytes; 29-double AoS rows would touch 64 sectors per store).
 //   hist_out (B, 3, 29) / hist_n: `prev_states = curr_states_seq` (RRT.py:190) -- the last min(3, A + 1) rows of [start, obs_1
 //   .. obs_A] land at the END of the candidate's three slots (only meaningful when the chunk ends with status OK).
-template <bool MODEL>
-__global__ void __launch_bounds__(256)
+template <bool MODEL, bool STAGE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))   // the action burst holds 64 registers
 ant_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, AntModelArg m, double* __restrict__ state_io,
                    const double* __restrict__ actions, int64_t act_stride, const double* __restrict__ tape, int64_t tape_stride,
                    int32_t* __restrict__ status_io, int B, int A, double gx, double gy, double goal_radius, double ball_radius,
@@ -121,12 +121,40 @@ ant_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, A
   double a[ANT_D], la[ANT_D];
 #pragma unroll
   for (int k = 0; k < ANT_D; ++k) la[k] = 0.0;
+  // STAGE: the action rows of four steps (16 x 16 bytes) come in one burst of loads into the lane's LDS slots (slot q of lane t at
+  // (q * blockDim + t) * 16) and are read back step by step; and every load issued so far has arrived before the loop starts.
+  // vmcnt retires in order and counts stores: a per-step action load -- or a late wait for the state loaded above -- made every
+  // step wait for the row stores of its predecessor (car_rollout_kernel, geom_kernels.hip, has the measurements).
+  double2* abuf = STAGE ? reinterpret_cast<double2*>(lds + (((size_t)rows * cols + 15) & ~(size_t)15)) + threadIdx.x : nullptr;
+  const int bd = blockDim.x;
+  __builtin_amdgcn_s_waitcnt(0x0F70);                                            // vmcnt(0)
   // Rows are stored in LOCKSTEP (every lane stores row i + 1 in the same instruction: its state while the edge runs, the zero
   // row of base_planner.py:282 afterwards), so candidate-minor storage writes whole 512-byte runs (see car_rollout_kernel).
   bool alive = true;
   for (int i = 0; i < A; ++i) {
+    if constexpr (STAGE) {
+      if ((i & 3) == 0) {
+        // sixteen named values, not an array: the scheduling barrier is opaque to the optimiser, an array on its two sides would
+        // stay in scratch memory
+#define ACT_LD(q) const double2 t##q = *reinterpret_cast<const double2*>(act + (size_t)min(i + (q >> 2), A - 1) * ANT_D + 2 * (q & 3))
+        ACT_LD(0); ACT_LD(1); ACT_LD(2); ACT_LD(3); ACT_LD(4); ACT_LD(5); ACT_LD(6); ACT_LD(7);
+        ACT_LD(8); ACT_LD(9); ACT_LD(10); ACT_LD(11); ACT_LD(12); ACT_LD(13); ACT_LD(14); ACT_LD(15);
+#undef ACT_LD
+        __builtin_amdgcn_sched_barrier(0);                        // all sixteen loads in flight before the first LDS write waits
+#define ACT_ST(q) abuf[q * bd] = t##q
+        ACT_ST(0); ACT_ST(1); ACT_ST(2); ACT_ST(3); ACT_ST(4); ACT_ST(5); ACT_ST(6); ACT_ST(7);
+        ACT_ST(8); ACT_ST(9); ACT_ST(10); ACT_ST(11); ACT_ST(12); ACT_ST(13); ACT_ST(14); ACT_ST(15);
+#undef ACT_ST
+      }
 #pragma unroll
-    for (int k = 0; k < ANT_D; ++k) a[k] = act[(size_t)i * ANT_D + k];
+      for (int k = 0; k < 4; ++k) {
+        const double2 v = abuf[((i & 3) * 4 + k) * bd];
+        a[2 * k] = v.x; a[2 * k + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < ANT_D; ++k) a[k] = act[(size_t)i * ANT_D + k];
+    }
     if (alive) {
       if constexpr (MODEL) {
         ant_model_step(s, a, m);
@@ -184,18 +212,29 @@ void launch_ant_rollout(const unsigned char* maze, int rows, int cols, const Ant
                         int32_t* chunks_run, double* prev_action_io, uint8_t* has_prev_io, double* hist_out, int32_t* hist_n,
                         const int32_t* idx, int act_dense, hipStream_t s, int chunk_from_counter, AntChunkStrides cs) {
   const size_t lds = ((size_t)rows * cols + 15) & ~(size_t)15;
-  // one wave per work-group while the batch is small (a round's 4096 candidates: 64 CUs instead of 16), four once every SIMD
-  // has a wave anyway
-  const int blk = B >= 32768 ? 256 : 64;
+  // one wave per work-group while the batch is small (a round's 4096 candidates: 64 CUs instead of 16), four once every SIMD has
+  // a wave anyway (65 536 x 16: 271.5 us against 279.2 in groups of 64).  Two-wave groups are the one size to avoid
+  // (car_rollout_kernel: +27 %); DITREE_ROLLOUT_BLK = 64 | 256 overrides.
+  static int blk_env = -1;
+  if (blk_env < 0) { const char* e = getenv("DITREE_ROLLOUT_BLK"); blk_env = e ? atoi(e) : 0; }
+  const int blk = (blk_env == 64 || blk_env == 256) ? blk_env : (B >= 32768 ? 256 : 64);
+  static bool attr_done = false;
+  if (!attr_done) {                                          // 256 threads x 256 B of staged actions + the maze exceed 64 KB
+    const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
+    (void)hipFuncSetAttribute((const void*)ant_rollout_kernel<true, true>, at, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)ant_rollout_kernel<false, true>, at, 96 * 1024);
+    attr_done = true;
+  }
   const dim3 grid((B + blk - 1) / blk);
-  if (model)
-    hipLaunchKernelGGL(ant_rollout_kernel<true>, grid, dim3(blk), lds, s, maze, rows, cols, *model, state_io, actions, act_stride, tape,
-                       tape_stride, status_io, B, A, gx, gy, goal_radius, ball_radius, s_global, states_out, sl, actions_out, al,
-                       steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, hist_out, hist_n, idx, act_dense,
-                       chunk_from_counter, cs);
-  else
-    hipLaunchKernelGGL(ant_rollout_kernel<false>, grid, dim3(blk), lds, s, maze, rows, cols, AntModelArg{}, state_io, actions,
-                       act_stride, tape, tape_stride, status_io, B, A, gx, gy, goal_radius, ball_radius, s_global, states_out, sl,
-                       actions_out, al, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, hist_out, hist_n, idx,
-                       act_dense, chunk_from_counter, cs);
+  static int stage_env = -1;
+  if (stage_env < 0) { const char* e = getenv("DITREE_ROLLOUT_STAGE"); stage_env = e ? atoi(e) : 1; }
+  const bool stage = stage_env && (act_stride % 2 == 0) && (cs.actions_in % 2 == 0) && ((uintptr_t)actions % 16 == 0);
+#define ANT_ROLLOUT_LAUNCH(MM, SS, MODEL_ARG)                                                                                     \
+  hipLaunchKernelGGL((ant_rollout_kernel<MM, SS>), grid, dim3(blk), lds + (SS ? (size_t)blk * 256 : 0), s, maze, rows, cols, MODEL_ARG, \
+                     state_io, actions, act_stride, tape, tape_stride, status_io, B, A, gx, gy, goal_radius, ball_radius, s_global,  \
+                     states_out, sl, actions_out, al, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, hist_out,    \
+                     hist_n, idx, act_dense, chunk_from_counter, cs)
+  if (model) { if (stage) ANT_ROLLOUT_LAUNCH(true, true, *model); else ANT_ROLLOUT_LAUNCH(true, false, *model); }
+  else { if (stage) ANT_ROLLOUT_LAUNCH(false, true, AntModelArg{}); else ANT_ROLLOUT_LAUNCH(false, false, AntModelArg{}); }
+#undef ANT_ROLLOUT_LAUNCH
 }

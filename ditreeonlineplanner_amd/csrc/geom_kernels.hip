@@ -331,15 +331,15 @@ void launch_path_after_obstacle(const float* path, int stride, int P, double cx,
 // G lanes per candidate (1 or 2).  G = 2: both lanes of a pair integrate the (identical) dynamics, lane g tests ball g and the
 // pair ORs by one lane exchange, lane 0 stores the state rows and lane 1 the action rows -- twice the waves for the same batch
 // (two per SIMD at 65 536 candidates), each with a shorter chain per step.  Same arithmetic, same results.
-template <int G, bool LOCKSTEP>
-__global__ void __launch_bounds__(256)
+template <int G, bool LOCKSTEP, bool STAGE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))   // the action burst holds 64 registers: no spills
 car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, double* __restrict__ state_io,
                    const double* __restrict__ actions, int64_t act_stride, int32_t* __restrict__ status_io, int B,
                    int A, double gx, double gy, double* __restrict__ states_out, ditree_strides sl,
                    double* __restrict__ actions_out, ditree_strides al, int32_t* __restrict__ steps_out,
                    int64_t steps_stride, int32_t* __restrict__ chunks_run, double* __restrict__ prev_action_io,
                    uint8_t* __restrict__ has_prev_io, const int32_t* __restrict__ idx, int act_dense,
-                   const int32_t* __restrict__ budget, int chunk_j, ChunkStrides cs, int stage) {
+                   const int32_t* __restrict__ budget, int chunk_j, ChunkStrides cs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   stage_maze(lds, maze, rows * cols);
   const int ob = (blockIdx.x * blockDim.x + threadIdx.x) / G, g = threadIdx.x & (G - 1);
@@ -360,19 +360,30 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
 #pragma unroll
   for (int k = 0; k < 6; ++k) s[k] = state_io[(size_t)b * 6 + k];
   const double* act = actions + (size_t)(act_dense ? ob : b) * act_stride;
-  // stage != 0: a lane copies eight steps of ITS actions (one 128-byte line) into its LDS slots in one burst of loads and reads
-  // them back step by step -- no barrier (a lane only reads what it wrote); slot q of lane t at (q * blockDim + t) * 16: no
-  // bank conflicts.  Without it every step's 16-byte load touches the line again, up to 4 us after it was fetched.
-  double2* abuf = stage ? reinterpret_cast<double2*>(lds + (((size_t)rows * cols + 15) & ~(size_t)15)) + threadIdx.x : nullptr;
+  // STAGE: a lane copies sixteen steps of ITS actions into its LDS slots in ONE burst of loads (issued back to back, one wait) and
+  // reads them back step by step -- no barrier (a lane only reads what it wrote); slot q of lane t at (q * blockDim + t) * 16: no
+  // bank conflicts.  Two things are wrong with a 16-byte global load per step: the same 128-byte line is touched eight times up to
+  // 4 us apart (re-fetched when the store stream has evicted it: 29 ... 114 MB per launch for 20 MB), and -- worse -- vmcnt retires
+  // in order and counts stores, so waiting for step i's load also waits for the row stores of step i - 1: 45 % of the wave
+  // cycles were s_waitcnt (profiles/r04_rollout_pmc_sq.json).  With the burst the step loop holds no global load at all.
+  double2* abuf = STAGE ? reinterpret_cast<double2*>(lds + (((size_t)rows * cols + 15) & ~(size_t)15)) + threadIdx.x : nullptr;
   const int bd = blockDim.x;
   auto action_at = [&](int i, double& a0, double& a1) {
-    if (abuf) {
-      if ((i & 7) == 0) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          if (i + q < A) abuf[q * bd] = *reinterpret_cast<const double2*>(act + 2 * (i + q));
+    if constexpr (STAGE) {
+      if ((i & 15) == 0) {
+        // sixteen named values, not an array: the scheduling barrier below is opaque to the optimiser, an array on its two sides
+        // would stay in scratch memory
+#define ACT_LD(q) const double2 t##q = *reinterpret_cast<const double2*>(act + 2 * min(i + q, A - 1))
+        ACT_LD(0); ACT_LD(1); ACT_LD(2); ACT_LD(3); ACT_LD(4); ACT_LD(5); ACT_LD(6); ACT_LD(7);
+        ACT_LD(8); ACT_LD(9); ACT_LD(10); ACT_LD(11); ACT_LD(12); ACT_LD(13); ACT_LD(14); ACT_LD(15);
+#undef ACT_LD
+        __builtin_amdgcn_sched_barrier(0);                        // all sixteen loads in flight before the first LDS write waits
+#define ACT_ST(q) abuf[q * bd] = t##q
+        ACT_ST(0); ACT_ST(1); ACT_ST(2); ACT_ST(3); ACT_ST(4); ACT_ST(5); ACT_ST(6); ACT_ST(7);
+        ACT_ST(8); ACT_ST(9); ACT_ST(10); ACT_ST(11); ACT_ST(12); ACT_ST(13); ACT_ST(14); ACT_ST(15);
+#undef ACT_ST
       }
-      const double2 v = abuf[(i & 7) * bd];
+      const double2 v = abuf[(i & 15) * bd];
       a0 = v.x; a1 = v.y;
     } else {
       a0 = act[2 * i]; a1 = act[2 * i + 1];
@@ -391,6 +402,10 @@ car_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, d
   int steps = 0;
   double la0 = 0.0, la1 = 0.0;
   int i = 0;
+  // Everything loaded so far (state, status, indices) has arrived BEFORE the step loop.  Left to the compiler, the wait for these
+  // loads sits at their first use inside the loop, as vmcnt(0) -- and vmcnt counts the row stores of the previous step too: every
+  // step then waited for its predecessor's stores to reach memory.
+  __builtin_amdgcn_s_waitcnt(0x0F70);                                            // vmcnt(0)
   if constexpr (LOCKSTEP) {
     // Candidate-minor rows (sl.cand == 1) are stored in LOCKSTEP: every lane of the wave stores row i + 1 in the same
     // instruction -- its state while its edge is running, the zero row (base_planner.py:282) once it has ended -- so every store
@@ -516,24 +531,43 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
   if (stage_env < 0) { const char* e = getenv("DITREE_ROLLOUT_STAGE"); stage_env = e ? atoi(e) : 1; }
   const int stage = stage_env && (act_stride % 2 == 0) && (cs.actions_in % 2 == 0) && ((uintptr_t)actions % 16 == 0) ? 1 : 0;
   // work-group size: one wave per group spreads a small batch over many CUs (1 024 candidates: 16 CUs instead of 4); once
-  // every SIMD has a wave anyway, four waves per group share one staged maze
-  const int blk = B >= 16384 ? 256 : 64;
+  // every SIMD has a wave anyway, four waves per group share one staged maze.  NOT two: 65 536 x 16 steps take 64.0 us in groups
+  // of 128 threads against 50.5 (256) and 51.2 (64) -- profiles/r04_rollout_blocksize_probe.json; two-wave groups do not spread
+  // evenly over the four SIMDs of a CU.  DITREE_ROLLOUT_BLK = 64 | 128 | 256 overrides.
+  static int blk_env = -1;
+  if (blk_env < 0) { const char* e = getenv("DITREE_ROLLOUT_BLK"); blk_env = e ? atoi(e) : 0; }
+  const int blk = (blk_env == 64 || blk_env == 128 || blk_env == 256) ? blk_env : (B >= 16384 ? 256 : 64);
+  static bool attr_done = false;
+  if (!attr_done) {                                          // 256 threads x 256 B of staged actions + the maze exceed 64 KB
+    const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
+    (void)hipFuncSetAttribute((const void*)car_rollout_kernel<1, true, true>, at, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)car_rollout_kernel<1, false, true>, at, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)car_rollout_kernel<2, true, true>, at, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)car_rollout_kernel<2, false, true>, at, 96 * 1024);
+    attr_done = true;
+  }
   // lanes per candidate, measured on MI355X (profiles/r03_rollout_lanes.json): 8 192 candidates x 8 steps 31.6 -> 26.2 us with
   // two lanes (the batch fills a quarter of the SIMDs: the second lane's wave is free), 65 536 x 16 steps 73.2 -> 80.0 us
   // (every SIMD already has a wave; the duplicated dynamics cost more than the shorter chain saves).  DITREE_ROLLOUT_LANES
-  // = 1 | 2 overrides.
+  // = 1 | 2 overrides.  (A wave-specialised form -- two waves per candidate set, one per half of the step's chain, two barriers
+  // per step -- gave the same results and the same 56 us: profiles/NOTES.md.)
   static int lanes_env = -1;
   if (lanes_env < 0) { const char* e = getenv("DITREE_ROLLOUT_LANES"); lanes_env = e ? atoi(e) : 0; }
-  const int G = lanes_env == 1 ? 1 : (lanes_env == 2 ? 2 : (B <= 32768 ? 2 : 1));
   // lockstep row stores pay with candidate-minor rows (whole 512-byte runs); with rows packed per candidate they cost 27 %
   // (dead lanes keep storing zero rows step by step: profiles/r04_rollout_layout_probe.json) -- chosen by the layout
-  const int pipe_env = ((states_out && states_stride.cand == 1) || (!states_out && actions_out && actout_stride.cand == 1)) ? 1 : 0;
-#define CAR_ROLLOUT_LAUNCH(GG, PP)                                                                                          \
-  hipLaunchKernelGGL((car_rollout_kernel<GG, PP>), dim3((GG * B + blk - 1) / blk), dim3(blk), lds + (stage ? (size_t)blk * 128 : 0), s, maze, rows, cols, state_io, \
-                     actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out, actout_stride,      \
-                     steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense, budget, chunk_j, cs, stage)
-  if (G == 2) { if (pipe_env) CAR_ROLLOUT_LAUNCH(2, true); else CAR_ROLLOUT_LAUNCH(2, false); }
-  else { if (pipe_env) CAR_ROLLOUT_LAUNCH(1, true); else CAR_ROLLOUT_LAUNCH(1, false); }
+  const bool lock = (states_out && states_stride.cand == 1) || (!states_out && actions_out && actout_stride.cand == 1);
+  const int G = lanes_env == 1 ? 1 : (lanes_env == 2 ? 2 : (B <= 32768 ? 2 : 1));
+#define CAR_ROLLOUT_LAUNCH(GG, PP, SS)                                                                                          \
+  hipLaunchKernelGGL((car_rollout_kernel<GG, PP, SS>), dim3((GG * B + blk - 1) / blk), dim3(blk), lds + (SS ? (size_t)blk * 256 : 0), s, maze, \
+                     rows, cols, state_io, actions, act_stride, status_io, B, A, gx, gy, states_out, states_stride, actions_out,  \
+                     actout_stride, steps_out, steps_stride, chunks_run, prev_action_io, has_prev_io, idx, act_dense, budget, chunk_j, cs)
+#define CAR_ROLLOUT_PICK(GG)                                                                        \
+  do {                                                                                              \
+    if (lock) { if (stage) CAR_ROLLOUT_LAUNCH(GG, true, true); else CAR_ROLLOUT_LAUNCH(GG, true, false); }   \
+    else { if (stage) CAR_ROLLOUT_LAUNCH(GG, false, true); else CAR_ROLLOUT_LAUNCH(GG, false, false); }      \
+  } while (0)
+  if (G == 2) CAR_ROLLOUT_PICK(2); else CAR_ROLLOUT_PICK(1);
+#undef CAR_ROLLOUT_PICK
 #undef CAR_ROLLOUT_LAUNCH
 }
 void launch_car_rollout(const unsigned char* maze, int rows, int cols, double* state_io, const double* actions,
