@@ -17,16 +17,20 @@ __device__ __forceinline__ bool ant_ball_collides(double x, double y, const unsi
   const double xc = (double)W / 2.0 * s, yc = (double)H / 2.0 * s;                 // :155-156
   const double fr = floor((yc - y) / s), fc = floor((x + xc) / s);                // :158-159
   // NaN / inf -> astype(int) gives INT64_MIN -> not (0 <= row < H) -> True (:171-172)
-  if (!(fr >= 0.0) || !(fr < (double)H) || !(fc >= 0.0) || !(fc < (double)W)) return true;
-  const int row = (int)fr, col = (int)fc;
+  const bool oob = !(fr >= 0.0) | !(fr < (double)H) | !(fc >= 0.0) | !(fc < (double)W);
+  const int row = oob ? 0 : (int)fr, col = oob ? 0 : (int)fc;      // (no early return: the lanes of a wave stay on one path)
   const double cell_x = ((double)col + 0.5) * s - xc, cell_y = yc - ((double)row + 0.5) * s;   // :161-162
   const double half = s / 2.0;
   const double x_min = cell_x - half, x_max = cell_x + half, y_min = cell_y - half, y_max = cell_y + half;
+  // side cells read up front with clipped indices (a side beyond the map counts as a wall by the index test alone) and the
+  // tests combined without short-circuit branches: the LDS reads are in flight together behind one wait
+  const unsigned char m_r = mz[row * W + min(col + 1, W - 1)], m_l = mz[row * W + max(col - 1, 0)],
+                      m_t = mz[max(row - 1, 0) * W + col], m_b = mz[min(row + 1, H - 1) * W + col];
   bool coll = false;
-  coll |= (x + r > x_max) && (col + 1 >= W || mz[row * W + col + 1] == 1);         // right  :175-178
-  coll |= (x - r < x_min) && (col - 1 < 0 || mz[row * W + col - 1] == 1);          // left   :181-185
-  coll |= (y + r > y_max) && (row - 1 < 0 || mz[(row - 1) * W + col] == 1);        // top    :188-192
-  coll |= (y - r < y_min) && (row + 1 >= H || mz[(row + 1) * W + col] == 1);       // bottom :195-199
+  coll |= (x + r > x_max) & ((col + 1 >= W) | (m_r == 1));                         // right  :175-178
+  coll |= (x - r < x_min) & ((col - 1 < 0) | (m_l == 1));                          // left   :181-185
+  coll |= (y + r > y_max) & ((row - 1 < 0) | (m_t == 1));                          // top    :188-192
+  coll |= (y - r < y_min) & ((row + 1 >= H) | (m_b == 1));                         // bottom :195-199
   if (r < 0.9 * half) {
     // :202-216 tests four corners; only the distance to the NEAREST one can be below r when r is well under half a cell (the ball
     // sits in its cell up to rounding, every other corner is half a cell away along at least one axis): one sqrt, same value
@@ -34,10 +38,10 @@ __device__ __forceinline__ bool ant_ball_collides(double x, double y, const unsi
     const int ci = up ? row - 1 : row + 1, cj = right ? col + 1 : col - 1;
     const double dx = (right ? x_max : x_min) - x, dy = (up ? y_max : y_min) - y;
     const double dist = sqrt(dx * dx + dy * dy);                                    // :210
-    const bool inside = ci >= 0 && ci < H && cj >= 0 && cj < W;                      // :213
+    const bool inside = (ci >= 0) & (ci < H) & (cj >= 0) & (cj < W);                 // :213
     const int i2 = min(max(ci, 0), H - 1), j2 = min(max(cj, 0), W - 1);
-    coll |= (dist < r) && inside && (mz[i2 * W + j2] == 1);
-    return coll;
+    coll |= (dist < r) & inside & (mz[i2 * W + j2] == 1);
+    return coll | oob;
   }
   const int ci[4] = {row - 1, row - 1, row + 1, row + 1};                           // :202-207
   const int cj[4] = {col + 1, col - 1, col + 1, col - 1};
@@ -51,7 +55,7 @@ __device__ __forceinline__ bool ant_ball_collides(double x, double y, const unsi
     const int i2 = min(max(ci[k], 0), H - 1), j2 = min(max(cj[k], 0), W - 1);
     coll |= (dist < r) && inside && (mz[i2 * W + j2] == 1);
   }
-  return coll;
+  return coll | oob;
 }
 
 // common/map_utils.py:126-136 is_colliding_ant(state, maze, ant_radius, map_scale): upside down when the body z axis points

@@ -12,30 +12,34 @@ __device__ __forceinline__ bool ball_collides(double x, double y, const unsigned
   const double xc = (double)W / 2.0 * s, yc = (double)H / 2.0 * s;
   double fr = floor((yc - y) / s), fc = floor((x + xc) / s);
   // numpy's astype(int) maps NaN/inf to INT64_MIN -> out of bounds -> collision (:255-259)
-  if (!(fr >= 0.0) || !(fr < (double)H) || !(fc >= 0.0) || !(fc < (double)W)) return true;
-  const int row = (int)fr, col = (int)fc;
-  bool coll = mz[row * W + col] == 1;                                            // :262
+  const bool oob = !(fr >= 0.0) | !(fr < (double)H) | !(fc >= 0.0) | !(fc < (double)W);
+  const int row = oob ? 0 : (int)fr, col = oob ? 0 : (int)fc;      // (no early return: the lanes of a wave stay on one path)
   const double cell_x = ((double)col + 0.5) * s - xc, cell_y = yc - ((double)row + 0.5) * s;
   const double half = s / 2.0;
   const double x_min = cell_x - half, x_max = cell_x + half, y_min = cell_y - half, y_max = cell_y + half;
   const int cr = min(col + 1, W - 1), cl = max(col - 1, 0), rt = max(row - 1, 0), rb = min(row + 1, H - 1);
-  coll |= (x + r > x_max) && (mz[row * W + cr] == 1);                            // right  :288-292
-  coll |= (x - r < x_min) && (mz[row * W + cl] == 1);                            // left   :294-298
-  coll |= (y + r > y_max) && (mz[rt * W + col] == 1);                            // top    :300-304
-  coll |= (y - r < y_min) && (mz[rb * W + col] == 1);                            // bottom :306-310
   // corners :315-327; invalid neighbour => collision; column clipped with map_length (sic, :326).
   // The reference tests all four corners: `invalid or (hypot(corner - p) < r and occupied)`.  Any invalid corner <=> the cell is on the
   // map's border.  Of the four distances only the one to the NEAREST corner can be below r: the ball sits in its cell (up to
   // rounding), every other corner is half a cell (0.5 >> r = 0.1) away along at least one axis and hypot >= max(|dx|, |dy|).
   // One hypot instead of four, same value.
-  coll |= row == 0 || row == H - 1 || col == 0 || col == W - 1;
   const bool right = x >= cell_x, up = y >= cell_y;
   const int ci = up ? row - 1 : row + 1, cj = right ? col + 1 : col - 1;
   const int i2 = min(max(ci, 0), H - 1);
   const int j2 = min(min(max(cj, 0), H - 1), W - 1);
+  // the six cells are read up front (every index is clipped into the map) and the tests are combined without short-circuit
+  // branches: six LDS reads in flight behind one wait instead of six dependent read-wait-branch rounds
+  const unsigned char m_c = mz[row * W + col], m_r = mz[row * W + cr], m_l = mz[row * W + cl], m_t = mz[rt * W + col],
+                      m_b = mz[rb * W + col], m_k = mz[i2 * W + j2];
   const double dist = hypot((right ? x_max : x_min) - x, (up ? y_max : y_min) - y);
-  coll |= (dist < r) && (mz[i2 * W + j2] == 1);
-  return coll;
+  bool coll = m_c == 1;                                                          // :262
+  coll |= (x + r > x_max) & (m_r == 1);                                          // right  :288-292
+  coll |= (x - r < x_min) & (m_l == 1);                                          // left   :294-298
+  coll |= (y + r > y_max) & (m_t == 1);                                          // top    :300-304
+  coll |= (y - r < y_min) & (m_b == 1);                                          // bottom :306-310
+  coll |= (row == 0) | (row == H - 1) | (col == 0) | (col == W - 1);
+  coll |= (dist < r) & (m_k == 1);
+  return coll | oob;
 }
 
 // common/map_utils.py:103-115: two balls +-0.075 m along the heading.
