@@ -5,6 +5,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "fp64_device.h"
+
 #define ANT_S 29
 #define ANT_D 8
 
@@ -102,7 +104,7 @@ __device__ __forceinline__ void ant_model_step(double* s, const double* a_raw, c
       hip = hip + h * hd;
       ank = ank + h * ad;
       s[7 + 2 * l] = hip; s[8 + 2 * l] = ank; s[21 + 2 * l] = hd; s[22 + 2 * l] = ad;
-      const double c = 0.5 * (1.0 + tanh(m.contact_gain * (ank - m.ank_rest)));
+      const double c = 0.5 * (1.0 + tanh_em(m.contact_gain * (ank - m.ank_rest)));
       const double push = -(m.leg_r * hd) * c;
       fxb = fxb + (-sph[l]) * push;
       fyb = fyb + cph[l] * push;

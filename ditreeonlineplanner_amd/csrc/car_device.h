@@ -5,6 +5,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "fp64_device.h"
+
 // ------------------------------------------------------------------------- collision
 // common/map_utils.py:221-329 for one ball (maze_size_scaling = 1, radius 0.1).
 __device__ __forceinline__ bool ball_collides(double x, double y, const unsigned char* mz, int H, int W) {
@@ -61,7 +63,7 @@ __device__ __forceinline__ void car_euler_step(double* s, double a0r, double a1r
   double a0 = a0r < -10.0 ? -10.0 : (a0r > 10.0 ? 10.0 : a0r);
   double a1 = a1r < -2.0 ? -2.0 : (a1r > 2.0 ? 2.0 : a1r);
   const double psi = s[2], v = s[3], D = s[4], dl = s[5];
-  double Fxd = (Cm1 - Cm2 * v) * D - Cr2 * (v * v) - Cr0 * tanh(5.0 * v);     // :380
+  double Fxd = (Cm1 - Cm2 * v) * D - Cr2 * (v * v) - Cr0 * tanh_em(5.0 * v);     // :380
   double ang = psi + C1 * dl;
   double sang, cang;
   sincos(ang, &sang, &cang);
