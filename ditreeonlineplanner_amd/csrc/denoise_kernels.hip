@@ -1233,7 +1233,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
 //     -- wait, barrier, read-ahead of the next step's A_hi / W_lo(0) --   P6 A_lo x W_hi(1) + the LDS-DMA issue.
 //   The small cross terms are accumulated first.
 // =================================================================================================
-template <int ET>
+template <int ET, bool SHORT = false>
 __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int A_BUF = 40960, W_BUF = 32768, W_BASE = 2 * A_BUF;
@@ -1489,7 +1489,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
 #ifdef HALO16_STAMP
   const unsigned long long xs2 = __builtin_amdgcn_s_memrealtime();
 #endif
-  gemm_epilogue16<ET, true>(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
+  gemm_epilogue16<ET, true, SHORT>(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
 #ifdef HALO16_STAMP
   __syncthreads();
   if (tid == 0) {
@@ -1901,8 +1901,13 @@ static bool gemm16_eligible(const ConvGemmParams& p, int fmt) {
          (p.mode == MODE_BIAS || (256 % p.L) == 0);
 }
 static bool halo_eligible(const ConvGemmParams& p, int fmt) {
+  // L = 8 (the ant network's middle level, split formats): a tile's 32 samples x 10 padded rows are exactly the 320 rows the
+  // five staging pieces hold; the fragment rows are per-lane offsets already (lrow0), the epilogue is the SHORT instantiation.
+  // L = 4 would need 384 staged rows (a sixth piece, 160 KB of LDS): it stays on gemm16_kernel.
+  static const bool l8_off = [] { const char* e = getenv("DITREE_HALO_L8"); return e && atoi(e) == 0; }();   // A/B switch
+  const bool l_ok = p.L >= 16 || (p.L == 8 && fmt_split(fmt) && !l8_off);
   return fmt_st(fmt) != ST_F32 && !p.c2d && p.taps == 3 && p.in_stride == 1 && p.in_Lp == p.L + 2 && (256 % p.L) == 0 &&
-         p.L >= 16 && (p.M & 255) == 0 && (p.N & 255) == 0 && (p.Cin & 63) == 0 && p.Cin >= 192;
+         l_ok && (p.M & 255) == 0 && (p.N & 255) == 0 && (p.Cin & 63) == 0 && p.Cin >= 192;
 }
 bool conv2d_small_eligible(int fmt) { return fmt_st(fmt) != ST_F32; }
 int conv_gemm_kind(const ConvGemmParams& p, int fmt) { return halo_eligible(p, fmt) ? 0 : (p.c2d ? 2 : 1); }
@@ -1929,6 +1934,8 @@ static void ensure_lds_attrs() {
   hipFuncSetAttribute((const void*)conv3_halo16_kernel<1, false>, at, 147456);
   hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<0>, at, 147456);
   hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<1>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<0, true>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<1, true>, at, 147456);
   hipFuncSetAttribute((const void*)gemm16_kernel<0, false>, at, 131072);
   hipFuncSetAttribute((const void*)gemm16_kernel<1, false>, at, 131072);
   hipFuncSetAttribute((const void*)gemm16_kernel<0, true>, at, 131072);
@@ -1947,7 +1954,10 @@ void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
   const dim3 grid(ntm * ntn), block(512);
   if (halo_eligible(p, fmt)) {
     if (split) {
-      if (f16) DN_LAUNCH(conv3_halo16x3_kernel<1>, grid, block, 147456, s, p);
+      if (p.L == 8) {
+        if (f16) DN_LAUNCH((conv3_halo16x3_kernel<1, true>), grid, block, 147456, s, p);
+        else DN_LAUNCH((conv3_halo16x3_kernel<0, true>), grid, block, 147456, s, p);
+      } else if (f16) DN_LAUNCH(conv3_halo16x3_kernel<1>, grid, block, 147456, s, p);
       else DN_LAUNCH(conv3_halo16x3_kernel<0>, grid, block, 147456, s, p);
     } else {
       if (f16) DN_LAUNCH((conv3_halo16_kernel<1, false>), grid, block, 147456, s, p);
