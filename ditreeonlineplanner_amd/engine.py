@@ -162,7 +162,8 @@ def allgather_round_fields(fields, per, rank, world, group=None):
             else:
                 dist.all_gather_into_tensor(flat, mine.clone(), group=group)
         return
-    # RCCL: seven small collectives per round (measured 0.4 ms of a 26 ms round on one MI355X).  With
+    # RCCL: one collective per field -- ONE per round in the default exchange (the packed records), seven with
+    # DITREE_GATHER_EDGES=1 (measured 0.4 ms of a 26 ms round on one MI355X).  With
     # DITREE_COALESCE=1 they are issued as one grouped launch through torch's coalescing manager
     # (no measurable gain on one GPU, so the plain, universally supported calls are the default).
     import os
