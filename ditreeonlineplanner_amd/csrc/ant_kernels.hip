@@ -218,17 +218,21 @@ void launch_ant_rollout(const unsigned char* maze, int rows, int cols, const Ant
   static int blk_env = -1;
   if (blk_env < 0) { const char* e = getenv("DITREE_ROLLOUT_BLK"); blk_env = e ? atoi(e) : 0; }
   const int blk = (blk_env == 64 || blk_env == 256) ? blk_env : (B >= 32768 ? 256 : 64);
-  static bool attr_done = false;
+  static bool attr_done_dev[64] = {};                        // the attribute is per kernel AND per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const bool attr_done = dev >= 0 && dev < 64 && attr_done_dev[dev];
   if (!attr_done) {                                          // 256 threads x 256 B of staged actions + the maze exceed 64 KB
     const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
-    (void)hipFuncSetAttribute((const void*)ant_rollout_kernel<true, true>, at, 96 * 1024);
-    (void)hipFuncSetAttribute((const void*)ant_rollout_kernel<false, true>, at, 96 * 1024);
-    attr_done = true;
+    (void)hipFuncSetAttribute((const void*)ant_rollout_kernel<true, true>, at, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ant_rollout_kernel<false, true>, at, 160 * 1024);
+    if (dev >= 0 && dev < 64) attr_done_dev[dev] = true;
   }
   const dim3 grid((B + blk - 1) / blk);
   static int stage_env = -1;
   if (stage_env < 0) { const char* e = getenv("DITREE_ROLLOUT_STAGE"); stage_env = e ? atoi(e) : 1; }
-  const bool stage = stage_env && (act_stride % 2 == 0) && (cs.actions_in % 2 == 0) && ((uintptr_t)actions % 16 == 0);
+  bool stage = stage_env && (act_stride % 2 == 0) && (cs.actions_in % 2 == 0) && ((uintptr_t)actions % 16 == 0);
+  if (lds + (size_t)blk * 256 > 160 * 1024) stage = false;    // a maze that leaves no room for the staged actions: per-step loads
 #define ANT_ROLLOUT_LAUNCH(MM, SS, MODEL_ARG)                                                                                     \
   hipLaunchKernelGGL((ant_rollout_kernel<MM, SS>), grid, dim3(blk), lds + (SS ? (size_t)blk * 256 : 0), s, maze, rows, cols, MODEL_ARG, \
                      state_io, actions, act_stride, tape, tape_stride, status_io, B, A, gx, gy, goal_radius, ball_radius, s_global,  \

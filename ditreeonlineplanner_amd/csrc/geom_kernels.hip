@@ -524,12 +524,12 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
                            uint8_t* has_prev_io, const int32_t* idx, int act_dense, hipStream_t s, const int32_t* budget,
                            int chunk_j, ChunkStrides cs) {
   size_t lds = ((size_t)rows * cols + 15) & ~(size_t)15;
-  // lane-private LDS staging of the action rows (DITREE_ROLLOUT_STAGE=0 turns it off): 65 536 x 16, candidate-minor rows:
-  // 114 -> 20.4 MB fetched per launch (total 188 -> 94.3 MB = 1.005 x the algorithmic 93.8 MB), same 70 us -- the FP64 chain
-  // bounds the kernel, not its bytes (profiles/r04_rollout_stage_* vs r04_rollout_nostage_*)
+  // lane-private LDS staging of the action rows (DITREE_ROLLOUT_STAGE=0 turns it off; needs 16-byte aligned rows): 65 536 x 16,
+  // candidate-minor rows: 114 -> 20.4 MB fetched per launch (total 188 -> 94.3 MB = 1.005 x the algorithmic 93.8 MB), and no
+  // global load or vmcnt wait left inside the step loop (profiles/r04_rollout_stage_* vs r04_rollout_nostage_*, NOTES.md)
   static int stage_env = -1;
   if (stage_env < 0) { const char* e = getenv("DITREE_ROLLOUT_STAGE"); stage_env = e ? atoi(e) : 1; }
-  const int stage = stage_env && (act_stride % 2 == 0) && (cs.actions_in % 2 == 0) && ((uintptr_t)actions % 16 == 0) ? 1 : 0;
+  int stage = stage_env && (act_stride % 2 == 0) && (cs.actions_in % 2 == 0) && ((uintptr_t)actions % 16 == 0) ? 1 : 0;
   // work-group size: one wave per group spreads a small batch over many CUs (1 024 candidates: 16 CUs instead of 4); once
   // every SIMD has a wave anyway, four waves per group share one staged maze.  NOT two: 65 536 x 16 steps take 64.0 us in groups
   // of 128 threads against 50.5 (256) and 51.2 (64) -- profiles/r04_rollout_blocksize_probe.json; two-wave groups do not spread
@@ -537,15 +537,19 @@ void launch_car_rollout_ex(const unsigned char* maze, int rows, int cols, double
   static int blk_env = -1;
   if (blk_env < 0) { const char* e = getenv("DITREE_ROLLOUT_BLK"); blk_env = e ? atoi(e) : 0; }
   const int blk = (blk_env == 64 || blk_env == 128 || blk_env == 256) ? blk_env : (B >= 16384 ? 256 : 64);
-  static bool attr_done = false;
+  static bool attr_done_dev[64] = {};                        // the attribute is per kernel AND per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const bool attr_done = dev >= 0 && dev < 64 && attr_done_dev[dev];
   if (!attr_done) {                                          // 256 threads x 256 B of staged actions + the maze exceed 64 KB
     const hipFuncAttribute at = hipFuncAttributeMaxDynamicSharedMemorySize;
-    (void)hipFuncSetAttribute((const void*)car_rollout_kernel<1, true, true>, at, 96 * 1024);
-    (void)hipFuncSetAttribute((const void*)car_rollout_kernel<1, false, true>, at, 96 * 1024);
-    (void)hipFuncSetAttribute((const void*)car_rollout_kernel<2, true, true>, at, 96 * 1024);
-    (void)hipFuncSetAttribute((const void*)car_rollout_kernel<2, false, true>, at, 96 * 1024);
-    attr_done = true;
+    (void)hipFuncSetAttribute((const void*)car_rollout_kernel<1, true, true>, at, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)car_rollout_kernel<1, false, true>, at, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)car_rollout_kernel<2, true, true>, at, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)car_rollout_kernel<2, false, true>, at, 160 * 1024);
+    if (dev >= 0 && dev < 64) attr_done_dev[dev] = true;
   }
+  if (lds + (size_t)blk * 256 > 160 * 1024) stage = 0;        // a maze that leaves no room for the staged actions: per-step loads
   // lanes per candidate, measured on MI355X (profiles/r03_rollout_lanes.json): 8 192 candidates x 8 steps 31.6 -> 26.2 us with
   // two lanes (the batch fills a quarter of the SIMDs: the second lane's wave is free), 65 536 x 16 steps 73.2 -> 80.0 us
   // (every SIMD already has a wave; the duplicated dynamics cost more than the shorter chain saves).  DITREE_ROLLOUT_LANES
