@@ -147,6 +147,65 @@ def test_car_rollout_layouts_agree(ctx):
     assert np.array_equal(outs["soa"][0] & 0xFF, ref["status"]) and np.abs(outs["soa"][1] - ref["states"]).max() < 1e-9
 
 
+def _misaligned(a):
+    """The same values in a buffer whose first element sits 8 bytes off a 16-byte boundary: the rollout kernels then read their
+    action rows step by step from global memory instead of staging them in LDS in one burst (16-byte loads need the alignment)."""
+    buf = torch.zeros(a.numel() + 3, dtype=torch.float64, device="cuda")
+    off = 1 if buf.data_ptr() % 16 == 0 else 2
+    v = buf[off:off + a.numel()].view(a.shape)
+    v.copy_(a)
+    assert v.data_ptr() % 16 == 8 and v.is_contiguous()
+    return v
+
+
+@pytest.mark.parametrize("T", [16, 21, 40])
+def test_car_rollout_staged_actions_equal_per_step_loads(ctx, T):
+    """The burst-staged action rows (16 steps per burst: refills at steps 16 and 32, clamped loads past the last step when T is
+    not a multiple of 16) against the per-step loads of a misaligned buffer, both layouts, bit for bit -- and against the oracle."""
+    rng = np.random.default_rng(3)
+    maze = load_maze("boxes")
+    ctx.upload_maze(maze)
+    B = 4500
+    free = np.argwhere(maze[1:-1, 1:-1] == 0) + 1
+    cell = free[rng.integers(0, len(free), B)]
+    s0 = np.stack([(cell[:, 1] + 0.5) - 10 + rng.uniform(-0.25, 0.25, B), 10 - (cell[:, 0] + 0.5) + rng.uniform(-0.25, 0.25, B),
+                   rng.uniform(-np.pi, np.pi, B), rng.uniform(0, 2, B), rng.uniform(0, 0.5, B), rng.uniform(-0.4, 0.4, B)], axis=1)
+    act = np.stack([rng.normal(0.2, 1.0, (B, T)), rng.normal(0.0, 0.92, (B, T))], axis=2).copy()
+    goal = np.array([7.5, 7.5])
+    ref = G.rollout_chunk(s0, act, maze, goal, T)
+    a_al = dev(act)
+    assert a_al.data_ptr() % 16 == 0
+    for layout in ("rows", "soa"):
+        outs = []
+        for a in (a_al, _misaligned(a_al)):
+            st = dev(s0.copy())
+            status, states, aout, steps = ctx.car_rollout(st, a, goal, A=T, layout=layout)
+            outs.append([t.cpu().numpy() for t in (status, states, aout, steps, st)])
+        for x, y in zip(*outs):
+            assert np.array_equal(x, y)
+        assert np.array_equal(outs[0][0] & 0xFF, ref["status"]) and np.array_equal(outs[0][3], ref["n_steps"])
+        assert np.abs(outs[0][1] - ref["states"]).max() < 1e-9 and np.array_equal(outs[0][2], ref["actions"])
+    assert (ref["n_steps"] > 16).sum() > 50 or T <= 16               # edges that live through a refill
+
+
+def test_ant_rollout_staged_actions_equal_per_step_loads(ctx):
+    """The ant kernel stages four steps per burst: T = 10 (two refills, clamped loads in the last burst), aligned against
+    misaligned action rows, bit for bit."""
+    B, T = 2500, 10
+    maze, s0, acts = _model_inputs(B, T)
+    desired = np.array([25.0, 25.0])
+    ctx.upload_maze(maze)
+    a_al = dev(acts)
+    outs = []
+    for a in (a_al, _misaligned(a_al)):
+        st = dev(s0.copy())
+        status, states, aout, steps = ctx.ant_rollout(st, a, desired, A=T, model=True, layout="soa")
+        outs.append([t.cpu().numpy() for t in (status, states, aout, steps, st)])
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+    assert (outs[0][3] == T).sum() > 100
+
+
 # ------------------------------------------------------------------------------------------ B = 1 engine = the reference planner
 def _engine(ctx, g, pre, m, batch, dynamics, **kw):
     from ditreeonlineplanner_amd.engine import AntExpansionEngine
