@@ -114,7 +114,7 @@ def pmc_traffic(kernel, precision="bf16"):
     gfx950 + WRITE_SIZE; profiles/run_profiles.sh + profiles/summarize.py).  Counters cannot be read inside a timed run, so
     this is the RECORDED figure of the same command (same precision), marked as such, or null when no summary is committed."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(here, "profiles", f"{rnd}_{precision}_pmc_traffic.json")
         try:
             with open(path) as f:
