@@ -56,6 +56,11 @@ struct ConvGemmParams {
   // contiguous range of K-steps and writes its partial f32 tile to Out + y * slab_stride elements
   int splitk;
   long long slab_stride;
+  // split-K of the halo kernel (latency mode, small batches): gridDim.y = splitk work-groups share a tile, each walks nv / splitk
+  // channel chunks and dumps its f32 accumulators to sk_ws[(y * tiles + tile) * 65536]; the last one to arrive (sk_cnt[tile])
+  // adds the slabs in split order -- one fixed order whoever arrives last -- and runs the epilogue
+  float* sk_ws;
+  int* sk_cnt;
   // f16 range guard: device flag word of this layer (set to 1 by any thread that stores a value beyond +-65504; null = off).
   // Only the f16 instantiations look at it.
   int* sat;

@@ -138,7 +138,36 @@ struct DenoiserState {
   bool prof_chain = false;
   std::vector<ProfRec> prof_pairs;                           // (start event, end event, kind, flops) per launch
   void note_other() { close_run(); prof_chain = false; }     // call BEFORE enqueueing the other kernel
-  void run_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
+  // Latency mode (DITREE_DENOISE_SPLITK=1, read per call; opt-in): below ~ 256 candidates a layer is a handful of 256 x 256 tiles
+  // and the K loop of ONE tile (up to 384 K-steps) is the layer's latency while most CUs idle.  The 3-tap convs of the split
+  // formats then run `splitk` work-groups per tile (each a contiguous share of the channel chunks), the last one adds the partial
+  // accumulators in split order and runs the fused epilogue.  Deterministic, but NOT bit-identical to the one-pass sum: with
+  // the mode on, a sample's result depends on whether its batch was small enough to split -- which is why it is opt-in and why
+  // a sharded planner must switch it by its GLOBAL batch.
+  float* sk_ws = nullptr;
+  int* sk_cnt = nullptr;
+  static constexpr int SK_MAX_SLABS = 512;                   // 512 x 256 KB = 128 MB of partial tiles
+  int pick_splitk(const ConvGemmParams& p, int fmt) {
+    const char* e = getenv("DITREE_DENOISE_SPLITK");
+    if (!e || atoi(e) == 0 || !fmt_split(fmt) || conv_gemm_kind(p, fmt) != 0) return 1;
+    const int tiles = (p.M >> 8) * (p.N >> 8), nvc = p.Cin >> 5;
+    int sk = 1;
+    // more work-groups only while the chip is mostly idle: every split adds a 256 KB partial tile to write and read back.
+    // Measured (profiles/r04_splitk_latency_probe.json): a denoiser call of 1 / 16 / 64 / 128 samples 6.8 -> 4.9 / 4.9 / 5.0 / 6.2 ms
+    // with at most 64 work-groups per layer; 128 or 256 are slower again
+    static const int cap = [] { const char* c = getenv("DITREE_DENOISE_SPLITK_WGS"); return c ? atoi(c) : 64; }();
+    while (sk < 16 && tiles * (sk * 2) <= cap && tiles * (sk * 2) <= SK_MAX_SLABS && nvc % (sk * 2) == 0 && nvc / (sk * 2) >= 2) sk *= 2;
+    return sk;
+  }
+  void run_gemm(const ConvGemmParams& p_in, int fmt, hipStream_t s) {
+    ConvGemmParams p = p_in;
+    if (const int sk = pick_splitk(p, fmt); sk > 1) {
+      if (sk_ws == nullptr) {
+        sk_ws = (float*)dalloc((size_t)SK_MAX_SLABS * 65536 * sizeof(float), false);
+        sk_cnt = (int*)dalloc(SK_MAX_SLABS * sizeof(int));
+      }
+      p.splitk = sk; p.sk_ws = sk_ws; p.sk_cnt = sk_cnt;
+    }
     // shape contract of the tiles (split formats exist on the halo / gemm16 / small-Conv2d tiles only): an error, not an abort
     if (!conv_gemm_supported(p, fmt))
       throw std::runtime_error("denoiser layer of shape M " + std::to_string(p.M) + " x N " + std::to_string(p.N) + " x K " +
@@ -221,6 +250,8 @@ struct DenoiserState {
   void free_workspace() {
     for (void* p : allocs) hipFree(p);
     allocs.clear();
+    sk_ws = nullptr;                   // (allocated through dalloc: freed with the rest)
+    sk_cnt = nullptr;
     named.clear();
     dev_w.clear();
     dev_f.clear();

@@ -1233,7 +1233,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
 //     -- wait, barrier, read-ahead of the next step's A_hi / W_lo(0) --   P6 A_lo x W_hi(1) + the LDS-DMA issue.
 //   The small cross terms are accumulated first.
 // =================================================================================================
-template <int ET, bool SHORT = false>
+template <int ET, bool SHORT = false, bool SPLITK = false>
 __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int A_BUF = 40960, W_BUF = 32768, W_BASE = 2 * A_BUF;
@@ -1247,7 +1247,10 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   const int tm = tile / ntn, tn = tile - tm * ntn;
   const int L = p.L, Lp = p.in_Lp, S = 256 / L;
   const int a_rows = S * Lp;
-  const int nv = p.Cin >> 5;                                         // 32-channel chunks
+  const int nv_all = p.Cin >> 5;                                     // 32-channel chunks
+  // SPLITK (latency mode): this work-group walks chunks [v_lo, nv) of the layer's nv_all (host: splitk | nv_all, >= 2 each)
+  const int v_lo = SPLITK ? (int)blockIdx.y * (nv_all / p.splitk) : 0;
+  const int nv = SPLITK ? v_lo + nv_all / p.splitk : nv_all;
   const long long K = 3LL * p.Cin;
   const unsigned a_plane = (unsigned)p.a_plane, w_plane = (unsigned)p.w_plane;
 
@@ -1443,15 +1446,15 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   const unsigned long long xs0 = __builtin_amdgcn_s_memrealtime();
 #endif
 #pragma unroll
-  for (int i = 0; i < 5; ++i) issue_a(0, i);
+  for (int i = 0; i < 5; ++i) issue_a(v_lo, i);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) issue_w(0, 0, q);
+  for (int q = 0; q < 4; ++q) issue_w(v_lo, 0, q);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) issue_w(0, 1, q);
-  rdA(0, 0, 0, 0);
-  rdB(0, 0, 0, 1, 0);
+  for (int q = 0; q < 4; ++q) issue_w(v_lo, 1, q);
+  rdA(0, v_lo, 0, 0);
+  rdB(0, v_lo, 0, 1, 0);
 #ifdef HALO16_STAMP
   const unsigned long long xs1 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1460,7 +1463,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   // x 4] [P4 of (v,1): A(v+1)[3,4]] [(v,1): W(v+1,0) x 4] [(v,2): W(v+1,1) x 4] ...  The barrier of a step needs the W
   // pieces requested behind the previous barrier -- what was requested after them may stay in flight: vmcnt(3) at T = 0,
   // vmcnt(2) at T = 1 -- and the barrier of T = 2 the whole activation stage of the next chunk: vmcnt(0).
-  for (int v = 0; v < nv - 2; ++v) {
+  for (int v = v_lo; v < nv - 2; ++v) {
     step(I0{}, Tt{}, Tt{}, Tt{}, I3{}, v);
     step(I1{}, Tt{}, Tt{}, Tt{}, I2{}, v);
     step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, v);
@@ -1489,6 +1492,35 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
 #ifdef HALO16_STAMP
   const unsigned long long xs2 = __builtin_amdgcn_s_memrealtime();
 #endif
+  if constexpr (SPLITK) {
+    const int ntiles = ntm * ntn;
+    float* mine = p.sk_ws + ((size_t)blockIdx.y * ntiles + tile) * 65536;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *(f32x4_t*)(mine + ((mb * 8 + j) * 512 + tid) * 4) = acc[mb][j];
+    __threadfence();                                          // the slab is visible device-wide before the arrival is counted
+    __syncthreads();
+    int* s_last = (int*)smem;
+    if (tid == 0) *s_last = atomicAdd(p.sk_cnt + tile, 1) == p.splitk - 1;
+    __syncthreads();
+    const bool last = *s_last != 0;
+    __syncthreads();                                          // smem is the epilogue's from here on
+    if (!last) return;
+    __threadfence();
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[mb][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < p.splitk; ++sp) {                   // split order: the sum does not depend on who arrived last
+      const float* sl = p.sk_ws + ((size_t)sp * ntiles + tile) * 65536;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[mb][j] += *(const f32x4_t*)(sl + ((mb * 8 + j) * 512 + tid) * 4);
+    }
+    if (tid == 0) p.sk_cnt[tile] = 0;                         // ready for the next launch on this stream
+  }
   gemm_epilogue16<ET, true, SHORT>(p, acc, smem, tm, tn, tid, lane, r4, h4, wm, wn);
 #ifdef HALO16_STAMP
   __syncthreads();
@@ -1936,6 +1968,10 @@ static void ensure_lds_attrs() {
   hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<1>, at, 147456);
   hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<0, true>, at, 147456);
   hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<1, true>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<0, false, true>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<1, false, true>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<0, true, true>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<1, true, true>, at, 147456);
   hipFuncSetAttribute((const void*)gemm16_kernel<0, false>, at, 131072);
   hipFuncSetAttribute((const void*)gemm16_kernel<1, false>, at, 131072);
   hipFuncSetAttribute((const void*)gemm16_kernel<0, true>, at, 131072);
@@ -1953,6 +1989,17 @@ void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
   const int ntn = (p.N + 255) >> 8, ntm = (p.M + 255) >> 8;
   const dim3 grid(ntm * ntn), block(512);
   if (halo_eligible(p, fmt)) {
+    if (split && p.splitk > 1) {                              // latency mode: gridDim.y work-groups per tile (denoise.h)
+      if (p.sk_ws == nullptr || p.sk_cnt == nullptr || ((p.Cin >> 5) % p.splitk) != 0 || (p.Cin >> 5) / p.splitk < 2)
+        throw std::runtime_error("conv_gemm: split-K of the halo kernel needs its workspace and splitk | Cin / 32, >= 2 chunks each");
+      const dim3 gsk(ntm * ntn, p.splitk);
+      if (p.L == 8) {
+        if (f16) DN_LAUNCH((conv3_halo16x3_kernel<1, true, true>), gsk, block, 147456, s, p);
+        else DN_LAUNCH((conv3_halo16x3_kernel<0, true, true>), gsk, block, 147456, s, p);
+      } else if (f16) DN_LAUNCH((conv3_halo16x3_kernel<1, false, true>), gsk, block, 147456, s, p);
+      else DN_LAUNCH((conv3_halo16x3_kernel<0, false, true>), gsk, block, 147456, s, p);
+      return;
+    }
     if (split) {
       if (p.L == 8) {
         if (f16) DN_LAUNCH((conv3_halo16x3_kernel<1, true>), grid, block, 147456, s, p);

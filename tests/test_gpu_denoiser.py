@@ -191,6 +191,35 @@ def test_denoiser_layers_and_output(ctx, oracle_net, inputs, prec):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("prec", [2, 3])
+def test_latency_mode_split_k_keeps_the_layer_bounds(ctx, oracle_net, inputs, prec, monkeypatch):
+    """DITREE_DENOISE_SPLITK=1 (opt-in latency mode for small batches: several work-groups per tile of the 3-tap convs, partial
+    accumulators added in split order by the last one): every tapped layer and the output stay inside the same bounds against
+    the fp32 oracle, repeated calls give the same bits, and switching the mode off restores the one-pass result exactly."""
+    noise, lm, cond = inputs
+    B = noise.shape[0]
+    _bind(ctx, oracle_net, prec, B)
+    x1_ref, taps = _oracle_with_taps(oracle_net, noise, lm, cond)
+    plain = ctx.denoise(noise.cuda(), lm.cuda(), cond.cuda(), want_actions=False).cpu().numpy()
+    monkeypatch.setenv("DITREE_DENOISE_SPLITK", "1")
+    x1 = ctx.denoise(noise.cuda(), lm.cuda(), cond.cuda(), want_actions=False).cpu().numpy()
+    bad = []
+    for name, _ in LAYERS:
+        if name == "enc.pool":
+            continue
+        bad += check_close(ctx.debug_read(name, B).cpu().numpy(), tap_to_blc(taps[name].numpy(), B), TOL[prec], name)
+    bad += check_close(x1, x1_ref, TOL[prec], "x1")
+    assert not bad, bad
+    again = ctx.denoise(noise.cuda(), lm.cuda(), cond.cuda(), want_actions=False).cpu().numpy()
+    assert np.array_equal(again, x1)                                   # deterministic: fixed summation order
+    _bind(ctx, oracle_net, prec, B + 200)                               # a larger reservation rebuilds the workspace (and the partial-tile slabs)
+    assert np.array_equal(ctx.denoise(noise.cuda(), lm.cuda(), cond.cuda(), want_actions=False).cpu().numpy(), x1)
+    assert not np.array_equal(x1, plain)                               # (the mode really ran: another summation order)
+    assert np.abs(x1 - plain).max() < 2e-5 * max(1.0, float(np.abs(plain).max()))
+    monkeypatch.setenv("DITREE_DENOISE_SPLITK", "0")
+    assert np.array_equal(ctx.denoise(noise.cuda(), lm.cuda(), cond.cuda(), want_actions=False).cpu().numpy(), plain)
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_one_corrupted_element_is_caught(ctx, oracle_net, inputs, prec):
     """The bounds must see a single wrong element per layer (round 1 recorded a kernel variant with exactly that defect
