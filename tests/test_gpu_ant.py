@@ -69,7 +69,8 @@ def ant_net():
 
 # Per-layer bounds as for the car network (tests/test_gpu_denoiser.py): relative L2, max|err| / rms and an element-wise bound
 # with no violation allowed, per tapped layer and on the flow-step output.  The ant levels L = 8 and L = 4 run other kernels
-# than the car's (plain-store gemm16_kernel / conv_gemm_kernel + gn1d_short_kernel), so they carry their own measured numbers:
+# than the car's (the SHORT epilogue of gemm16_kernel / conv3_halo16x3_kernel on the 16-bit tiles; conv_gemm_kernel +
+# gn1d_short_kernel for f32 and for batches that do not fill a tile), so they carry their own measured numbers:
 # gpurun_out/ant_layers_prec*.json (committed as profiles/r03_ant_layers.json); bounds = the car's, times ANT_SCALE.
 from tests.test_gpu_denoiser import LAYERS, TOL, _oracle_with_taps, check_close, err_stats, tap_to_blc  # noqa: E402
 
