@@ -317,17 +317,18 @@ void launch_path_after_obstacle(const float* path, int stride, int P, double cx,
 // ------------------------------------------------------------------------- rollout
 // planners/base_planner.py:257-320 + car_env.py:240-282,341-396 + common/map_utils.py:103-115 for a batch of candidates.
 // One lane per candidate: the A Euler steps with their goal + two-ball collision tests are a sequential FP64 chain of
-// ~1 200 instructions per step (3 sin / cos pairs, tanh, 9 sqrt / hypot).  Work-group size by batch (launcher): one wave
+// ~ 800 instructions per step (2 sincos, cos, tanh, 2 hypot, sqrt; round 3: 1 200).  Work-group size by batch (launcher): one wave
 // per group spreads a small batch over many CUs (the round's 1 024 candidates: 16 CUs instead of 4), 256 threads once every
 // SIMD has a wave anyway.
-//   The kernel is bound by that FP64 chain with one wave per SIMD, not by HBM: 65 536 x 16 steps take 68 us = 1.0 TB/s of
-//   algorithmic bytes (13 % of peak); rocprofv3 counters (profiles/r02_rollout_*): 57 % of the wave cycles issue
-//   instructions, 38 % wait on memory, 227 MB cross the fabric for 71 MB of algorithmic bytes (the per-lane 16..48-byte
-//   fragments at strides of hundreds of bytes touch a line each).  Two rewrites aimed at that traffic were measured and
-//   dropped: wave-cooperative LDS-staged action loads + (A + 1, 6)-row stores (every candidate's rows leave as one
-//   contiguous run; 100 us: each of its 12 barriers exposes a full memory latency to the only wave of the SIMD and the
-//   index arithmetic of the wave-wide copies adds a third to the instruction count) and register prefetch of the next four
-//   steps' actions (74 us).  What would help is a second wave per SIMD (two lanes per candidate, one ball each) -- DESIGN.md.
+//   The kernel is bound by that FP64 chain with one wave per SIMD (dependent FP64 instructions, ~ 8 cycles each), not by HBM:
+//   65 536 x 16 steps take 41.6 us with candidate-minor rows, 35.6 us without any row stores (round 3: 66.6 us); HBM-side
+//   traffic 94.3 MB for 93.8 MB of algorithmic bytes (round 3: 214 MB).  What it took, each step measured on its own
+//   (profiles/NOTES.md): lockstep stores of candidate-minor rows; the action rows staged per lane in LDS by
+//   one burst of loads per 16 steps and an explicit vmcnt(0) in front of the step loop (vmcnt counts stores: any wait for a load
+//   inside the loop also waited for the previous step's row stores); one sincos per sin / cos pair, the nearest-corner test,
+//   branch-free cell tests, tanh through expm1 (car_device.h, fp64_device.h).  Measured and dropped: wave-cooperative LDS staging
+//   with barriers (100 us), register prefetch of the next steps' actions, software-pipelined steps, a wave-specialised two-wave
+//   form, work-groups of 128 threads (+ 27 %).
 // G lanes per candidate (1 or 2).  G = 2: both lanes of a pair integrate the (identical) dynamics, lane g tests ball g and the
 // pair ORs by one lane exchange, lane 0 stores the state rows and lane 1 the action rows -- twice the waves for the same batch
 // (two per SIMD at 65 536 candidates), each with a shorter chain per step.  Same arithmetic, same results.
