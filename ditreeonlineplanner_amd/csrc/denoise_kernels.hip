@@ -663,8 +663,8 @@ __device__ __forceinline__ void gemm_epilogue16(const ConvGemmParams& p, f32x4_t
   // 16-row block mb of this wave: tile rows wm*64 + mb*16 .. +15.  16 | L: the block lies inside one sample.  L = 8, 4 (the ant
   // config's lower levels): the block holds 2 / 4 samples, but the four rows 4*h4 .. 4*h4 + 3 a LANE owns are consecutive
   // positions of ONE sample (4 | L): sample blk_b + lane_b, first position blk_l + 4*h4 + lane_l with the per-lane offsets below
-  // (L | 16, so they do not depend on the block).  SHORT is its own instantiation (gemm16_kernel only): the 16 | L kernels
-  // have no registers to spare for it.
+  // (L | 16, so they do not depend on the block).  SHORT is its own instantiation (gemm16_kernel at L = 8 / 4, the split halo
+  // kernel at L = 8): the 16 | L kernels have no registers to spare for it.
   constexpr bool short_l = SHORT;
   const int lane_b = short_l ? (4 * h4) / p.L : 0, lane_l = -lane_b * p.L;
   int blk_b[4], blk_l[4];
