@@ -183,6 +183,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   return start + k;
 }
+// The same with the walk INSIDE an XCD's range shaped for its L2: the 32 work-groups an XCD runs at a time (one per CU) stream
+// the A panels of their tile rows and the W panels of their tile columns together.  With 8 tile columns (C_out = 2048, W panel
+// 6.3 MB, A panel 2.1 MB at K = 6144) a group of 4 rows x 8 columns pulls 4 A + 8 W panels = 59 MB through the L2, a group of
+// 8 rows x 4 columns 8 A + 4 W = 42 MB: the range is walked in strips of four tile columns.  (Needs whole tile rows per XCD;
+// anything else keeps the plain order.)  DITREE_XCD_STRIPS=0 on the host passes strips = 0.
+__device__ __forceinline__ int xcd_remap_strips(int bid, int ntm, int ntn, int strips) {
+  const int nwg = ntm * ntn;
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7, k = bid >> 3;
+  const int start = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  if (strips && r == 0 && ntn >= 8 && (ntn & 3) == 0 && (q % ntn) == 0) {
+    const int per = (q / ntn) * 4, strip = k / per, kk = k - strip * per;
+    return start + (kk >> 2) * ntn + strip * 4 + (kk & 3);
+  }
+  return start + k;
+}
 
 // ---- shared epilogue: bias, GroupNorm + Mish (+ FiLM | + residual), store ------------------------
 // acc[mb][j][i] of lane (r5, h), wave (wm, wn) holds tile row wm*64 + mb*32 + (i&3) + 8*(i>>2) + 4*h,
@@ -1243,7 +1258,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   const int wm = w >> 1, wn = w & 1;
   const int ntn = (p.N + 255) >> 8;
   const int ntm = (p.M + 255) >> 8;
-  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int tile = xcd_remap_strips(blockIdx.x, ntm, ntn, p.dbg);
   const int tm = tile / ntn, tn = tile - tm * ntn;
   const int L = p.L, Lp = p.in_Lp, S = 256 / L;
   const int a_rows = S * Lp;
