@@ -41,7 +41,7 @@ struct ConvGemmParams {
   const void* Res;    // residual, activation type
   int ldres, res_Lp, res_off;
   int out_f32;        // store f32 regardless of the activation type
-  int dbg;            // conv3_halo16x3_kernel: 1 = walk an XCD's tile range in strips of four tile columns (xcd_remap_strips)
+  int dbg;            // halo / gemm16 kernels: 1 = walk an XCD's tile range in strips of four tile columns (xcd_remap_strips)
   // implicit Conv2d on NHWC activations (c2d != 0): GEMM row m = (b, oh, ow); K = live taps x Cin
   // (Cin a multiple of 64: one tap spans Cin/64 K-steps); A is the input activation (B, H, W, Cin);
   // taps that fall outside the map read `zero` (>= 128 zero bytes).

@@ -162,7 +162,7 @@ struct DenoiserState {
   void run_gemm(const ConvGemmParams& p_in, int fmt, hipStream_t s) {
     ConvGemmParams p = p_in;
     static const int strips = [] { const char* e = getenv("DITREE_XCD_STRIPS"); return e ? atoi(e) : 1; }();
-    p.dbg = strips;                    // the split halo kernel walks an XCD's tiles in strips of four tile columns (xcd_remap_strips)
+    p.dbg = strips;                    // the halo / gemm16 kernels walk an XCD's tiles in strips of four tile columns (xcd_remap_strips)
     if (const int sk = pick_splitk(p, fmt); sk > 1) {
       if (sk_ws == nullptr) {
         sk_ws = (float*)dalloc((size_t)SK_MAX_SLABS * 65536 * sizeof(float), false);

@@ -993,7 +993,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
   const int wm = w >> 1, wn = w & 1;
   const int ntn = (p.N + 255) >> 8;
   const int ntm = (p.M + 255) >> 8;
-  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int tile = xcd_remap_strips(blockIdx.x, ntm, ntn, p.dbg);
   const int tm = tile / ntn, tn = tile - tm * ntn;
   const int L = p.L, Lp = p.in_Lp, S = 256 / L;
   const int a_rows = S * Lp;
@@ -1703,7 +1703,7 @@ __global__ void __launch_bounds__(512, 2) gemm16_kernel(ConvGemmParams p) {
   const int r4 = lane & 15, h4 = lane >> 4;
   const int wm = w >> 1, wn = w & 1;
   const int ntn = p.N >> 8, ntm = p.M >> 8;
-  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int tile = xcd_remap_strips(blockIdx.x, ntm, ntn, p.dbg);
   const int tm = tile / ntn, tn = tile - tm * ntn;
   // SPLIT (hi + lo planes): a K-step is 32 channels of one tap, an LDS row holds [32 ch hi | the same 32 ch lo] (slots
   // 0..3 / 4..7, chosen by the per-lane source offset) and the step runs the three products A_hi W_lo, A_hi W_hi, A_lo W_hi
