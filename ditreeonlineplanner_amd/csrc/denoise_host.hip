@@ -149,7 +149,7 @@ struct DenoiserState {
   static constexpr int SK_MAX_SLABS = 512;                   // 512 x 256 KB = 128 MB of partial tiles
   int pick_splitk(const ConvGemmParams& p, int fmt) {
     const char* e = getenv("DITREE_DENOISE_SPLITK");
-    if (!e || atoi(e) == 0 || !fmt_split(fmt) || conv_gemm_kind(p, fmt) != 0) return 1;
+    if (!e || atoi(e) == 0 || !fmt_split(fmt) || p.L == 4 || conv_gemm_kind(p, fmt) != 0) return 1;   // (L = 4: no split-K form)
     const int tiles = (p.M >> 8) * (p.N >> 8), nvc = p.Cin >> 5;
     int sk = 1;
     // more work-groups only while the chip is mostly idle: every split adds a 256 KB partial tile to write and read back.

@@ -1248,10 +1248,13 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16_kernel(ConvGemmParams p) 
 //     -- wait, barrier, read-ahead of the next step's A_hi / W_lo(0) --   P6 A_lo x W_hi(1) + the LDS-DMA issue.
 //   The small cross terms are accumulated first.
 // =================================================================================================
-template <int ET, bool SHORT = false, bool SPLITK = false>
+template <int ET, bool SHORT = false, bool SPLITK = false, int NP = 5>
 __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int A_BUF = 40960, W_BUF = 32768, W_BASE = 2 * A_BUF;
+  // NP staging pieces of 64 rows: 5 hold the 256 + 2 S <= 320 padded rows of a tile at L >= 8; L = 4 (64 samples x 6 padded rows =
+  // 384) takes a sixth -- 2 x 48 KB of activations + 2 x 32 KB of weights = all 160 KB of LDS
+  static_assert(NP == 5 || NP == 6, "five or six activation pieces");
+  constexpr int A_BUF = NP * 8192, W_BUF = 32768, W_BASE = 2 * A_BUF;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r4 = lane & 15, h4 = lane >> 4;
@@ -1269,7 +1272,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   const long long K = 3LL * p.Cin;
   const unsigned a_plane = (unsigned)p.a_plane, w_plane = (unsigned)p.w_plane;
 
-  unsigned pa0, pa4, pbe, pbo;
+  unsigned pa0, pa4, pa5 = 0, pbe, pbo;
   const char* const a_base = (const char*)p.A + ((long long)tm * S * Lp + p.in_off) * p.lda * 2;
   const char* const w_base = (const char*)p.W + ((long long)tn * 256) * K * 2;
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 0x7fffffff, 0x00020000);
@@ -1282,6 +1285,11 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
     const int r4r = r + 256;
     const int rs = r4r < a_rows ? r4r : a_rows - 1;
     pa4 = (unsigned)((rs * p.lda + (slot & 3) * 8) * 2) + po;
+    if constexpr (NP == 6) {
+      const int r5r = r + 320;
+      const int rs5 = r5r < a_rows ? r5r : a_rows - 1;
+      pa5 = (unsigned)((rs5 * p.lda + (slot & 3) * 8) * 2) + po;
+    }
   }
   const int a_piece = 64 * p.lda * 2;
   long long wq[4];
@@ -1301,7 +1309,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   const int w_tap = p.Cin * 2;
   auto issue_a = [&](int v, int i) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (LDS_AS void*)(smem + (v & 1) * A_BUF + (w + 8 * i) * 1024), 16,
-                                             i < 4 ? pa0 : pa4, v * 64 + (i < 4 ? i * a_piece : 0), 0, 0);
+                                             i < 4 ? pa0 : (i == 4 ? pa4 : pa5), v * 64 + (i < 4 ? i * a_piece : 0), 0, 0);
   };
   auto issue_w = [&](int v, int t, int q) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (LDS_AS void*)(smem + W_BASE + ((v + t) & 1) * W_BUF + (w * 4 + q) * 1024),
@@ -1402,13 +1410,13 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
     mm16(1, 0, 0);                      // P4: A_lo x W_hi(0) + the activation pieces of chunk v+1 (T = 0: 0..2, T = 1: 3, 4)
     if constexpr (ISSUE_A && T != 2) {
       if constexpr (T == 0) { issue_a(v + 1, 0); issue_a(v + 1, 1); issue_a(v + 1, 2); }
-      else { issue_a(v + 1, 3); issue_a(v + 1, 4); }
+      else { issue_a(v + 1, 3); issue_a(v + 1, 4); if constexpr (NP == 6) issue_a(v + 1, 5); }
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 2);
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 2);
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 2);
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 2);
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 2);
-      if constexpr (T == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 2);
+      if constexpr (T == 0 || NP == 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 2);
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 2);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1461,7 +1469,7 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   const unsigned long long xs0 = __builtin_amdgcn_s_memrealtime();
 #endif
 #pragma unroll
-  for (int i = 0; i < 5; ++i) issue_a(v_lo, i);
+  for (int i = 0; i < NP; ++i) issue_a(v_lo, i);
 #pragma unroll
   for (int q = 0; q < 4; ++q) issue_w(v_lo, 0, q);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1478,9 +1486,10 @@ __global__ void __launch_bounds__(512, 2) conv3_halo16x3_kernel(ConvGemmParams p
   // x 4] [P4 of (v,1): A(v+1)[3,4]] [(v,1): W(v+1,0) x 4] [(v,2): W(v+1,1) x 4] ...  The barrier of a step needs the W
   // pieces requested behind the previous barrier -- what was requested after them may stay in flight: vmcnt(3) at T = 0,
   // vmcnt(2) at T = 1 -- and the barrier of T = 2 the whole activation stage of the next chunk: vmcnt(0).
+  using IT1 = std::integral_constant<int, NP == 6 ? 3 : 2>;      // activation pieces requested in P4 of T = 1
   for (int v = v_lo; v < nv - 2; ++v) {
     step(I0{}, Tt{}, Tt{}, Tt{}, I3{}, v);
-    step(I1{}, Tt{}, Tt{}, Tt{}, I2{}, v);
+    step(I1{}, Tt{}, Tt{}, Tt{}, IT1{}, v);
     step(I2{}, Tt{}, Tt{}, Tt{}, I0{}, v);
   }
 #ifdef X3_PHASE_STAMP
@@ -1950,9 +1959,11 @@ static bool gemm16_eligible(const ConvGemmParams& p, int fmt) {
 static bool halo_eligible(const ConvGemmParams& p, int fmt) {
   // L = 8 (the ant network's middle level, split formats): a tile's 32 samples x 10 padded rows are exactly the 320 rows the
   // five staging pieces hold; the fragment rows are per-lane offsets already (lrow0), the epilogue is the SHORT instantiation.
-  // L = 4 would need 384 staged rows (a sixth piece, 160 KB of LDS): it stays on gemm16_kernel.
-  static const bool l8_off = [] { const char* e = getenv("DITREE_HALO_L8"); return e && atoi(e) == 0; }();   // A/B switch
-  const bool l_ok = p.L >= 16 || (p.L == 8 && fmt_split(fmt) && !l8_off);
+  // L = 4: 64 samples x 6 padded rows = 384 staged rows, the six-piece instantiation (all 160 KB of LDS; no split-K form).
+  // DITREE_HALO_L8=0 / DITREE_HALO_L4=0 send these levels back to gemm16_kernel (A/B switches).
+  static const bool l8_off = [] { const char* e = getenv("DITREE_HALO_L8"); return e && atoi(e) == 0; }();
+  static const bool l4_off = [] { const char* e = getenv("DITREE_HALO_L4"); return e && atoi(e) == 0; }();
+  const bool l_ok = p.L >= 16 || (p.L == 8 && fmt_split(fmt) && !l8_off) || (p.L == 4 && fmt_split(fmt) && !l4_off && p.splitk <= 1);
   return fmt_st(fmt) != ST_F32 && !p.c2d && p.taps == 3 && p.in_stride == 1 && p.in_Lp == p.L + 2 && (256 % p.L) == 0 &&
          l_ok && (p.M & 255) == 0 && (p.N & 255) == 0 && (p.Cin & 63) == 0 && p.Cin >= 192;
 }
@@ -1987,6 +1998,8 @@ static void ensure_lds_attrs() {
   hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<1, false, true>, at, 147456);
   hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<0, true, true>, at, 147456);
   hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<1, true, true>, at, 147456);
+  hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<0, true, false, 6>, at, 163840);
+  hipFuncSetAttribute((const void*)conv3_halo16x3_kernel<1, true, false, 6>, at, 163840);
   hipFuncSetAttribute((const void*)gemm16_kernel<0, false>, at, 131072);
   hipFuncSetAttribute((const void*)gemm16_kernel<1, false>, at, 131072);
   hipFuncSetAttribute((const void*)gemm16_kernel<0, true>, at, 131072);
@@ -2013,6 +2026,11 @@ void launch_conv_gemm(const ConvGemmParams& p, int fmt, hipStream_t s) {
         else DN_LAUNCH((conv3_halo16x3_kernel<0, true, true>), gsk, block, 147456, s, p);
       } else if (f16) DN_LAUNCH((conv3_halo16x3_kernel<1, false, true>), gsk, block, 147456, s, p);
       else DN_LAUNCH((conv3_halo16x3_kernel<0, false, true>), gsk, block, 147456, s, p);
+      return;
+    }
+    if (split && p.L == 4) {                                  // six activation pieces: all 160 KB of LDS
+      if (f16) DN_LAUNCH((conv3_halo16x3_kernel<1, true, false, 6>), grid, block, 163840, s, p);
+      else DN_LAUNCH((conv3_halo16x3_kernel<0, true, false, 6>), grid, block, 163840, s, p);
       return;
     }
     if (split) {

@@ -49,12 +49,13 @@ def test_halo_kernel_loop_has_no_scratch_traffic(tmp_path):
     subprocess.run([hipcc, "-S", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", src, "-o", str(out)],
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     text = out.read_text()
-    # every instantiation: <element type 0 bf16 / 1 f16, split 0 / 1>; for the split kernel also <SHORT (the L = 8 epilogue),
-    # SPLITK (latency mode)>.  (The epilogue has a loop of its own -- the FiLM rows going to LDS -- so the chunk loop is the one
+    # every instantiation: <element type 0 bf16 / 1 f16, split 0 / 1>; for the split kernel also <SHORT (the L = 8 / 4 epilogue),
+    # SPLITK (latency mode), NP (activation pieces: 5, or 6 at L = 4)>.  (The epilogue has a loop of its own -- the FiLM rows going to LDS -- so the chunk loop is the one
     # that holds the MFMAs.)  The default instantiations do not spill at all, which is asserted too (a spill in the epilogue
     # costs a store round trip per reload); the SHORT epilogue may spill a few registers OUTSIDE the chunk loop.
     cases = [(0, 0, "", "bf16"), (1, 0, "", "f16")]
-    cases += [(et, 1, f"ELb{sh}ELb{sk}", mf) for et, mf in ((0, "bf16"), (1, "f16")) for sh in (0, 1) for sk in (0, 1)]
+    cases += [(et, 1, f"ELb{sh}ELb{sk}ELi5", mf) for et, mf in ((0, "bf16"), (1, "f16")) for sh in (0, 1) for sk in (0, 1)]
+    cases += [(et, 1, "ELb1ELb0ELi6", mf) for et, mf in ((0, "bf16"), (1, "f16"))]      # six activation pieces (L = 4)
     for et, split, extra, mfma in cases:
         name = (f"_Z21conv3_halo16x3_kernelILi{et}{extra}EEv14ConvGemmParams:" if split
                 else f"_Z19conv3_halo16_kernelILi{et}ELb0EEv14ConvGemmParams:")
@@ -70,10 +71,10 @@ def test_halo_kernel_loop_has_no_scratch_traffic(tmp_path):
         loops = [lp for lp in loops if any("v_mfma" in l for l in lp)]
         assert len(loops) == 1, "expected exactly one loop with MFMAs (the chunk loop) in the halo kernel"
         loop = loops[0]
-        if extra in ("", "ELb0ELb0"):
+        if extra in ("", "ELb0ELb0ELi5"):
             assert not any("scratch_" in l for l in body), (et, split, extra, "register spills in the halo kernel")
         assert sum(f"v_mfma_f32_16x16x32_{mfma}" in l for l in loop) == (288 if split else 192)   # 3 K-steps x 64 (96: hi/lo) MFMAs
-        assert any("vmcnt(2)" in l for l in loop)
+        assert any(("vmcnt(3)" if extra.endswith("ELi6") else "vmcnt(2)") in l for l in loop)      # the counted wait of T = 1
         offenders = [l.strip() for l in loop if "scratch_" in l or re.search(r"\b(global|flat)_(load|store)", l)]
         assert not offenders, (et, split, extra, offenders)
 
