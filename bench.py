@@ -938,7 +938,7 @@ def run_ant_round(args):
                           "parallelism": f"candidates sharded x{world}, one {eng.tree.record_doubles * 8}-byte record all-gather per round"},
                "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                             **recorded_traffic("ant_round", prec),
-                            "kernel": "all MFMA kernels of the denoiser (L = 16 / 8: conv3_halo16x3_kernel, L = 4 and the strided / 1x1 layers: gemm16_kernel, GroupNorm fused; split formats: 3 MFMAs per product)",
+                            "kernel": "all MFMA kernels of the denoiser (3-tap convs at L = 16 / 8 / 4: conv3_halo16x3_kernel, strided / 1x1 / FiLM layers: gemm16_kernel, GroupNorm fused; split formats: 3 MFMAs per product)",
                             "per_kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
                             "algorithmic_gflop_per_candidate": 2.0 * mac * nC / 1e9,
                             "note": "events around every MFMA launch inside the timed region (costs a few %)"},
