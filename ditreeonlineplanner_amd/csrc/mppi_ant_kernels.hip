@@ -141,10 +141,19 @@ mppi_ant_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int co
     const int lo = max(ip - a.wback, 0), hi = min(ip + a.wfwd, a.P - 1);
     double best = __builtin_huge_val();
     int bi = lo;
-    for (int i = lo; i <= hi; ++i) {
-      const double dx = s_path[i].x - s[0], dy = s_path[i].y - s[1];
-      const double d = dx * dx + dy * dy;
-      if (d < best) { best = d; bi = i; }
+    // eight points per trip: independent LDS reads and distances, only the running minimum chains (one read-wait-compare
+    // round per point exposed the LDS latency 57 times per step); indices past `hi` are clamped for the read and masked
+    for (int i = lo; i <= hi; i += 8) {
+      double d[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const double2 pt = s_path[min(i + q, hi)];
+        const double dx = pt.x - s[0], dy = pt.y - s[1];
+        d[q] = dx * dx + dy * dy;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (i + q <= hi && d[q] < best) { best = d[q]; bi = i + q; }
     }
     ip = bi;
     cost = cost + a.w_track * best;

@@ -99,11 +99,20 @@ __device__ __forceinline__ void nearest_in_window(const double2* path, int lo, i
                                                   double& d2) {
   double best = __builtin_huge_val();
   int bi = 0x7fffffff;
-  for (int i = lo + g; i <= hi; i += G) {
-    const double2 p = path[i];
-    const double dx = p.x - x, dy = p.y - y;
-    const double d = dx * dx + dy * dy;
-    if (d < best) { best = d; bi = i; }
+  // four points per trip: their LDS reads and distances are independent (one read-wait-compare round per point left the LDS
+  // latency exposed 28 times per step -- the window search was the longest part of a controller step), only the running
+  // minimum chains; indices past `hi` are clamped for the read and masked for the compare
+  for (int i = lo + g; i <= hi; i += 4 * G) {
+    double d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double2 p = path[min(i + u * G, hi)];
+      const double dx = p.x - x, dy = p.y - y;
+      d[u] = dx * dx + dy * dy;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u * G <= hi && d[u] < best) { best = d[u]; bi = i + u * G; }
   }
   const double m = quad_min<G>(best);
   // first index attaining the minimum over the quad (ties -> lowest index)
@@ -163,11 +172,26 @@ mppi_rollout_kernel(const unsigned char* __restrict__ maze, int rows, int cols, 
   double cost = 0.0;
   int ip = i0;
   int flag = 0;                                        // 1 = reached the goal, 2 = collided
+  double n0 = 0.0, n1 = 0.0;                           // G >= 2: the noise this lane generated for step (t & ~1) + (g & 1)
   for (int t = 0; live && t < a.T; ++t) {
     double e0 = 0.0, e1 = 0.0;
     if (a.k0 + k > 0) {                                // GLOBAL rollout 0 is the noise-free nominal sequence
-      if (noise != nullptr) { e0 = noise[((size_t)k * a.T + t) * 2]; e1 = noise[((size_t)k * a.T + t) * 2 + 1]; }
-      else mppi_noise(a.seed, a.counter, a.k0 + k, t, a.s0, a.s1, e0, e1);
+      if (noise != nullptr) {
+        e0 = noise[((size_t)k * a.T + t) * 2]; e1 = noise[((size_t)k * a.T + t) * 2 + 1];
+      } else if constexpr (G >= 2) {
+        // the lanes of a rollout would all evaluate the same Box-Muller pair (log, sqrt, sincos: a quarter of the step): lane
+        // parity p generates the pair of step t + p on even t and hands it to its neighbour for the other step (the branches
+        // around this are uniform over the lanes of a rollout, so both partners always execute the exchange)
+        if ((t & 1) == 0) {
+          n0 = 0.0; n1 = 0.0;
+          if (t + (g & 1) < a.T) mppi_noise(a.seed, a.counter, a.k0 + k, t + (g & 1), a.s0, a.s1, n0, n1);
+        }
+        const double o0 = __shfl_xor(n0, 1), o1 = __shfl_xor(n1, 1);
+        const bool mine = (t & 1) == (g & 1);
+        e0 = mine ? n0 : o0; e1 = mine ? n1 : o1;
+      } else {
+        mppi_noise(a.seed, a.counter, a.k0 + k, t, a.s0, a.s1, e0, e1);
+      }
     }
     const double u0 = s_U[2 * t], u1 = s_U[2 * t + 1];
     car_euler_step(s, u0 + e0, u1 + e1);
