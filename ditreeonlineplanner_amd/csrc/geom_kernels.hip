@@ -61,13 +61,24 @@ nn_argmin_kernel(const double* __restrict__ queries, int q_stride, int B, const 
     best[k] = __builtin_huge_val();
     bidx[k] = 0x7fffffff;
   }
-  for (int i = lane; i < N; i += WAVE) {
-    double2 p = node_xy[i];
+  // eight nodes per trip: their loads are independent (one load - wait - compare round per node exposes a memory round trip
+  // N / 64 times: 1.1 ms of a round at 10^5 nodes), only the running minima chain; indices past N are clamped for the load and
+  // masked for the compare, the scan order per lane is unchanged (increasing index, strict '<': lowest index wins)
+  for (int i = lane; i < N; i += 8 * WAVE) {
+    double2 p[8];
 #pragma unroll
-    for (int k = 0; k < NN_QPW; ++k) {
-      double dx = qx[k] - p.x, dy = qy[k] - p.y;
-      double d = dx * dx + dy * dy;
-      if (d < best[k]) { best[k] = d; bidx[k] = i; }     // strict: keeps the lowest index per lane
+    for (int u = 0; u < 8; ++u) p[u] = node_xy[min(i + u * WAVE, N - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int iu = i + u * WAVE;
+      if (iu < N) {
+#pragma unroll
+        for (int k = 0; k < NN_QPW; ++k) {
+          double dx = qx[k] - p[u].x, dy = qy[k] - p[u].y;
+          double d = dx * dx + dy * dy;
+          if (d < best[k]) { best[k] = d; bidx[k] = iu; }     // strict: keeps the lowest index per lane
+        }
+      }
     }
   }
 #pragma unroll
